@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""DPD timesteps/s on the rho=4 cubic box (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 200            # 64^3, dpd/fast/meso (configs[2])
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full run_style mvv/meso timestep (NVE initial, ghost refresh, pair force, NVE final, and a
+neighbour rebuild every 5th step) over the whole box; inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4 copy: 6290 GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--box", type=int, default=64, help="cubic box edge L (N = 4 L^3)")
+    ap.add_argument("--style", default="dpd/fast/meso", choices=["dpd/meso", "dpd/fast/meso"])
+    ap.add_argument("--every", type=int, default=5, help="neigh_modify every")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--profile-steps", type=int, default=200)
+    return ap.parse_args()
+
+
+def cpu_baseline(L, x, v, lo, hi, every, steps):
+    """Stock LAMMPS CPU pair_style dpd restatement (oracle/lmp_dpd_cpu.c, golden-pinned) timed on the host
+    cores of this box: the same box, a bounded number of steps."""
+    from oracle import bindings as ob
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if steps <= 0:
+        # ~1.4 M particle-steps/s/core measured for the reference binary; aim at ~15 s
+        steps = int(max(5, min(200, 15.0 * 1.4e6 * cores * 0.6 / len(x))))
+        steps = max(every, steps // every * every)
+    s = ob.LmpDpd(x, lo, hi, nthreads=cores)
+    s.pair_style(1.0, 1.0, 419084618)
+    s.pair_coeff(1, 1, 15.0, 4.5)
+    s.set_velocities(v)
+    s.neighbor(0.3, every, 0)
+    s.timestep(0.005)
+    s.setup()
+    s.run(every, ev_last=False)          # warm caches / thread pool
+    t0 = time.perf_counter()
+    s.run(steps, ev_last=False)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "timesteps/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the same %d^3 rho=4 box (N=%d), rebuild every %d, OpenMP %d threads; "
+                      "oracle/lmp_dpd_cpu.c" % (steps, L, len(x), every, cores),
+            "M_particle_steps_per_s": steps * len(x) / dt / 1e6}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, a.gpus))
+
+    import torch
+    from meso_amd.api import Meso
+    from meso_amd.datagen import make_box
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        raise SystemExit("multi-GPU spatial decomposition is not wired into bench.py in this build")
+
+    L = a.box
+    x, v, lo, hi = make_box(L)
+    n = len(x)
+    m = Meso(local_rank)
+    m.read_atoms(x, v, lo, hi)
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=a.every, check=False)
+    m.pair_style(a.style, 1.0, 419084618)
+    m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    m.timestep(0.005)
+    m.setup()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        m.sync()
+        torch.cuda.synchronize()
+
+    m.run(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    m.run(a.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps_per_s = a.steps / elapsed
+
+    # ---- dominant kernel: pair force.  Average launch duration from HIP events recorded on the engine's
+    # stream around every launch of a second, profiled pass (events perturb the whole-step time, so they
+    # are kept out of the pass that produces `value`).
+    info = m.neigh_info()
+    m.set_option("profile", 1)
+    m.timer_reset()
+    m.run(a.profile_steps)
+    phases = {}
+    for name in ("pair", "neigh", "nve", "merge", "halo", "reorder", "bin", "total_steps"):
+        ms, calls = m.timer(name)
+        phases[name] = {"ms_per_call": ms / calls if calls else None, "calls": calls}
+    m.set_option("profile", 0)
+    t_pair = phases["pair"]["ms_per_call"] * 1e-3
+    w = 8  # forces are stored as fp64 in both styles
+    b_pair = n * (16 + 16 + 4 + 4.0 * info["avg_count"] + 3 * w)
+    achieved = b_pair / t_pair / 1e9
+    T = m.temperature()
+
+    line = {
+        "metric": "DPD timesteps/s, %d^3 rho=4 box" % L,
+        "value": steps_per_s,
+        "unit": "timesteps/s",
+        "n_gpus": a.gpus,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32" if a.style == "dpd/fast/meso" else "f64",
+        "data": "synthetic",
+        "config": {"workload": "%d^3 box rho=4 (N=%d), pair_style %s, neighbor 0.3 bin, rebuild every %d, dt 0.005, "
+                               "1 MI355X" % (L, n, a.style, a.every),
+                   "M_particle_steps_per_s": steps_per_s * n / 1e6,
+                   "avg_neighbors": info["avg_count"], "temperature_end": T},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_pair_dpd", "bytes_per_launch": b_pair, "us_per_launch": t_pair * 1e6},
+        "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
+    }
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(L, x, v, lo, hi, a.every, a.cpu_steps)
+        line["config"]["gpu_over_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
+    m.close()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+/* meso_hip.h - C ABI of libmeso_hip.so: the MI355X-native DPD hot path of LAMMPS' USER-MESO package.
+ *
+ * Drop-in boundary.  Each entry point names the reference interface it replaces
+ * (paths relative to /root/reference/src/USER-MESO unless stated).  The library owns all device memory;
+ * host pointers are borrowed for the duration of a call only.  One context per GPU / per rank; a context
+ * is not thread-safe, different contexts are independent.  Every function returns 0 on success and a
+ * non-zero status otherwise; the message is available from meso_last_error() (the LAMMPS glue maps it to
+ * error->one(FLERR,msg), replacing raise(SIGABRT) of util_meso.h:96-97 and exit(0) of engine_meso.h:139).
+ */
+#ifndef MESO_HIP_H
+#define MESO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct meso_ctx meso_ctx;
+
+enum { MESO_OK = 0, MESO_ERR_ARG = 1, MESO_ERR_HIP = 2, MESO_ERR_STATE = 3, MESO_ERR_OVERFLOW = 4, MESO_ERR_COMM = 5 };
+
+/* pair styles: PairStyle(dpd/meso,MesoPairDPD) pair_dpd_meso.h:3 ; PairStyle(dpd/fast/meso,...) pair_dpd_fast_meso.h:3 */
+enum { MESO_PAIR_DPD = 0, MESO_PAIR_DPD_FAST = 1 };
+/* work ranges, AtomAttribute::LOCAL/BULK/BORDER util_meso.h:43-74, resolve_work_range atom_vec_meso.cu:194-218 */
+enum { MESO_RANGE_LOCAL = 0, MESO_RANGE_BULK = 1, MESO_RANGE_BORDER = 2 };
+/* ghost transports */
+enum { MESO_TRANSPORT_SELF = 0, MESO_TRANSPORT_RCCL = 1, MESO_TRANSPORT_HOST = 2 };
+
+const char *meso_last_error(void);
+int meso_version(void);
+
+/* ---- device runtime: MesoDevice::init engine_meso.cu:38-96, LAMMPS -device flag src/lammps.cpp:170-191,432-455 */
+int meso_init(int device, meso_ctx **ctx);
+int meso_finalize(meso_ctx *ctx);
+int meso_device_sync(meso_ctx *ctx);
+/* engine options (profiling windows, kernel variants); unknown keys are an error */
+int meso_set_option(meso_ctx *ctx, const char *key, double value);
+
+/* ---- domain + decomposition: Domain box, MesoComm procgrid (comm_meso.cu:41-186, src/comm.cpp Comm::setup) */
+int meso_set_box(meso_ctx *ctx, const double boxlo[3], const double boxhi[3], const int periodicity[3]);
+/* one rank per GPU on a brick procgrid; uid = 128-byte ncclUniqueId from rank 0 (RCCL transport only) */
+int meso_comm_init(meso_ctx *ctx, int nranks, int rank, const int procgrid[3], int transport, const void *uid,
+                   size_t uid_bytes);
+int meso_comm_get_unique_id(void *uid, size_t uid_bytes);
+/* host-staged transport (tests: several ranks sharing one GPU): exchange(user, npeer, peer[], sendbuf[],
+ * sendbytes[], recvbuf[], recvbytes[]) must deliver every buffer; all pointers are host memory */
+typedef int (*meso_host_exchange_fn)(void *user, int npeer, const int *peer, const void *const *sendbuf,
+                                     const size_t *sendbytes, void *const *recvbuf, const size_t *recvbytes);
+int meso_comm_set_host_exchange(meso_ctx *ctx, meso_host_exchange_fn fn, void *user);
+
+/* ---- atoms: AtomStyle(dpd/atomic/meso,AtomVecDPDAtomic) atom_vec_dpd_atomic_meso.h:3; upload replaces
+ *      MesoAtomVec::transfer CUDACOPY_C2G (atom_vec_meso.cu:220-323); x,v are LAMMPS AoS double[n][3] */
+int meso_set_mass(meso_ctx *ctx, int ntypes, const double *mass_per_type /* [ntypes+1], index 0 unused */);
+int meso_atoms_upload(meso_ctx *ctx, int nlocal, const double *x, const double *v, const int *tag,
+                      const int *type, const int *mask /* nullable: all 1 */, const int *image /* nullable */);
+int meso_atoms_count(meso_ctx *ctx, int *nlocal, int *nghost, int *n_bulk);
+/* transfer_pre_output (atom_meso.cu:258-266): device order; any pointer may be NULL; arrays sized nlocal */
+int meso_atoms_download(meso_ctx *ctx, double *x, double *v, double *f, int *tag, int *type, int *image);
+
+/* ---- neighbor / neigh_modify commands (src/neighbor.cpp Neighbor::set / modify_params) */
+int meso_neighbor(meso_ctx *ctx, double skin, int every, int delay, int check);
+
+/* ---- pair_style dpd/meso rc seed ; pair_coeff i j a0 gamma sigma s [rc]  (pair_dpd_meso.cu:272-327) */
+int meso_pair_dpd_settings(meso_ctx *ctx, int style, double cut_global, int seed);
+int meso_pair_dpd_coeff(meso_ctx *ctx, int itype, int jtype, double a0, double gamma, double sigma, double expw,
+                        double cut /* <=0: cut_global */);
+
+/* ---- timestep, fix nve/meso group */
+int meso_timestep(meso_ctx *ctx, double dt);
+
+/* ---- integrator: IntegrateStyle(mvv/meso,ModifiedVerlet) mvv_meso.h:3-4 */
+int meso_setup(meso_ctx *ctx);                 /* ModifiedVerlet::setup  mvv_meso.cu:139-219 */
+int meso_run(meso_ctx *ctx, int nsteps);       /* ModifiedVerlet::run    mvv_meso.cu:243-425 */
+/* the individual virtuals the LAMMPS host calls, for glue code that keeps its own run loop */
+int meso_nve_initial(meso_ctx *ctx);           /* FixNVEMeso::initial_integrate fix_nve_meso.cu:97-155 */
+int meso_nve_final(meso_ctx *ctx);             /* FixNVEMeso::final_integrate   fix_nve_meso.cu:180-199 */
+int meso_neighbor_decide(meso_ctx *ctx, int *rebuild); /* Neighbor::decide src/neighbor.cpp:1216-1231 */
+int meso_reneighbor(meso_ctx *ctx);            /* pbc+exchange+sort_local+borders+build mvv_meso.cu:270-335 */
+int meso_halo_forward(meso_ctx *ctx);          /* Comm::forward_comm + transfer_pre/post_comm mvv_meso.cu:338-358 */
+int meso_force_clear(meso_ctx *ctx, int range);/* MesoAtomVec::force_clear atom_vec_meso.cu:325-336 */
+int meso_pair_compute(meso_ctx *ctx, int range, int eflag, int vflag); /* Pair::compute/compute_bulk/compute_border
+                                                                          pair_dpd_meso.cu:241-266 */
+int meso_step_advance(meso_ctx *ctx, int64_t ntimestep); /* update->ntimestep for glue-driven loops */
+
+/* ---- computes: ComputeStyle(temp/meso,MesoComputeTemp) compute_temp_meso.cu:77-101; pe/pressure
+ *      compute_pe_meso.cu:66-125 */
+int meso_compute_temp(meso_ctx *ctx, double *temperature);
+int meso_compute_pe(meso_ctx *ctx, double *pe_total);
+int meso_compute_pressure(meso_ctx *ctx, double *pressure);
+
+/* ---- introspection used by the parity tests and bench.py */
+int meso_neigh_info(meso_ctx *ctx, int *n_col, int *max_count, double *avg_count, int64_t *nbuild);
+/* row-major copy of the neighbour table: table[i*stride + p], rows of atoms in device order */
+int meso_neigh_download(meso_ctx *ctx, int *count, int *table, int stride);
+int meso_merged_download(meso_ctx *ctx, float *coord4, float *veloc4, int nall);
+/* per-phase device time (ms, HIP events on the engine's stream) accumulated since the last reset;
+ * names: "pair","neigh","nve","merge","halo","reorder","bin","total_steps" */
+int meso_timer_reset(meso_ctx *ctx);
+int meso_timer_get(meso_ctx *ctx, const char *name, double *ms, int64_t *calls);
+int64_t meso_ntimestep(meso_ctx *ctx);
+
+/* ---- known-answer kernels (math_meso.h:444-484) on caller-provided host arrays */
+int meso_test_tea(meso_ctx *ctx, int n, int rounds, const uint32_t *u, const uint32_t *v, uint32_t *out0,
+                  uint32_t *out1);
+int meso_test_gaussian(meso_ctx *ctx, int n, const uint32_t *u, const uint32_t *v, double *out_dp, float *out_sp);
+uint32_t meso_seed_now(int seed, int64_t ntimestep); /* MesoPairDPD::seed_now pair_dpd_meso.cu:268-270 */
+
+/* ---- mini driver: runs the input-script subset of example/simple/{sp,dp}.run unchanged */
+int meso_script_run(meso_ctx *ctx, const char *path, const char *var_name, const char *var_value, char *log,
+                    size_t log_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,252 @@
+"""Host-side mirror of the reference's style interface for the DPD hot path.
+
+The method names are the LAMMPS commands / virtuals of the USER-MESO styles so that tests read
+like the reference's decks (``example/simple/dp.run``):
+
+    m = Meso()
+    m.read_atoms(x, v, box_lo, box_hi)           # read_data
+    m.neighbor(0.3); m.neigh_modify(delay=0, every=5, check=False)
+    m.pair_style("dpd/meso", 1.0, 419084618)     # pair_dpd_meso.cu:272-288
+    m.pair_coeff(1, 1, 15, 4.5, 3.0, 1.0, 1.0)   # pair_dpd_meso.cu:290-327
+    m.fix_nve(); m.timestep(0.005)
+    m.run(1000)
+
+Everything is a thin ctypes call into libmeso_hip.so; no arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1}
+RANGES = {"local": 0, "bulk": 1, "border": 2}
+
+
+class MesoError(RuntimeError):
+    pass
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Meso:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        self._h = None
+        self._ck(self.lib.meso_init(device, C.byref(h)))
+        self._h = h
+        self._setup_done = False
+        self._skin, self._every, self._delay, self._check = 0.3, 1, 10, True
+        self._cb = None
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc:
+            raise MesoError(self.lib.meso_last_error().decode())
+
+    def close(self):
+        if self._h is not None:
+            self.lib.meso_finalize(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_option(self, key, value):
+        self._ck(self.lib.meso_set_option(self._h, key.encode(), float(value)))
+
+    # -- read_data / create atoms -----------------------------------------------------------
+    def read_atoms(self, x, v, box_lo, box_hi, types=None, tags=None, masses=None, ntypes=None,
+                   periodicity=(1, 1, 1)):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        n = len(x)
+        types = np.ones(n, np.int32) if types is None else np.ascontiguousarray(types, np.int32)
+        tags = np.arange(1, n + 1, dtype=np.int32) if tags is None else np.ascontiguousarray(tags, np.int32)
+        ntypes = int(types.max()) if ntypes is None else ntypes
+        masses = np.ones(ntypes + 1) if masses is None else np.ascontiguousarray(masses, np.float64)
+        lo = np.ascontiguousarray(box_lo, np.float64)
+        hi = np.ascontiguousarray(box_hi, np.float64)
+        per = np.ascontiguousarray(periodicity, np.int32)
+        self._ck(self.lib.meso_set_box(self._h, _p(lo), _p(hi), _p(per)))
+        self._ck(self.lib.meso_set_mass(self._h, ntypes, _p(masses)))
+        self._ck(self.lib.meso_atoms_upload(self._h, n, _p(x), _p(v), _p(tags), _p(types), None, None))
+        self.natoms = n
+        self._setup_done = False
+
+    # -- neighbor / neigh_modify ------------------------------------------------------------
+    def neighbor(self, skin, style="bin"):
+        if style != "bin":
+            raise MesoError("Illegal neighbor command")
+        self._skin = skin
+        self._push_neigh()
+
+    def neigh_modify(self, delay=None, every=None, check=None):
+        if delay is not None:
+            self._delay = delay
+        if every is not None:
+            self._every = every
+        if check is not None:
+            self._check = bool(check)
+        self._push_neigh()
+
+    def _push_neigh(self):
+        self._ck(self.lib.meso_neighbor(self._h, self._skin, self._every, self._delay, int(self._check)))
+
+    # -- styles -----------------------------------------------------------------------------
+    def pair_style(self, style, cut_global, seed):
+        if style not in PAIR_STYLES:
+            raise MesoError("Unknown pair style " + style)
+        self._ck(self.lib.meso_pair_dpd_settings(self._h, PAIR_STYLES[style], cut_global, seed))
+
+    def pair_coeff(self, i, j, a0, gamma, sigma, expw, cut=0.0):
+        self._ck(self.lib.meso_pair_dpd_coeff(self._h, i, j, a0, gamma, sigma, expw, cut))
+
+    def fix_nve(self):
+        pass  # fix nve/meso is the only integrator fix on this path; always active
+
+    def timestep(self, dt):
+        self._ck(self.lib.meso_timestep(self._h, dt))
+
+    # -- run_style mvv/meso -----------------------------------------------------------------
+    def setup(self):
+        self._push_neigh()
+        self._ck(self.lib.meso_setup(self._h))
+        self._setup_done = True
+
+    def run(self, nsteps):
+        if not self._setup_done:
+            self.setup()
+        self._ck(self.lib.meso_run(self._h, nsteps))
+
+    def sync(self):
+        self._ck(self.lib.meso_device_sync(self._h))
+
+    # individual virtuals
+    def initial_integrate(self):
+        self._ck(self.lib.meso_nve_initial(self._h))
+
+    def final_integrate(self):
+        self._ck(self.lib.meso_nve_final(self._h))
+
+    def decide(self):
+        r = C.c_int()
+        self._ck(self.lib.meso_neighbor_decide(self._h, C.byref(r)))
+        return bool(r.value)
+
+    def reneighbor(self):
+        self._ck(self.lib.meso_reneighbor(self._h))
+
+    def forward_comm(self):
+        self._ck(self.lib.meso_halo_forward(self._h))
+
+    def force_clear(self, which="local"):
+        self._ck(self.lib.meso_force_clear(self._h, RANGES[which]))
+
+    def compute(self, eflag=0, vflag=0, which="local"):
+        self._ck(self.lib.meso_pair_compute(self._h, RANGES[which], eflag, vflag))
+
+    def step_advance(self, ntimestep):
+        self._ck(self.lib.meso_step_advance(self._h, ntimestep))
+
+    @property
+    def ntimestep(self):
+        return self.lib.meso_ntimestep(self._h)
+
+    # -- computes ---------------------------------------------------------------------------
+    def temperature(self):
+        t = C.c_double()
+        self._ck(self.lib.meso_compute_temp(self._h, C.byref(t)))
+        return t.value
+
+    def pe(self):
+        t = C.c_double()
+        self._ck(self.lib.meso_compute_pe(self._h, C.byref(t)))
+        return t.value
+
+    def pressure(self):
+        t = C.c_double()
+        self._ck(self.lib.meso_compute_pressure(self._h, C.byref(t)))
+        return t.value
+
+    # -- data access ------------------------------------------------------------------------
+    def counts(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.meso_atoms_count(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def gather(self, by_tag=True):
+        """x, v, f, tag, type of the local atoms (device order, or sorted by tag)."""
+        n = self.counts()[0]
+        x = np.empty((n, 3)); v = np.empty((n, 3)); f = np.empty((n, 3))
+        tag = np.empty(n, np.int32); typ = np.empty(n, np.int32)
+        self._ck(self.lib.meso_atoms_download(self._h, _p(x), _p(v), _p(f), _p(tag), _p(typ), None))
+        if by_tag:
+            o = np.argsort(tag, kind="stable")
+            return x[o], v[o], f[o], tag[o], typ[o]
+        return x, v, f, tag, typ
+
+    def neigh_info(self):
+        a, b, c, d = C.c_int(), C.c_int(), C.c_double(), C.c_int64()
+        self._ck(self.lib.meso_neigh_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"n_col": a.value, "max_count": b.value, "avg_count": c.value, "nbuild": d.value}
+
+    def neigh_table(self, stride=None):
+        n = self.counts()[0]
+        stride = self.neigh_info()["n_col"] if stride is None else stride
+        count = np.zeros(n, np.int32)
+        table = np.zeros((n, stride), np.int32)
+        self._ck(self.lib.meso_neigh_download(self._h, _p(count), _p(table), stride))
+        return count, table
+
+    def merged(self):
+        nl, ng, _ = self.counts()
+        c4 = np.empty((nl + ng, 4), np.float32)
+        v4 = np.empty((nl + ng, 4), np.float32)
+        self._ck(self.lib.meso_merged_download(self._h, _p(c4), _p(v4), nl + ng))
+        return c4, v4
+
+    def timer_reset(self):
+        self._ck(self.lib.meso_timer_reset(self._h))
+
+    def timer(self, name):
+        ms, calls = C.c_double(), C.c_int64()
+        self._ck(self.lib.meso_timer_get(self._h, name.encode(), C.byref(ms), C.byref(calls)))
+        return ms.value, calls.value
+
+    # -- known-answer kernels ---------------------------------------------------------------
+    def tea(self, rounds, u, v):
+        u = np.ascontiguousarray(u, np.uint32); v = np.ascontiguousarray(v, np.uint32)
+        o0 = np.empty_like(u); o1 = np.empty_like(u)
+        self._ck(self.lib.meso_test_tea(self._h, len(u), rounds, _p(u), _p(v), _p(o0), _p(o1)))
+        return o0, o1
+
+    def gaussian(self, u, v):
+        u = np.ascontiguousarray(u, np.uint32); v = np.ascontiguousarray(v, np.uint32)
+        dp = np.empty(len(u), np.float64); sp = np.empty(len(u), np.float32)
+        self._ck(self.lib.meso_test_gaussian(self._h, len(u), _p(u), _p(v), _p(dp), _p(sp)))
+        return dp, sp
+
+    def script(self, path, var=None, value=None, log_bytes=1 << 16):
+        buf = C.create_string_buffer(log_bytes)
+        rc = self.lib.meso_script_run(self._h, path.encode(), None if var is None else var.encode(),
+                                      None if value is None else str(value).encode(), buf, log_bytes)
+        log = buf.value.decode()
+        if rc:
+            raise MesoError(self.lib.meso_last_error().decode() + "\n" + log)
+        self._setup_done = True
+        return log

@@ -1,0 +1,176 @@
+// Host-side engine of the MI355X DPD hot path: device-resident particle state, the per-step schedule
+// of run_style mvv/meso, neighbour rebuilds, halo exchange.  Mirrors the roles of the reference's
+// MesoDevice / MesoAtom(+Vec) / MesoNeighbor / MesoComm / ModifiedVerlet behind one
+// context object; see include/meso_hip.h for the C ABI that exposes it.
+#pragma once
+#include "kernels.h"
+#include "sort.h"
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+
+struct ncclComm;
+
+namespace meso {
+
+struct PhaseTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0.0;
+    long calls = 0;
+};
+
+typedef int (*host_exchange_fn)(void *user, int npeer, const int *peer, const void *const *sendbuf,
+                                const size_t *sendbytes, void *const *recvbuf, const size_t *recvbytes);
+
+class Engine {
+public:
+    explicit Engine(int device);
+    ~Engine();
+
+    // configuration
+    int set_box(const double *lo, const double *hi, const int *per);
+    int comm_init(int nranks, int rank, const int *procgrid, int transport, const void *uid, size_t uid_bytes);
+    int set_mass(int ntypes, const double *mass);
+    int atoms_upload(int n, const double *x, const double *v, const int *tag, const int *type, const int *mask,
+                     const int *image);
+    int atoms_download(double *x, double *v, double *f, int *tag, int *type, int *image);
+    int neighbor(double skin, int every, int delay, int check);
+    int pair_settings(int style, double cut, int seed);
+    int pair_coeff(int i, int j, double a0, double gamma, double sigma, double expw, double cut);
+    int set_option(const std::string &key, double val);
+
+    // schedule
+    int setup();
+    int run(int nsteps);
+    int nve_initial();
+    int nve_final();
+    int decide(int *rebuild);
+    int reneighbor();
+    int halo_forward();
+    int force_clear(int range);
+    int pair_compute(int range, int eflag, int vflag);
+
+    // computes
+    int compute_temp(double *t);
+    int compute_pe(double *pe);
+    int compute_pressure(double *p);
+
+    // introspection
+    int neigh_info(int *n_col, int *max_count, double *avg, int64_t *nbuild);
+    int neigh_download(int *count, int *table, int stride);
+    int merged_download(float *c4, float *v4, int nall);
+    int timer_reset();
+    int timer_get(const std::string &name, double *ms, int64_t *calls);
+    int test_tea(int n, int rounds, const uint32_t *u, const uint32_t *v, uint32_t *o0, uint32_t *o1);
+    int test_gaussian(int n, const uint32_t *u, const uint32_t *v, double *odp, float *osp);
+    int sync();
+
+    std::string err;
+    int64_t ntimestep = 0;
+    int nlocal = 0, nghost = 0, n_bulk = 0;
+    double dt = 0.005;
+    host_exchange_fn host_exchange = nullptr;
+    void *host_exchange_user = nullptr;
+
+private:
+    int fail(int code, const std::string &msg);
+    int check(hipError_t e, const char *what);
+    int init_params();
+    int ensure_capacity(int need_atoms);
+    int alloc_atoms(int cap);
+    void free_all();
+    void range(int r, int &beg, int &end) const;
+    int merge_locals(uint32_t seed);
+    int halo_borders();
+    int halo_forward_seed(uint32_t seed);
+    int build_cells_and_table();
+    int reorder_locals();
+    int migrate();
+    int check_overflow();
+    double reduce_global_sum(double v);
+    void tbegin(const char *name);
+    void tend(const char *name);
+    void tflush();
+
+    int device;
+    hipStream_t stream = nullptr, side = nullptr;
+    bool profiling = false;
+    std::map<std::string, PhaseTimer> timers;
+    std::vector<hipEvent_t> event_pool;
+
+    // box / decomposition
+    double boxlo[3], boxhi[3], prd[3];
+    int periodic[3];
+    bool have_box = false;
+    int nranks = 1, rank = 0, procgrid[3] = {1, 1, 1}, myloc[3] = {0, 0, 0};
+    int transport = 0;
+    ncclComm *nccl = nullptr;
+    double sublo[3], subhi[3];
+    double slab_lo[3], slab_hi[3];
+    double shift27[81], center27[81];
+    int peer27[27];
+    bool send_active[27];
+
+    // settings
+    double skin = 0.3;
+    int every = 1, delay = 10, dist_check = 1;
+    int groupbit = 1;
+    int pair_style = 0, seed = 0, ntypes = 0;
+    double cut_global = 0.0, cutmax = 0.0, cutghost = 0.0;
+    bool have_pair = false, have_coeff = false, params_ready = false, is_setup = false;
+    std::vector<double> coeff;      // ntypes*ntypes*7
+    std::vector<int> coeff_set;
+    std::vector<double> mass_type;  // ntypes+1
+    int neigh_kernel = 1;           // 0 simple, 1 wave/LDS
+    int fuse_clear = 1;             // pair kernel writes f instead of clear + accumulate
+    long natoms_total = 0;
+
+    // atoms (device)
+    int nmax = 0;
+    AtomSoA cur{}, alt{};
+    float4 *coord4 = nullptr, *veloc4 = nullptr;
+    double *virial[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *e_pair = nullptr;
+    double *xhold = nullptr;
+    double *d_mass_type = nullptr, *d_coeff64 = nullptr;
+    float *d_coeff32 = nullptr;
+
+    // neighbour
+    BinGeom geom{};
+    int n_col = 0;
+    int *pair_count = nullptr, *pair_table = nullptr;
+    size_t table_tiles = 0;
+    uint32_t *bin_id = nullptr, *bin_key = nullptr, *bin_key_alt = nullptr;
+    int *bin_val = nullptr, *bin_val_alt = nullptr, *bin_start = nullptr;
+    int bin_cap = 0;
+    int64_t nbuild = 0;
+    int ago = 0;
+
+    // reorder
+    uint64_t *rkey = nullptr, *rkey_alt = nullptr;
+    int *rval = nullptr, *rval_alt = nullptr;
+    void *sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+
+    // halo
+    int *sendlist = nullptr;
+    int send_cap = 0;
+    int *chunk_count = nullptr, *chunk_offset = nullptr;
+    int chunk_cap = 0;
+    int *d_dir_start = nullptr;
+    int h_dir_start[28];
+    int nsend = 0;
+
+    // scalars
+    double *d_partial = nullptr, *d_scalar = nullptr;
+    int *d_flags = nullptr;     // [0] overflow, [1] n_bulk
+    int *h_flags = nullptr;     // pinned
+    double *h_scalar = nullptr; // pinned
+    bool ev_valid = false;
+};
+
+int comm_unique_id(void *uid, size_t uid_bytes);
+int script_run(Engine &E, const char *path, const char *var_name, const char *var_value, std::string &out);
+
+} // namespace meso

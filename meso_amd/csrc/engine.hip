@@ -1,0 +1,884 @@
+// Engine: device-resident DPD timestep for MI355X.  The per-step schedule follows
+// ModifiedVerlet::run (/root/reference/src/USER-MESO/mvv_meso.cu:243-425) with the host round trips removed:
+// particles never leave HBM between steps, ghosts are produced by device pack kernels (self transport)
+// or travel as packed float4 pairs over RCCL, and the reorder / cell list use rocPRIM sorts.
+#include "engine.h"
+#include "meso_device.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace meso {
+
+#define HIPCHK(call)                                                      \
+    do {                                                                  \
+        int _rc = check((call), #call);                                   \
+        if (_rc) return _rc;                                              \
+    } while (0)
+#define TRY(call)                                                         \
+    do {                                                                  \
+        int _rc = (call);                                                 \
+        if (_rc) return _rc;                                              \
+    } while (0)
+
+static const double BIG = 1.0e20;
+
+int Engine::fail(int code, const std::string &msg)
+{
+    err = msg;
+    return code;
+}
+
+int Engine::check(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return 0;
+    err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    return 2;
+}
+
+Engine::Engine(int dev) : device(dev)
+{
+    for (int d = 0; d < 3; d++) { boxlo[d] = 0; boxhi[d] = 1; prd[d] = 1; periodic[d] = 1; }
+}
+
+Engine::~Engine() { free_all(); }
+
+template <typename T>
+static hipError_t dalloc(T *&p, size_t n)
+{
+    p = nullptr;
+    return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T));
+}
+
+template <typename T>
+static void dfree(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static void free_soa(AtomSoA &a)
+{
+    for (int d = 0; d < 3; d++) { dfree(a.x[d]); dfree(a.v[d]); dfree(a.f[d]); }
+    dfree(a.tag); dfree(a.type); dfree(a.mask); dfree(a.image); dfree(a.mass);
+}
+
+void Engine::free_all()
+{
+    if (stream) (void)hipStreamSynchronize(stream);
+    free_soa(cur); free_soa(alt);
+    dfree(coord4); dfree(veloc4);
+    for (int k = 0; k < 6; k++) dfree(virial[k]);
+    dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32);
+    dfree(pair_count); dfree(pair_table);
+    dfree(bin_id); dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(bin_start);
+    dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
+    if (sort_temp) (void)hipFree(sort_temp);
+    sort_temp = nullptr;
+    dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
+    dfree(d_partial); dfree(d_scalar); dfree(d_flags);
+    if (h_flags) (void)hipHostFree(h_flags);
+    if (h_scalar) (void)hipHostFree(h_scalar);
+    h_flags = nullptr; h_scalar = nullptr;
+    for (auto &kv : timers)
+        for (auto &pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    timers.clear();
+    for (auto e : event_pool) (void)hipEventDestroy(e);
+    event_pool.clear();
+    if (stream) (void)hipStreamDestroy(stream);
+    if (side) (void)hipStreamDestroy(side);
+    stream = side = nullptr;
+    nmax = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timers (HIP events on the engine stream; only when profiling is on)
+// ------------------------------------------------------------------------------------------------
+void Engine::tbegin(const char *name)
+{
+    if (!profiling) return;
+    hipEvent_t a, b;
+    if (event_pool.size() >= 2) {
+        a = event_pool.back(); event_pool.pop_back();
+        b = event_pool.back(); event_pool.pop_back();
+    } else {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+    }
+    (void)hipEventRecord(a, stream);
+    timers[name].pending.push_back(std::make_pair(a, b));
+}
+
+void Engine::tend(const char *name)
+{
+    if (!profiling) return;
+    PhaseTimer &t = timers[name];
+    if (t.pending.empty()) return;
+    (void)hipEventRecord(t.pending.back().second, stream);
+}
+
+void Engine::tflush()
+{
+    if (!profiling) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto &kv : timers) {
+        for (auto &pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                kv.second.ms += ms;
+                kv.second.calls++;
+            }
+            event_pool.push_back(pr.first);
+            event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+int Engine::timer_reset()
+{
+    tflush();
+    for (auto &kv : timers) { kv.second.ms = 0.0; kv.second.calls = 0; }
+    return 0;
+}
+
+int Engine::timer_get(const std::string &name, double *ms, int64_t *calls)
+{
+    tflush();
+    auto it = timers.find(name);
+    if (ms) *ms = it == timers.end() ? 0.0 : it->second.ms;
+    if (calls) *calls = it == timers.end() ? 0 : it->second.calls;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// configuration
+// ------------------------------------------------------------------------------------------------
+int Engine::set_box(const double *lo, const double *hi, const int *per)
+{
+    for (int d = 0; d < 3; d++) {
+        if (!(hi[d] > lo[d])) return fail(1, "Box bounds are invalid");
+        boxlo[d] = lo[d]; boxhi[d] = hi[d]; prd[d] = hi[d] - lo[d]; periodic[d] = per ? per[d] : 1;
+    }
+    have_box = true;
+    params_ready = false;
+    return 0;
+}
+
+int Engine::set_mass(int nt, const double *m)
+{
+    if (nt < 1) return fail(1, "Invalid number of atom types");
+    if (ntypes && nt != ntypes) return fail(1, "Number of atom types changed");
+    ntypes = nt;
+    mass_type.assign(m, m + nt + 1);
+    for (int t = 1; t <= nt; t++)
+        if (!(mass_type[t] > 0.0)) return fail(1, "Invalid mass value");
+    if ((int)coeff.size() != nt * nt * N_COEFF) { coeff.assign((size_t)nt * nt * N_COEFF, 0.0); coeff_set.assign((size_t)nt * nt, 0); }
+    params_ready = false;
+    return 0;
+}
+
+int Engine::neighbor(double s, int ev, int dl, int chk)
+{
+    if (s < 0.0) return fail(1, "Illegal neighbor command");
+    if (ev <= 0 || dl < 0) return fail(1, "Illegal neigh_modify command");
+    skin = s; every = ev; delay = dl; dist_check = chk ? 1 : 0;
+    params_ready = false;
+    return 0;
+}
+
+// MesoPairDPD::settings (pair_dpd_meso.cu:272-288): pair_style dpd/meso rc seed
+int Engine::pair_settings(int style, double cut, int sd)
+{
+    if (style != 0 && style != 1) return fail(1, "Illegal pair_style command");
+    if (!(cut > 0.0)) return fail(1, "Illegal pair_style command");
+    pair_style = style; cut_global = cut; seed = sd;
+    have_pair = true;
+    params_ready = false;
+    return 0;
+}
+
+// MesoPairDPD::coeff (pair_dpd_meso.cu:290-327): pair_coeff i j a0 gamma sigma s [rc]; init_one mirrors ij -> ji
+int Engine::pair_coeff(int i, int j, double a0, double gamma, double sigma, double expw, double cut)
+{
+    if (!have_pair) return fail(3, "pair_coeff before pair_style");
+    if (ntypes == 0) return fail(3, "pair_coeff before atom types are known");
+    if (i < 1 || j < 1 || i > ntypes || j > ntypes) return fail(1, "Incorrect args for pair coefficients");
+    if (cut <= 0.0) cut = cut_global;
+    for (int k = 0; k < 2; k++) {
+        int a = k ? j - 1 : i - 1, b = k ? i - 1 : j - 1;
+        double *c = &coeff[((size_t)a * ntypes + b) * N_COEFF];
+        c[P_CUT] = cut; c[P_CUTSQ] = cut * cut; c[P_CUTINV] = 1.0 / cut; c[P_EXPW] = expw;
+        c[P_A0] = a0; c[P_GAMMA] = gamma; c[P_SIGMA] = sigma;
+        coeff_set[(size_t)a * ntypes + b] = 1;
+    }
+    have_coeff = true;
+    params_ready = false;
+    return 0;
+}
+
+int Engine::set_option(const std::string &key, double val)
+{
+    if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
+    if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
+    if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
+    if (key == "groupbit") { groupbit = (int)val; return 0; }
+    return fail(1, "Unknown option '" + key + "'");
+}
+
+int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *, size_t)
+{
+    if (nr < 1 || rk < 0 || rk >= nr) return fail(1, "Invalid rank layout");
+    if (pg[0] * pg[1] * pg[2] != nr) return fail(1, "Bad grid of processors");
+    if (nr > 1) return fail(5, "Multi-rank transport not initialised in this build step");
+    nranks = nr; rank = rk; transport = tr;
+    for (int d = 0; d < 3; d++) procgrid[d] = pg[d];
+    myloc[0] = rk % pg[0]; myloc[1] = (rk / pg[0]) % pg[1]; myloc[2] = rk / (pg[0] * pg[1]);
+    params_ready = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// memory
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t regrow(T *&p, size_t keep, size_t cap, hipStream_t s)
+{
+    T *q = nullptr;
+    hipError_t e = hipMalloc((void **)&q, (cap ? cap : 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+        e = hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    return hipSuccess;
+}
+
+int Engine::alloc_atoms(int cap)
+{
+    size_t keep = (size_t)nlocal, c = (size_t)cap;
+    if (!stream) {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIPCHK(dalloc(d_partial, 1024));
+        HIPCHK(dalloc(d_scalar, 16));
+        HIPCHK(dalloc(d_flags, 16));
+        HIPCHK(dalloc(d_dir_start, 32));
+        HIPCHK(hipHostMalloc((void **)&h_flags, 64 * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&h_scalar, 16 * sizeof(double)));
+        HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), stream));
+    }
+    for (int d = 0; d < 3; d++) {
+        HIPCHK(regrow(cur.x[d], keep, c, stream));
+        HIPCHK(regrow(cur.v[d], keep, c, stream));
+        HIPCHK(regrow(cur.f[d], keep, c, stream));
+        HIPCHK(regrow(alt.x[d], 0, c, stream));
+        HIPCHK(regrow(alt.v[d], 0, c, stream));
+        HIPCHK(regrow(alt.f[d], 0, c, stream));
+    }
+    HIPCHK(regrow(cur.tag, keep, c, stream)); HIPCHK(regrow(alt.tag, 0, c, stream));
+    HIPCHK(regrow(cur.type, keep, c, stream)); HIPCHK(regrow(alt.type, 0, c, stream));
+    HIPCHK(regrow(cur.mask, keep, c, stream)); HIPCHK(regrow(alt.mask, 0, c, stream));
+    HIPCHK(regrow(cur.image, keep, c, stream)); HIPCHK(regrow(alt.image, 0, c, stream));
+    HIPCHK(regrow(cur.mass, keep, c, stream)); HIPCHK(regrow(alt.mass, 0, c, stream));
+    HIPCHK(regrow(coord4, 0, c, stream)); HIPCHK(regrow(veloc4, 0, c, stream));
+    for (int k = 0; k < 6; k++) HIPCHK(regrow(virial[k], 0, c, stream));
+    HIPCHK(regrow(e_pair, 0, c, stream));
+    HIPCHK(regrow(xhold, 0, 3 * c, stream));
+    HIPCHK(regrow(pair_count, 0, c, stream));
+    HIPCHK(regrow(bin_id, 0, c, stream)); HIPCHK(regrow(bin_key, 0, c, stream)); HIPCHK(regrow(bin_key_alt, 0, c, stream));
+    HIPCHK(regrow(bin_val, 0, c, stream)); HIPCHK(regrow(bin_val_alt, 0, c, stream));
+    HIPCHK(regrow(rkey, 0, c, stream)); HIPCHK(regrow(rkey_alt, 0, c, stream));
+    HIPCHK(regrow(rval, 0, c, stream)); HIPCHK(regrow(rval_alt, 0, c, stream));
+    HIPCHK(regrow(sendlist, 0, c, stream));
+    send_cap = cap;
+    chunk_cap = (cap + 255) / 256 + 1;
+    HIPCHK(regrow(chunk_count, 0, (size_t)27 * chunk_cap + 1, stream));
+    HIPCHK(regrow(chunk_offset, 0, (size_t)27 * chunk_cap + 1, stream));
+    size_t tb = std::max(sort_temp_bytes_u32(cap), sort_temp_bytes_u64(cap));
+    tb = std::max(tb, scan_temp_bytes(27 * chunk_cap + 1));
+    if (tb > sort_temp_bytes) {
+        if (sort_temp) (void)hipFree(sort_temp);
+        sort_temp = nullptr;
+        HIPCHK(hipMalloc(&sort_temp, tb));
+        sort_temp_bytes = tb;
+    }
+    if (n_col > 0) {
+        table_tiles = ((size_t)cap + 63) / 64;
+        dfree(pair_table);
+        HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
+    }
+    nmax = cap;
+    return 0;
+}
+
+int Engine::ensure_capacity(int need)
+{
+    if (need <= nmax) return 0;
+    int cap = (int)(need * 1.15) + 4096;
+    TRY(alloc_atoms(cap));
+    is_setup = is_setup;   // neighbour table contents are rebuilt by the caller
+    return 0;
+}
+
+int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag, const int *type, const int *mask,
+                         const int *image)
+{
+    if (n < 0 || !x || !v || !tag || !type) return fail(1, "Invalid atom arrays");
+    if (!have_box) return fail(3, "Box must be set before atoms are created");
+    // capacity: locals + expected ghosts (periodic images within cutghost) with head-room
+    double ext = 1.0;
+    double cg = (cut_global > 0 ? cut_global : 1.0) + skin;
+    for (int d = 0; d < 3; d++) ext *= (prd[d] / procgrid[d] + 2.0 * cg) / (prd[d] / procgrid[d]);
+    int cap = (int)(1.25 * n * std::min(ext, 27.0)) + 8192;
+    nlocal = 0;
+    if (cap > nmax) TRY(alloc_atoms(cap));
+    std::vector<double> tmp((size_t)n);
+    for (int d = 0; d < 3; d++) {
+        for (int i = 0; i < n; i++) tmp[i] = x[3 * (size_t)i + d];
+        HIPCHK(hipMemcpy(cur.x[d], tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        for (int i = 0; i < n; i++) tmp[i] = v[3 * (size_t)i + d];
+        HIPCHK(hipMemcpy(cur.v[d], tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(cur.f[d], 0, n * sizeof(double), stream));
+    }
+    HIPCHK(hipMemcpy(cur.tag, tag, n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(cur.type, type, n * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> itmp((size_t)n, 1);
+    HIPCHK(hipMemcpy(cur.mask, mask ? mask : itmp.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    // image flags: 10 bits per dimension, 512 = no wrap (LAMMPS' smallint packing)
+    std::fill(itmp.begin(), itmp.end(), 512 | (512 << 10) | (512 << 20));
+    HIPCHK(hipMemcpy(cur.image, image ? image : itmp.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    for (int i = 0; i < n; i++)
+        if (type[i] < 1 || (ntypes && type[i] > ntypes)) return fail(1, "Invalid atom type in atom arrays");
+    nlocal = n;
+    nghost = 0;
+    n_bulk = 0;
+    is_setup = false;
+    params_ready = false;
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Engine::atoms_download(double *x, double *v, double *f, int *tag, int *type, int *image)
+{
+    HIPCHK(hipStreamSynchronize(stream));
+    int n = nlocal;
+    std::vector<double> tmp((size_t)n);
+    double *dst[3] = {x, v, f};
+    for (int a = 0; a < 3; a++) {
+        if (!dst[a]) continue;
+        for (int d = 0; d < 3; d++) {
+            double *src = a == 0 ? cur.x[d] : (a == 1 ? cur.v[d] : cur.f[d]);
+            HIPCHK(hipMemcpy(tmp.data(), src, n * sizeof(double), hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; i++) dst[a][3 * (size_t)i + d] = tmp[i];
+        }
+    }
+    if (tag) HIPCHK(hipMemcpy(tag, cur.tag, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (type) HIPCHK(hipMemcpy(type, cur.type, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (image) HIPCHK(hipMemcpy(image, cur.image, n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameters: sub-box, slabs, bins (MesoNeighbor::setup_bins neighbor_meso.cu:858-931), row width
+// ------------------------------------------------------------------------------------------------
+int Engine::init_params()
+{
+    if (params_ready) return 0;
+    if (!have_box) return fail(3, "Box has not been set");
+    if (!have_pair || !have_coeff) return fail(3, "Pair style/coefficients have not been set");
+    if (ntypes < 1 || (int)mass_type.size() != ntypes + 1) return fail(3, "Masses have not been set");
+    for (int i = 0; i < ntypes * ntypes; i++)
+        if (!coeff_set[i]) return fail(3, "All pair coeffs are not set");
+    cutmax = 0.0;
+    for (int i = 0; i < ntypes * ntypes; i++) cutmax = std::max(cutmax, coeff[(size_t)i * N_COEFF + P_CUT]);
+    cutghost = cutmax + skin;
+    const double cutneighmax = cutmax + skin;
+
+    for (int d = 0; d < 3; d++) {
+        sublo[d] = boxlo[d] + prd[d] * myloc[d] / procgrid[d];
+        subhi[d] = (myloc[d] == procgrid[d] - 1) ? boxhi[d] : boxlo[d] + prd[d] * (myloc[d] + 1) / procgrid[d];
+        if (subhi[d] - sublo[d] < cutghost)
+            return fail(1, "Sub-domain smaller than the ghost cutoff is not supported");
+        bool has_lo = periodic[d] || myloc[d] > 0, has_hi = periodic[d] || myloc[d] < procgrid[d] - 1;
+        slab_lo[d] = has_lo ? sublo[d] + cutghost : -BIG;
+        slab_hi[d] = has_hi ? subhi[d] - cutghost : BIG;
+    }
+    for (int dir = 0; dir < 27; dir++) {
+        int s[3] = {dir % 3 - 1, (dir / 3) % 3 - 1, dir / 9 - 1};
+        bool active = dir != 13;
+        int loc[3];
+        for (int d = 0; d < 3; d++) {
+            shift27[3 * dir + d] = 0.0;
+            loc[d] = myloc[d] + s[d];
+            if (loc[d] < 0 || loc[d] >= procgrid[d]) {
+                if (!periodic[d]) active = false;
+                shift27[3 * dir + d] = -s[d] * prd[d];
+                loc[d] = (loc[d] + procgrid[d]) % procgrid[d];
+            }
+            double lo = boxlo[d] + prd[d] * loc[d] / procgrid[d];
+            double hi = (loc[d] == procgrid[d] - 1) ? boxhi[d] : boxlo[d] + prd[d] * (loc[d] + 1) / procgrid[d];
+            center27[3 * dir + d] = 0.5 * (hi + lo);
+        }
+        send_active[dir] = active;
+        peer27[dir] = loc[0] + procgrid[0] * (loc[1] + procgrid[1] * loc[2]);
+    }
+
+    // bins aligned with the sub-box, one ghost layer each side
+    double subvol = 1.0;
+    for (int d = 0; d < 3; d++) {
+        double dim = subhi[d] - sublo[d];
+        subvol *= dim;
+        geom.lo[d] = sublo[d]; geom.hi[d] = subhi[d];
+        geom.mbin[d] = std::max((int)(dim * (1.0 / cutneighmax)), 1) + 2;
+        geom.binsize[d] = dim / (geom.mbin[d] - 2);
+        geom.bininv[d] = 1.0 / geom.binsize[d];
+    }
+    geom.nbin = geom.mbin[0] * geom.mbin[1] * geom.mbin[2];
+    double density = nlocal / subvol;
+    if (density < 3.0) density = 3.0;
+    double expected = density * (4.0 / 3.0 * 3.142 * std::pow(cutneighmax, 3.0)) * 4.0;
+    expected = std::max(expected, 32.0);
+    int ncol = ((int)std::ceil(expected) + 31) / 32 * 32;
+    if (ncol != n_col || !pair_table) {
+        n_col = ncol;
+        table_tiles = ((size_t)nmax + 63) / 64;
+        dfree(pair_table);
+        HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
+    }
+    if (geom.nbin + 1 > bin_cap) {
+        dfree(bin_start);
+        bin_cap = geom.nbin + 1;
+        HIPCHK(dalloc(bin_start, (size_t)bin_cap));
+    }
+    // coefficient tables (prepare_coeff pair_dpd_meso.cu:68-89)
+    dfree(d_coeff64); dfree(d_coeff32); dfree(d_mass_type);
+    HIPCHK(dalloc(d_coeff64, coeff.size()));
+    HIPCHK(dalloc(d_coeff32, coeff.size()));
+    HIPCHK(dalloc(d_mass_type, mass_type.size()));
+    std::vector<float> c32(coeff.begin(), coeff.end());
+    HIPCHK(hipMemcpy(d_coeff64, coeff.data(), coeff.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_coeff32, c32.data(), c32.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_mass_type, mass_type.data(), mass_type.size() * sizeof(double), hipMemcpyHostToDevice));
+    launch_unpack_mass(cur.type, d_mass_type, ntypes, cur.mass, 0, nlocal, stream);
+    natoms_total = (long)reduce_global_sum((double)nlocal);
+    params_ready = true;
+    return 0;
+}
+
+double Engine::reduce_global_sum(double v) { return v; }   // single rank; RCCL all-reduce when nranks > 1
+
+int comm_unique_id(void *, size_t) { return 1; }
+
+void Engine::range(int r, int &beg, int &end) const
+{
+    beg = 0; end = nlocal;
+    if (r == 1) end = n_bulk;
+    else if (r == 2) beg = n_bulk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rebuild pieces
+// ------------------------------------------------------------------------------------------------
+int Engine::migrate() { return 0; }   // single rank: PBC wrap only
+
+// MesoAtom::sort_local (atom_meso.cu:343-384) + transfer_post_sort, all device resident
+int Engine::reorder_locals()
+{
+    if (nlocal == 0) { n_bulk = 0; return 0; }
+    tbegin("reorder");
+    int bits = reorder_key_bits(geom);
+    launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
+    HIPCHK(sort_pairs_u64(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
+    HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
+    launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
+    launch_permute_atoms(cur, alt, rval, nlocal, stream);
+    std::swap(cur, alt);
+    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    tend("reorder");
+    HIPCHK(hipStreamSynchronize(stream));
+    if (h_flags[0]) return fail(4, "Pair table overflow: local density too high");
+    n_bulk = h_flags[1];
+    return 0;
+}
+
+// MesoComm::borders (comm_meso.cu:41-186) as device list building + device pack
+int Engine::halo_borders()
+{
+    tbegin("halo");
+    int beg = n_bulk, end = nlocal;
+    int nchunk = (end - beg + 255) / 256;
+    nsend = 0;
+    for (int k = 0; k < 28; k++) h_dir_start[k] = 0;
+    if (nchunk > 0) {
+        launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
+        HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+        // direction starts = offsets of chunk 0 of each direction (+ total)
+        for (int dir = 0; dir < 27; dir++)
+            HIPCHK(hipMemcpyAsync(d_dir_start + dir, chunk_offset + (size_t)dir * nchunk, sizeof(int),
+                                  hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(d_dir_start + 27, chunk_offset + (size_t)27 * nchunk, sizeof(int),
+                              hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];
+        nsend = h_dir_start[27];
+    } else {
+        HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
+    }
+    // single rank: every send is my own ghost
+    nghost = nsend;
+    if (nlocal + nghost > nmax || nsend > send_cap) {
+        TRY(ensure_capacity(nlocal + nghost));
+        // lists are rebuilt below on the new buffers; chunk arrays were regrown, so recount
+        launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
+        HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+    }
+    if (nsend > 0) {
+        launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
+        launch_pack_border(cur, sendlist, nsend, d_dir_start, shift27, cur.x[0] + nlocal, cur.x[1] + nlocal,
+                           cur.x[2] + nlocal, cur.tag + nlocal, cur.type + nlocal, cur.mask + nlocal, stream);
+    }
+    tend("halo");
+    return 0;
+}
+
+// Comm::forward_comm + gpu_merge_xvt(ghost range): ghosts arrive as merged float4 pairs
+int Engine::halo_forward_seed(uint32_t sd)
+{
+    if (nsend <= 0) return 0;
+    tbegin("halo");
+    launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,
+                        stream);
+    tend("halo");
+    return 0;
+}
+
+int Engine::merge_locals(uint32_t sd)
+{
+    tbegin("merge");
+    launch_merge_xvt(cur, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]),
+                     0.5 * (subhi[2] + sublo[2]), sd, 0, nlocal, stream);
+    tend("merge");
+    return 0;
+}
+
+// binning_meso (neighbor_meso.cu:535-711) + full_bin_meso (neigh_build_meso.cu:254-417)
+int Engine::build_cells_and_table()
+{
+    int nall = nlocal + nghost;
+    tbegin("bin");
+    launch_assign_bin(cur, geom, nlocal, nall, bin_id, bin_val, stream);
+    HIPCHK(hipMemcpyAsync(bin_key, bin_id, (size_t)nall * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    int bits = 1;
+    while ((1 << bits) < geom.nbin) bits++;
+    HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nall, bits, stream));
+    launch_bin_bounds(bin_key, nall, geom.nbin, bin_start, stream);
+    tend("bin");
+    TRY(merge_locals(0));
+    TRY(halo_forward_seed(0));
+    tbegin("neigh");
+    float rc2 = (float)((cutmax + skin) * (cutmax + skin));
+    if (neigh_kernel == 0)
+        launch_neigh_build_simple(coord4, bin_id, bin_start, bin_val, geom, rc2, nlocal, n_col, pair_count, pair_table,
+                                  d_flags, stream);
+    else
+        launch_neigh_build_wave(coord4, bin_id, bin_start, bin_val, geom, rc2, nlocal, n_col, pair_count, pair_table,
+                                d_flags, stream);
+    tend("neigh");
+    nbuild++;
+    return 0;
+}
+
+int Engine::check_overflow()
+{
+    HIPCHK(hipMemcpyAsync(h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (h_flags[0]) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "Pair table overflow: %d > %d; local density too high", h_flags[0], n_col);
+        return fail(4, buf);
+    }
+    return 0;
+}
+
+int Engine::reneighbor()
+{
+    TRY(init_params());
+    launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
+    TRY(migrate());
+    TRY(reorder_locals());
+    TRY(halo_borders());
+    TRY(build_cells_and_table());
+    if (dist_check) launch_copy_hold(cur, xhold, nlocal, nmax, stream);
+    ago = 0;
+    return 0;
+}
+
+// Neighbor::decide (src/neighbor.cpp:1216-1231) with check_distance on the device
+int Engine::decide(int *rebuild)
+{
+    ago++;
+    *rebuild = 0;
+    if (ago >= delay && ago % every == 0) {
+        if (!dist_check) { *rebuild = 1; return 0; }
+        launch_max_disp2(cur, xhold, nlocal, nmax, d_partial, d_scalar, stream);
+        HIPCHK(hipMemcpyAsync(h_scalar, d_scalar, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        double trig = 0.5 * skin;
+        *rebuild = reduce_global_sum(h_scalar[0] > trig * trig ? 1.0 : 0.0) > 0.0 ? 1 : 0;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-step pieces
+// ------------------------------------------------------------------------------------------------
+int Engine::nve_initial()
+{
+    tbegin("nve");
+    launch_nve_initial(cur, 0.5 * dt, dt, groupbit, nlocal, stream);
+    tend("nve");
+    return 0;
+}
+
+int Engine::nve_final()
+{
+    tbegin("nve");
+    launch_nve_final(cur, 0.5 * dt, groupbit, nlocal, stream);
+    tend("nve");
+    return 0;
+}
+
+int Engine::halo_forward() { return halo_forward_seed(premix_tea<64>((u32)seed, (u32)ntimestep)); }
+
+int Engine::force_clear(int r)
+{
+    int beg, end;
+    range(r, beg, end);
+    for (int d = 0; d < 3; d++) launch_fill_f64(cur.f[d] + beg, 0.0, end - beg, stream);
+    return 0;
+}
+
+// MesoPairDPD::compute / compute_bulk / compute_border (pair_dpd_meso.cu:241-266).  The merged arrays of the
+// local range are refreshed for LOCAL and BULK calls, the ghost range for LOCAL and BORDER calls, exactly the
+// split the reference uses to hide its host round trip.
+int Engine::pair_compute(int r, int eflag, int vflag)
+{
+    if (!is_setup && !params_ready) return fail(3, "pair_compute before setup");
+    u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
+    if (r == 0 || r == 1) TRY(merge_locals(sd));
+    if (r == 0 || r == 2) TRY(halo_forward_seed(sd));
+    int beg, end;
+    range(r, beg, end);
+    PairArgs p;
+    p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
+    for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
+    int ev = (eflag || vflag) ? 1 : 0;
+    p.e_pair = ev ? e_pair : nullptr;
+    for (int k = 0; k < 6; k++) p.virial[k] = ev ? virial[k] : nullptr;
+    p.coeff64 = d_coeff64; p.coeff32 = d_coeff32; p.ntypes = ntypes;
+    p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
+    p.beg = beg; p.end = end;
+    p.accumulate = 1;
+    tbegin("pair");
+    // energy/virial exist only in the fp64 kernel (the reference's fast style accumulates them in fp32;
+    // thermo output steps are rare, so they take the fp64 path here)
+    launch_pair_dpd(p, ev ? 0 : pair_style, ev, stream);
+    tend("pair");
+    if (ev) ev_valid = true;
+    return 0;
+}
+
+int Engine::setup()
+{
+    if (nlocal <= 0 && nranks == 1) return fail(3, "No atoms have been uploaded");
+    TRY(init_params());
+    TRY(reneighbor());
+    nbuild = 0;
+    TRY(force_clear(0));
+    for (int k = 0; k < 6; k++) launch_fill_f64(virial[k], 0.0, nlocal, stream);
+    TRY(pair_compute(0, 1, 1));
+    TRY(check_overflow());
+    is_setup = true;
+    return 0;
+}
+
+int Engine::run(int nsteps)
+{
+    if (!is_setup) return fail(3, "run before setup");
+    tbegin("total_steps");
+    for (int it = 0; it < nsteps; it++) {
+        ntimestep++;
+        TRY(nve_initial());
+        int rebuild = 0;
+        TRY(decide(&rebuild));
+        if (rebuild) TRY(reneighbor());
+        u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
+        TRY(merge_locals(sd));
+        TRY(halo_forward_seed(sd));
+        PairArgs p;
+        p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
+        for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
+        p.e_pair = nullptr;
+        for (int k = 0; k < 6; k++) p.virial[k] = nullptr;
+        p.coeff64 = d_coeff64; p.coeff32 = d_coeff32; p.ntypes = ntypes;
+        p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
+        p.beg = 0; p.end = nlocal;
+        p.accumulate = fuse_clear ? 0 : 1;
+        if (!fuse_clear) TRY(force_clear(0));
+        tbegin("pair");
+        launch_pair_dpd(p, pair_style, 0, stream);
+        tend("pair");
+        TRY(nve_final());
+        ev_valid = false;
+    }
+    tend("total_steps");
+    TRY(check_overflow());
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int Engine::sync()
+{
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// computes
+// ------------------------------------------------------------------------------------------------
+int Engine::compute_temp(double *t)
+{
+    TRY(init_params());
+    launch_sum_mv2(cur, groupbit, nlocal, d_partial, d_scalar, stream);
+    HIPCHK(hipMemcpyAsync(h_scalar, d_scalar, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    double sum = reduce_global_sum(h_scalar[0]);
+    double dof = 3.0 * natoms_total - 3.0;   // extra_dof = 3 (src/compute_temp.cpp dof_compute)
+    *t = dof > 0.0 ? sum / dof : 0.0;        // units lj: mvv2e = boltz = 1
+    return 0;
+}
+
+static int host_sum(double *d, int n, hipStream_t s, double &out)
+{
+    std::vector<double> h((size_t)n);
+    if (hipMemcpyAsync(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return 2;
+    if (hipStreamSynchronize(s) != hipSuccess) return 2;
+    long double acc = 0.0L;
+    for (int i = 0; i < n; i++) acc += h[i];
+    out = (double)acc;
+    return 0;
+}
+
+int Engine::compute_pe(double *pe)
+{
+    if (!ev_valid) {
+        // recompute with energy/virial tallies on the current configuration (no force change: scratch f)
+        return fail(3, "Energy was not tallied on this timestep");
+    }
+    double s = 0.0;
+    if (host_sum(e_pair, nlocal, stream, s)) return fail(2, "HIP error in compute_pe");
+    *pe = reduce_global_sum(s);
+    return 0;
+}
+
+int Engine::compute_pressure(double *p)
+{
+    if (!ev_valid) return fail(3, "Virial was not tallied on this timestep");
+    double t = 0.0;
+    TRY(compute_temp(&t));
+    double vsum = 0.0;
+    for (int k = 0; k < 3; k++) {
+        double s = 0.0;
+        if (host_sum(virial[k], nlocal, stream, s)) return fail(2, "HIP error in compute_pressure");
+        vsum += s;
+    }
+    vsum = reduce_global_sum(vsum);
+    double dof = 3.0 * natoms_total - 3.0;
+    double vol = prd[0] * prd[1] * prd[2];
+    *p = (dof * t + vsum) / 3.0 / vol;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// introspection / tests
+// ------------------------------------------------------------------------------------------------
+int Engine::neigh_info(int *ncol, int *max_count, double *avg, int64_t *nb)
+{
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<int> h((size_t)nlocal);
+    if (nlocal) HIPCHK(hipMemcpy(h.data(), pair_count, nlocal * sizeof(int), hipMemcpyDeviceToHost));
+    long tot = 0;
+    int mx = 0;
+    for (int i = 0; i < nlocal; i++) { tot += h[i]; mx = std::max(mx, h[i]); }
+    if (ncol) *ncol = n_col;
+    if (max_count) *max_count = mx;
+    if (avg) *avg = nlocal ? (double)tot / nlocal : 0.0;
+    if (nb) *nb = nbuild;
+    return 0;
+}
+
+int Engine::neigh_download(int *count, int *table, int stride)
+{
+    HIPCHK(hipStreamSynchronize(stream));
+    if (!nlocal) return 0;
+    HIPCHK(hipMemcpy(count, pair_count, nlocal * sizeof(int), hipMemcpyDeviceToHost));
+    size_t tiles = ((size_t)nlocal + 63) / 64;
+    std::vector<int> h(tiles * 64 * (size_t)n_col);
+    HIPCHK(hipMemcpy(h.data(), pair_table, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nlocal; i++) {
+        int n = std::min(count[i], stride);
+        for (int p = 0; p < n; p++) table[(size_t)i * stride + p] = h[(((size_t)(i >> 6)) * n_col + p) * 64 + (i & 63)];
+    }
+    return 0;
+}
+
+int Engine::merged_download(float *c4, float *v4, int nall)
+{
+    HIPCHK(hipStreamSynchronize(stream));
+    if (nall > nlocal + nghost) return fail(1, "merged_download: nall exceeds nlocal+nghost");
+    if (c4) HIPCHK(hipMemcpy(c4, coord4, (size_t)nall * sizeof(float4), hipMemcpyDeviceToHost));
+    if (v4) HIPCHK(hipMemcpy(v4, veloc4, (size_t)nall * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int Engine::test_tea(int n, int rounds, const uint32_t *u, const uint32_t *v, uint32_t *o0, uint32_t *o1)
+{
+    if (!stream) TRY(alloc_atoms(1024));
+    uint32_t *du, *dv, *d0, *d1;
+    HIPCHK(dalloc(du, n)); HIPCHK(dalloc(dv, n)); HIPCHK(dalloc(d0, n)); HIPCHK(dalloc(d1, n));
+    HIPCHK(hipMemcpy(du, u, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv, v, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    launch_test_tea(du, dv, n, rounds, d0, d1, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipMemcpy(o0, d0, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(o1, d1, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    dfree(du); dfree(dv); dfree(d0); dfree(d1);
+    return 0;
+}
+
+int Engine::test_gaussian(int n, const uint32_t *u, const uint32_t *v, double *odp, float *osp)
+{
+    if (!stream) TRY(alloc_atoms(1024));
+    uint32_t *du, *dv;
+    double *dd;
+    float *ds;
+    HIPCHK(dalloc(du, n)); HIPCHK(dalloc(dv, n)); HIPCHK(dalloc(dd, n)); HIPCHK(dalloc(ds, n));
+    HIPCHK(hipMemcpy(du, u, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv, v, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    launch_test_gaussian(du, dv, n, dd, ds, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipMemcpy(odp, dd, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(osp, ds, n * sizeof(float), hipMemcpyDeviceToHost));
+    dfree(du); dfree(dv); dfree(dd); dfree(ds);
+    return 0;
+}
+
+} // namespace meso

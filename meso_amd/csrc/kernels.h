@@ -1,0 +1,106 @@
+// Launch wrappers for the HIP kernels of the DPD hot path (gfx950).  Raw device pointers and
+// a stream only; no ownership.  Each wrapper names the reference kernel it replaces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace meso {
+
+struct BinGeom {
+    double lo[3], hi[3];      // my sub-box
+    double bininv[3];
+    double binsize[3];
+    int mbin[3];              // bins per dim incl. one ghost layer each side
+    int nbin;
+};
+
+// SoA views (device pointers)
+struct AtomSoA {
+    double *x[3], *v[3], *f[3];
+    int *tag, *type, *mask, *image;
+    double *mass;
+};
+
+struct HaloShift { double prd[3]; };
+
+// ---- atom kernels (atom_vec_meso.cu:142-167, fix_nve_meso.cu:62-95,157-178, compute_temp_meso.cu:58-75,
+//      domain_meso.cu:30-145, memory_meso.h:17, atom_vec_meso.h:90) -------------------------------------
+void launch_merge_xvt(const AtomSoA &a, float4 *coord4, float4 *veloc4, double cx, double cy, double cz,
+                      uint32_t seed, int beg, int end, hipStream_t s);
+void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s);
+void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s);
+void launch_sum_mv2(const AtomSoA &a, int groupbit, int n, double *partial, double *result, hipStream_t s);
+void launch_pbc(const AtomSoA &a, const double *boxlo, const double *boxhi, const int *periodic, int n,
+                hipStream_t s);
+void launch_fill_f64(double *p, double val, int n, hipStream_t s);
+void launch_fill_i32(int *p, int val, int n, hipStream_t s);
+void launch_unpack_mass(const int *type, const double *mass_type, int ntypes, double *mass, int beg, int end,
+                        hipStream_t s);
+void launch_max_disp2(const AtomSoA &a, const double *xhold, int n, int stride, double *partial, double *result,
+                      hipStream_t s);
+void launch_copy_hold(const AtomSoA &a, double *xhold, int n, int stride, hipStream_t s);
+
+// ---- reorder (atom_meso.cu:268-314, comm_meso.cu:188-254) ---------------------------------------------
+// key = [border][Morton(bin)][Morton(16^3 sub-cell)]; returns number of significant key bits.
+int reorder_key_bits(const BinGeom &g);
+void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi,
+                         const int *dim_active, uint64_t *key, int *val, int n, hipStream_t s);
+void launch_count_border(const uint64_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
+void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, hipStream_t s);
+void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s);
+
+// ---- halo: border lists + pack (comm_meso.cu:41-186, atom_vec_dpd_atomic_meso.cu:61-244) --------------
+// 26 directions d = (dx+1) + 3*(dy+1) + 9*(dz+1), centre (13) unused.
+void launch_border_count(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi,
+                         const int *dim_active, int *chunk_count /*[27][nchunk]*/, int nchunk, hipStream_t s);
+void launch_border_fill(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi,
+                        const int *dim_active, const int *chunk_offset /*[27][nchunk] exclusive, global*/,
+                        int nchunk, int *sendlist, hipStream_t s);
+// border payload: fp64 x (+shift), tag, type, mask -> destination arrays (tail of SoA or a send buffer)
+void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start /*dev [28]*/,
+                        const double *shift27 /*host [27][3]*/, double *dx, double *dy, double *dz, int *dtag,
+                        int *dtype, int *dmask, hipStream_t s);
+// per-step payload: merged float4 pair in the receiver's frame (centre c_recv), signature included
+void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start /*dev [28]*/,
+                         const double *shift27 /*host [27][3]*/, const double *center27 /*host [27][3]*/,
+                         uint32_t seed, float4 *dcoord, float4 *dveloc, hipStream_t s);
+
+// ---- cell binning (neighbor_meso.cu:386-475) ----------------------------------------------------------
+void launch_assign_bin(const AtomSoA &a, const BinGeom &g, int nlocal, int nall, uint32_t *bin_id, int *atom_id,
+                       hipStream_t s);
+void launch_bin_bounds(const uint32_t *sorted_bin, int nall, int nbin, int *bin_start /*[nbin+1]*/,
+                       hipStream_t s);
+
+// ---- neighbour table (neigh_build_meso.cu:20-240) -----------------------------------------------------
+// Table layout (wave64): entry p of atom i at table[((i>>6)*n_col + p)*64 + (i&63)].
+void launch_neigh_build_simple(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
+                               const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col,
+                               int *count, int *table, int *overflow, hipStream_t s);
+void launch_neigh_build_wave(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
+                             const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col,
+                             int *count, int *table, int *overflow, hipStream_t s);
+
+// ---- pair force (pair_dpd_meso.cu:91-205, pair_dpd_fast_meso.cu:91-205) -------------------------------
+struct PairArgs {
+    const float4 *coord4, *veloc4;
+    const int *count, *table;
+    int n_col;
+    double *f[3];
+    double *e_pair;       // nullable
+    double *virial[6];    // nullable when e_pair is null
+    const double *coeff64;
+    const float *coeff32;
+    int ntypes;
+    double dt_inv_sqrt;
+    int beg, end;
+    int accumulate;       // 1: f += (reference semantics), 0: f = (force_clear fused)
+};
+void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
+
+// ---- unit kernels for known-answer tests --------------------------------------------------------------
+void launch_test_tea(const uint32_t *u, const uint32_t *v, int n, int rounds, uint32_t *out0, uint32_t *out1,
+                     hipStream_t s);
+void launch_test_gaussian(const uint32_t *u, const uint32_t *v, int n, double *out_dp, float *out_sp,
+                          hipStream_t s);
+
+} // namespace meso

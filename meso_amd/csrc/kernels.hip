@@ -1,0 +1,878 @@
+// HIP kernels of the DPD hot path for gfx950 (CDNA4, wave64).  See kernels.h for the map to the
+// reference kernels.  Compiled with -ffp-contract=off; fused ops are written as fma()/fmaf().
+#include "kernels.h"
+#include "meso_device.h"
+
+namespace meso {
+
+static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
+static inline int capgrid(long n, int b, int cap = 256 * 8) { int g = nblk(n, b); return g < 1 ? 1 : (g > cap ? cap : g); }
+
+// =========================================================================================
+// atom kernels
+// =========================================================================================
+
+// gpu_merge_xvt (atom_vec_meso.cu:142-167): fp64 SoA -> float4 pair, recentred, signature in .w
+__global__ void __launch_bounds__(256) k_merge_xvt(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, const double *__restrict__ vx,
+                                                   const double *__restrict__ vy, const double *__restrict__ vz,
+                                                   const int *__restrict__ type, const int *__restrict__ tag,
+                                                   float4 *__restrict__ coord4, float4 *__restrict__ veloc4,
+                                                   double cx, double cy, double cz, u32 seed, int beg, int end)
+{
+    for (int i = beg + blockDim.x * blockIdx.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        float4 c;
+        c.x = (float)(x[i] - cx);
+        c.y = (float)(y[i] - cy);
+        c.z = (float)(z[i] - cz);
+        c.w = __uint_as_float((u32)(type[i] - 1));
+        coord4[i] = c;
+        float4 v;
+        v.x = (float)vx[i];
+        v.y = (float)vy[i];
+        v.z = (float)vz[i];
+        v.w = __uint_as_float(signature(seed, tag[i], v.x, v.y, v.z));
+        veloc4[i] = v;
+    }
+}
+
+void launch_merge_xvt(const AtomSoA &a, float4 *coord4, float4 *veloc4, double cx, double cy, double cz,
+                      uint32_t seed, int beg, int end, hipStream_t s)
+{
+    if (end <= beg) return;
+    hipLaunchKernelGGL(k_merge_xvt, dim3(capgrid(end - beg, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], a.v[0],
+                       a.v[1], a.v[2], a.type, a.tag, coord4, veloc4, cx, cy, cz, seed, beg, end);
+}
+
+// gpu_fix_NVE_init_intgrate<0> (fix_nve_meso.cu:62-95)
+__global__ void __launch_bounds__(256) k_nve_initial(double *__restrict__ x, double *__restrict__ y,
+                                                     double *__restrict__ z, double *__restrict__ vx,
+                                                     double *__restrict__ vy, double *__restrict__ vz,
+                                                     const double *__restrict__ fx, const double *__restrict__ fy,
+                                                     const double *__restrict__ fz, const int *__restrict__ mask,
+                                                     const double *__restrict__ mass, double dtf, double dtv,
+                                                     int groupbit, int n)
+{
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (mask[i] & groupbit) {
+            double dtfm = dtf * rcp_poly(mass[i]);
+            double a = vx[i] + dtfm * fx[i], b = vy[i] + dtfm * fy[i], c = vz[i] + dtfm * fz[i];
+            vx[i] = a; vy[i] = b; vz[i] = c;
+            x[i] += dtv * a; y[i] += dtv * b; z[i] += dtv * c;
+        }
+    }
+}
+
+void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_nve_initial, dim3(capgrid(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], a.v[0], a.v[1],
+                       a.v[2], a.f[0], a.f[1], a.f[2], a.mask, a.mass, dtf, dtv, groupbit, n);
+}
+
+// gpu_fix_NVE_final_integrate (fix_nve_meso.cu:157-178)
+__global__ void __launch_bounds__(256) k_nve_final(double *__restrict__ vx, double *__restrict__ vy,
+                                                   double *__restrict__ vz, const double *__restrict__ fx,
+                                                   const double *__restrict__ fy, const double *__restrict__ fz,
+                                                   const int *__restrict__ mask, const double *__restrict__ mass,
+                                                   double dtf, int groupbit, int n)
+{
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (mask[i] & groupbit) {
+            double dtfm = dtf * rcp_poly(mass[i]);
+            vx[i] += dtfm * fx[i]; vy[i] += dtfm * fy[i]; vz[i] += dtfm * fz[i];
+        }
+    }
+}
+
+void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_nve_final, dim3(capgrid(n, 256)), dim3(256), 0, s, a.v[0], a.v[1], a.v[2], a.f[0], a.f[1],
+                       a.f[2], a.mask, a.mass, dtf, groupbit, n);
+}
+
+// ---- deterministic two-stage block reductions (replace gpu_reduce_sum_host, math_meso.h:677-692)
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ inline double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+template <int OP>
+__device__ inline double block_reduce(double v)
+{
+    __shared__ double sm[4];
+    v = OP == 0 ? wave_sum(v) : wave_max(v);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        r = sm[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); k++) r = OP == 0 ? r + sm[k] : fmax(r, sm[k]);
+    }
+    __syncthreads();
+    return r;
+}
+
+// gpu_eK_scalar (compute_temp_meso.cu:58-75) fused with the first reduction stage
+__global__ void __launch_bounds__(256) k_sum_mv2(const double *__restrict__ vx, const double *__restrict__ vy,
+                                                 const double *__restrict__ vz, const double *__restrict__ mass,
+                                                 const int *__restrict__ mask, int groupbit, int n,
+                                                 double *__restrict__ partial)
+{
+    double t = 0.0;
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (mask[i] & groupbit) t += mass[i] * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
+    double r = block_reduce<0>(t);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__ partial, int n,
+                                                      double *__restrict__ out)
+{
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) t = OP == 0 ? t + partial[i] : fmax(t, partial[i]);
+    double r = block_reduce<OP>(t);
+    if (threadIdx.x == 0) *out = r;
+}
+
+#define MESO_REDUCE_BLOCKS 512
+
+void launch_sum_mv2(const AtomSoA &a, int groupbit, int n, double *partial, double *result, hipStream_t s)
+{
+    int g = capgrid(n, 256, MESO_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_sum_mv2, dim3(g), dim3(256), 0, s, a.v[0], a.v[1], a.v[2], a.mass, a.mask, groupbit, n,
+                       partial);
+    hipLaunchKernelGGL(k_reduce_final<0>, dim3(1), dim3(256), 0, s, partial, g, result);
+}
+
+// Neighbor::check_distance equivalent: max squared displacement since the last build
+__global__ void __launch_bounds__(256) k_max_disp2(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, const double *__restrict__ xhold,
+                                                   int n, int stride, double *__restrict__ partial)
+{
+    double t = 0.0;
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double dx = x[i] - xhold[i], dy = y[i] - xhold[stride + i], dz = z[i] - xhold[2 * stride + i];
+        t = fmax(t, dx * dx + dy * dy + dz * dz);
+    }
+    double r = block_reduce<1>(t);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+void launch_max_disp2(const AtomSoA &a, const double *xhold, int n, int stride, double *partial, double *result,
+                      hipStream_t s)
+{
+    int g = capgrid(n, 256, MESO_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_max_disp2, dim3(g), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], xhold, n, stride, partial);
+    hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(256), 0, s, partial, g, result);
+}
+
+__global__ void __launch_bounds__(256) k_copy_hold(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, double *__restrict__ xhold, int n,
+                                                   int stride)
+{
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        xhold[i] = x[i]; xhold[stride + i] = y[i]; xhold[2 * stride + i] = z[i];
+    }
+}
+
+void launch_copy_hold(const AtomSoA &a, double *xhold, int n, int stride, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_copy_hold, dim3(capgrid(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], xhold, n, stride);
+}
+
+// MesoDomain::pbc (domain_meso.cu:30-145): wrap into [lo,hi), update image flags (10 bits/dim)
+__global__ void __launch_bounds__(256) k_pbc(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                             int *__restrict__ image, double lox, double loy, double loz, double hix,
+                                             double hiy, double hiz, int px, int py, int pz, int n)
+{
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int img = image[i];
+        int ix = img & 1023, iy = (img >> 10) & 1023, iz = img >> 20;
+        if (px) {
+            double c = x[i], p = hix - lox;
+            if (c < lox) { c += p; ix = (ix - 1) & 1023; }
+            if (c >= hix) { c -= p; c = fmax(c, lox); ix = (ix + 1) & 1023; }
+            x[i] = c;
+        }
+        if (py) {
+            double c = y[i], p = hiy - loy;
+            if (c < loy) { c += p; iy = (iy - 1) & 1023; }
+            if (c >= hiy) { c -= p; c = fmax(c, loy); iy = (iy + 1) & 1023; }
+            y[i] = c;
+        }
+        if (pz) {
+            double c = z[i], p = hiz - loz;
+            if (c < loz) { c += p; iz = (iz - 1) & 1023; }
+            if (c >= hiz) { c -= p; c = fmax(c, loz); iz = (iz + 1) & 1023; }
+            z[i] = c;
+        }
+        image[i] = ix | (iy << 10) | (iz << 20);
+    }
+}
+
+void launch_pbc(const AtomSoA &a, const double *lo, const double *hi, const int *per, int n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pbc, dim3(capgrid(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], a.image, lo[0], lo[1],
+                       lo[2], hi[0], hi[1], hi[2], per[0], per[1], per[2], n);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_fill(T *__restrict__ p, T val, int n)
+{
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = val;
+}
+void launch_fill_f64(double *p, double val, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_fill<double>, dim3(capgrid(n, 256)), dim3(256), 0, s, p, val, n);
+}
+void launch_fill_i32(int *p, int val, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_fill<int>, dim3(capgrid(n, 256)), dim3(256), 0, s, p, val, n);
+}
+
+// gpu_unpack_by_type (atom_vec_meso.h:90)
+__global__ void __launch_bounds__(256) k_unpack_mass(const int *__restrict__ type, const double *__restrict__ mt,
+                                                     double *__restrict__ mass, int beg, int end)
+{
+    for (int i = beg + blockDim.x * blockIdx.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x)
+        mass[i] = mt[type[i]];
+}
+void launch_unpack_mass(const int *type, const double *mass_type, int, double *mass, int beg, int end, hipStream_t s)
+{
+    if (end > beg)
+        hipLaunchKernelGGL(k_unpack_mass, dim3(capgrid(end - beg, 256)), dim3(256), 0, s, type, mass_type, mass, beg, end);
+}
+
+// =========================================================================================
+// reorder
+// =========================================================================================
+int reorder_key_bits(const BinGeom &g)
+{
+    int max_bin = g.mbin[0] > g.mbin[1] ? g.mbin[0] : g.mbin[1];
+    if (g.mbin[2] > max_bin) max_bin = g.mbin[2];
+    int l1 = 0;
+    while ((1 << (l1 + 1)) <= max_bin * 2) l1++;   // floor(log2(2*max_bin))
+    return 1 + 3 * l1 + 12;
+}
+
+// gpu_build_reorder_keypair<1> (atom_meso.cu:268-308) with borderness (comm_meso.cu:188-254) computed in place
+__global__ void __launch_bounds__(256) k_reorder_keys(const double *__restrict__ x, const double *__restrict__ y,
+                                                      const double *__restrict__ z, BinGeom g, double slx, double sly,
+                                                      double slz, double shx, double shy, double shz, int border_bit,
+                                                      u64 *__restrict__ key, int *__restrict__ val, int n)
+{
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i >= n) return;
+    const double c[3] = {x[i], y[i], z[i]};
+    u32 b[3], sc[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        b[d] = (u32)clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1), 0, g.mbin[d]);
+        sc[d] = (u32)clampi((int)((c[d] - g.lo[d] - ((double)b[d] - 1) * g.binsize[d]) * (16 * g.bininv[d])), 0, 16);
+    }
+    u64 k = ((u64)interleave3(b[0], b[1], b[2]) << 12) | (u64)interleave3(sc[0], sc[1], sc[2]);
+    bool border = c[0] <= slx || c[0] >= shx || c[1] <= sly || c[1] >= shy || c[2] <= slz || c[2] >= shz;
+    if (border) k |= (1ULL << border_bit);
+    key[i] = k;
+    val[i] = i;
+}
+
+void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi, const int *,
+                         uint64_t *key, int *val, int n, hipStream_t s)
+{
+    if (n <= 0) return;
+    int bits = reorder_key_bits(g);
+    hipLaunchKernelGGL(k_reorder_keys, dim3(nblk(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, slab_lo[0],
+                       slab_lo[1], slab_lo[2], slab_hi[0], slab_hi[1], slab_hi[2], bits - 1, (u64 *)key, val, n);
+}
+
+// first sorted position whose key carries the border bit == n_bulk
+__global__ void __launch_bounds__(256) k_count_border(const u64 *__restrict__ key, int n, int border_bit,
+                                                      int *__restrict__ n_bulk)
+{
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i > n) return;
+    bool cur = (i == n) ? true : ((key[i] >> border_bit) & 1ULL) != 0;
+    bool prev = (i == 0) ? false : ((key[i - 1] >> border_bit) & 1ULL) != 0;
+    if (cur && !prev) *n_bulk = i;
+}
+void launch_count_border(const uint64_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_count_border, dim3(nblk(n + 1, 256)), dim3(256), 0, s, (const u64 *)sorted_key, n, border_bit,
+                       n_bulk_out);
+}
+
+// gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
+__global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n)
+{
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i >= n) return;
+    int j = from[i];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        dst.x[d][i] = src.x[d][j];
+        dst.v[d][i] = src.v[d][j];
+        dst.f[d][i] = src.f[d][j];
+    }
+    dst.tag[i] = src.tag[j];
+    dst.type[i] = src.type[j];
+    dst.mask[i] = src.mask[j];
+    dst.image[i] = src.image[j];
+    dst.mass[i] = src.mass[j];
+}
+void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n);
+}
+
+// gpu_permute_from2to (atom_meso.cu:310-314)
+__global__ void __launch_bounds__(256) k_invert_perm(const int *__restrict__ A, int *__restrict__ T, int n)
+{
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i < n) T[A[i]] = i;
+}
+void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_invert_perm, dim3(nblk(n, 256)), dim3(256), 0, s, perm_from, perm_to, n);
+}
+
+// =========================================================================================
+// halo: border lists (deterministic two-pass compaction, no global atomics) + pack kernels
+// =========================================================================================
+#define BORDER_CHUNK 256
+
+__device__ inline int near_flags(double cx, double cy, double cz, const double *sl, const double *sh)
+{
+    // bit 2d: near the low face of dim d (sent down), bit 2d+1: near the high face (sent up)
+    int f = 0;
+    if (cx <= sl[0]) f |= 1;
+    if (cx >= sh[0]) f |= 2;
+    if (cy <= sl[1]) f |= 4;
+    if (cy >= sh[1]) f |= 8;
+    if (cz <= sl[2]) f |= 16;
+    if (cz >= sh[2]) f |= 32;
+    return f;
+}
+
+__device__ inline bool in_dir(int flags, int dir)
+{
+    int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
+    bool okx = sx == 0 || (sx < 0 ? (flags & 1) : (flags & 2));
+    bool oky = sy == 0 || (sy < 0 ? (flags & 4) : (flags & 8));
+    bool okz = sz == 0 || (sz < 0 ? (flags & 16) : (flags & 32));
+    return okx && oky && okz;
+}
+
+struct Slabs { double lo[3], hi[3]; };
+
+__global__ void __launch_bounds__(BORDER_CHUNK) k_border_count(const double *__restrict__ x,
+                                                               const double *__restrict__ y,
+                                                               const double *__restrict__ z, int beg, int end,
+                                                               Slabs sl, int *__restrict__ chunk_count, int nchunk)
+{
+    int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
+    int flags = 0;
+    if (i < end) flags = near_flags(x[i], y[i], z[i], sl.lo, sl.hi);
+    for (int dir = 0; dir < 27; dir++) {
+        if (dir == 13) continue;
+        int c = __syncthreads_count(flags && in_dir(flags, dir));
+        if (threadIdx.x == 0) chunk_count[dir * nchunk + blockIdx.x] = c;
+    }
+    if (threadIdx.x == 0) chunk_count[13 * nchunk + blockIdx.x] = 0;
+}
+
+void launch_border_count(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi, const int *,
+                         int *chunk_count, int nchunk, hipStream_t s)
+{
+    if (nchunk <= 0) return;
+    Slabs sl;
+    for (int d = 0; d < 3; d++) { sl.lo[d] = slab_lo[d]; sl.hi[d] = slab_hi[d]; }
+    hipLaunchKernelGGL(k_border_count, dim3(nchunk), dim3(BORDER_CHUNK), 0, s, a.x[0], a.x[1], a.x[2], beg, end, sl,
+                       chunk_count, nchunk);
+}
+
+__global__ void __launch_bounds__(BORDER_CHUNK) k_border_fill(const double *__restrict__ x,
+                                                              const double *__restrict__ y,
+                                                              const double *__restrict__ z, int beg, int end, Slabs sl,
+                                                              const int *__restrict__ chunk_offset, int nchunk,
+                                                              int *__restrict__ sendlist)
+{
+    __shared__ int wave_tot[BORDER_CHUNK / 64];
+    int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int flags = 0;
+    if (i < end) flags = near_flags(x[i], y[i], z[i], sl.lo, sl.hi);
+    for (int dir = 0; dir < 27; dir++) {
+        if (dir == 13) continue;
+        bool hit = flags && in_dir(flags, dir);
+        u64 m = __ballot(hit);
+        int pre = __popcll(m & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int base = chunk_offset[dir * nchunk + blockIdx.x];
+        for (int k = 0; k < w; k++) base += wave_tot[k];
+        if (hit) sendlist[base + pre] = i;
+        __syncthreads();
+    }
+}
+
+void launch_border_fill(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi, const int *,
+                        const int *chunk_offset, int nchunk, int *sendlist, hipStream_t s)
+{
+    if (nchunk <= 0) return;
+    Slabs sl;
+    for (int d = 0; d < 3; d++) { sl.lo[d] = slab_lo[d]; sl.hi[d] = slab_hi[d]; }
+    hipLaunchKernelGGL(k_border_fill, dim3(nchunk), dim3(BORDER_CHUNK), 0, s, a.x[0], a.x[1], a.x[2], beg, end, sl,
+                       chunk_offset, nchunk, sendlist);
+}
+
+struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0 when not crossing a PBC)
+struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction
+
+__device__ inline int dir_of_entry(const int *__restrict__ dir_start, int k)
+{
+    // dir_start[28]: exclusive offsets of each direction's segment in the send list
+    int d = 0;
+#pragma unroll
+    for (int q = 1; q < 27; q++) d += (k >= dir_start[q]) ? 1 : 0;
+    return d;
+}
+
+// pack_border_vel (atom_vec_dpd_atomic_meso.cu:61-135), device resident: x(+shift), tag, type, mask
+__global__ void __launch_bounds__(256) k_pack_border(AtomSoA a, const int *__restrict__ sendlist, int nsend,
+                                                     const int *__restrict__ dir_start, Shift27 sh,
+                                                     double *__restrict__ dx, double *__restrict__ dy,
+                                                     double *__restrict__ dz, int *__restrict__ dtag,
+                                                     int *__restrict__ dtype, int *__restrict__ dmask)
+{
+    __shared__ int ds[28];
+    if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
+    __syncthreads();
+    int k = blockDim.x * blockIdx.x + threadIdx.x;
+    if (k >= nsend) return;
+    int j = sendlist[k];
+    int d = dir_of_entry(ds, k);
+    dx[k] = a.x[0][j] + sh.s[d][0];
+    dy[k] = a.x[1][j] + sh.s[d][1];
+    dz[k] = a.x[2][j] + sh.s[d][2];
+    dtag[k] = a.tag[j];
+    dtype[k] = a.type[j];
+    dmask[k] = a.mask[j];
+}
+
+// pack_comm_vel (atom_vec_dpd_atomic_meso.cu:165-228) fused with gpu_merge_xvt for the ghost range:
+// what travels per step is the merged float4 pair, already in the receiver's frame.
+__global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__restrict__ sendlist, int nsend,
+                                                      const int *__restrict__ dir_start, Shift27 sh, Center27 ce,
+                                                      u32 seed, float4 *__restrict__ dcoord,
+                                                      float4 *__restrict__ dveloc)
+{
+    __shared__ int ds[28];
+    if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
+    __syncthreads();
+    int k = blockDim.x * blockIdx.x + threadIdx.x;
+    if (k >= nsend) return;
+    int j = sendlist[k];
+    int d = dir_of_entry(ds, k);
+    float4 c;
+    c.x = (float)((a.x[0][j] + sh.s[d][0]) - ce.c[d][0]);
+    c.y = (float)((a.x[1][j] + sh.s[d][1]) - ce.c[d][1]);
+    c.z = (float)((a.x[2][j] + sh.s[d][2]) - ce.c[d][2]);
+    c.w = __uint_as_float((u32)(a.type[j] - 1));
+    dcoord[k] = c;
+    float4 v;
+    v.x = (float)a.v[0][j];
+    v.y = (float)a.v[1][j];
+    v.z = (float)a.v[2][j];
+    v.w = __uint_as_float(signature(seed, a.tag[j], v.x, v.y, v.z));
+    dveloc[k] = v;
+}
+
+void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start, const double *shift27,
+                        double *dx, double *dy, double *dz, int *dtag, int *dtype, int *dmask, hipStream_t s)
+{
+    if (nsend <= 0) return;
+    Shift27 sh;
+    for (int d = 0; d < 27; d++)
+        for (int k = 0; k < 3; k++) sh.s[d][k] = shift27[3 * d + k];
+    hipLaunchKernelGGL(k_pack_border, dim3(nblk(nsend, 256)), dim3(256), 0, s, a, sendlist, nsend, dir_start, sh, dx, dy,
+                       dz, dtag, dtype, dmask);
+}
+
+void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start, const double *shift27,
+                         const double *center27, uint32_t seed, float4 *dcoord, float4 *dveloc, hipStream_t s)
+{
+    if (nsend <= 0) return;
+    Shift27 sh;
+    Center27 ce;
+    for (int d = 0; d < 27; d++)
+        for (int k = 0; k < 3; k++) { sh.s[d][k] = shift27[3 * d + k]; ce.c[d][k] = center27[3 * d + k]; }
+    hipLaunchKernelGGL(k_pack_forward, dim3(nblk(nsend, 256)), dim3(256), 0, s, a, sendlist, nsend, dir_start, sh, ce,
+                       seed, dcoord, dveloc);
+}
+
+// =========================================================================================
+// cell binning
+// =========================================================================================
+// gpu_assign_bin_id (neighbor_meso.cu:386-421)
+__global__ void __launch_bounds__(256) k_assign_bin(const double *__restrict__ x, const double *__restrict__ y,
+                                                    const double *__restrict__ z, BinGeom g, int nlocal, int nall,
+                                                    u32 *__restrict__ bin_id, int *__restrict__ atom_id)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nall) return;
+    const double c[3] = {x[i], y[i], z[i]};
+    int b[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        b[d] = clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1.0), 0, g.mbin[d]);
+        if (i >= nlocal) b[d] = (c[d] >= g.lo[d]) ? (c[d] <= g.hi[d] ? b[d] : g.mbin[d] - 1) : 0;
+    }
+    atom_id[i] = i;
+    bin_id[i] = b[0] + g.mbin[0] * (b[1] + b[2] * g.mbin[1]);
+}
+void launch_assign_bin(const AtomSoA &a, const BinGeom &g, int nlocal, int nall, uint32_t *bin_id, int *atom_id,
+                       hipStream_t s)
+{
+    if (nall > 0)
+        hipLaunchKernelGGL(k_assign_bin, dim3(nblk(nall, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, nlocal, nall,
+                           bin_id, atom_id);
+}
+
+// gpu_find_bin_boundary (neighbor_meso.cu:423-460): bin_start[b] = first sorted slot with bin >= b
+__global__ void __launch_bounds__(256) k_bin_bounds(const u32 *__restrict__ sorted_bin, int nall, int nbin,
+                                                    int *__restrict__ bin_start)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nall) return;
+    int prev = (i == 0) ? -1 : (int)sorted_bin[i - 1];
+    int cur = (i == nall) ? nbin : (int)sorted_bin[i];
+    for (int b = prev + 1; b <= cur; b++) bin_start[b] = i;
+}
+void launch_bin_bounds(const uint32_t *sorted_bin, int nall, int nbin, int *bin_start, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bin_bounds, dim3(nblk(nall + 1, 256)), dim3(256), 0, s, sorted_bin, nall, nbin, bin_start);
+}
+
+// =========================================================================================
+// neighbour table
+// =========================================================================================
+__device__ inline float dist2(float4 a, float4 b)
+{
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// v1: one lane per centre atom, 27-bin walk (reference: gpu_build_neighbor_list, neigh_build_meso.cu:20-119;
+// same membership test, fp32 distance, j != i, dr2 <= rc2_tail)
+__global__ void __launch_bounds__(256) k_neigh_simple(const float4 *__restrict__ coord4,
+                                                      const u32 *__restrict__ bin_of_atom,
+                                                      const int *__restrict__ bin_start,
+                                                      const int *__restrict__ sorted_atom, BinGeom g, float rc2,
+                                                      int nlocal, int n_col, int *__restrict__ count,
+                                                      int *__restrict__ table, int *__restrict__ overflow)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlocal) return;
+    float4 ci = coord4[i];
+    int b = (int)bin_of_atom[i];
+    int bx = b % g.mbin[0], by = (b / g.mbin[0]) % g.mbin[1], bz = b / (g.mbin[0] * g.mbin[1]);
+    int *col = table + ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
+    int n = 0;
+    for (int dz = -1; dz <= 1; dz++) {
+        int z2 = bz + dz;
+        if (z2 < 0 || z2 >= g.mbin[2]) continue;
+        for (int dy = -1; dy <= 1; dy++) {
+            int y2 = by + dy;
+            if (y2 < 0 || y2 >= g.mbin[1]) continue;
+            int x0 = bx - 1 < 0 ? 0 : bx - 1, x1 = bx + 1 >= g.mbin[0] ? g.mbin[0] - 1 : bx + 1;
+            int row = g.mbin[0] * (y2 + z2 * g.mbin[1]);
+            int pb = bin_start[row + x0], pe = bin_start[row + x1 + 1];   // 3 x-adjacent bins are contiguous
+            for (int p = pb; p < pe; p++) {
+                int j = sorted_atom[p];
+                float d2 = dist2(ci, coord4[j]);
+                if (j != i && d2 <= rc2) {
+                    if (n < n_col) col[(size_t)n * 64] = j;
+                    n++;
+                }
+            }
+        }
+    }
+    if (n > n_col) { atomicMax(overflow, n); n = n_col; }
+    count[i] = n;
+}
+
+void launch_neigh_build_simple(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
+                               const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col, int *count,
+                               int *table, int *overflow, hipStream_t s)
+{
+    if (nlocal > 0)
+        hipLaunchKernelGGL(k_neigh_simple, dim3(nblk(nlocal, 256)), dim3(256), 0, s, coord4, bin_of_atom, bin_start,
+                           sorted_atom, g, rc2, nlocal, n_col, count, table, overflow);
+}
+
+// v2: one wave per 64-atom tile of centres; candidates on lanes, centres looped; ballot + popcount give
+// every hit its slot (no global atomics); rows are staged in LDS and written out as whole 256-byte
+// lines of the transposed table.  Centres of one tile are consecutive in the cell-sorted order, so the
+// candidate ranges of neighbouring centres overlap and stay in L1/L2.
+#define NB_LDS_ROWS 64        // slots staged per centre; longer rows spill straight to global
+__global__ void __launch_bounds__(64) k_neigh_wave(const float4 *__restrict__ coord4,
+                                                   const u32 *__restrict__ bin_of_atom,
+                                                   const int *__restrict__ bin_start,
+                                                   const int *__restrict__ sorted_atom, BinGeom g, float rc2,
+                                                   int nlocal, int n_col, int *__restrict__ count,
+                                                   int *__restrict__ table, int *__restrict__ overflow)
+{
+    __shared__ int rows[NB_LDS_ROWS][65];   // [slot][centre], +1 pad: conflict-free both ways
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int base = tile * 64;
+    const int ncen = min(64, nlocal - base);
+    const u64 lt = (1ULL << lane) - 1ULL;
+    int *tcol = table + ((size_t)tile * n_col) * 64;
+
+    // lane c keeps centre c's data; broadcast to the wave with readlane as centres are visited
+    float4 cme = make_float4(0.f, 0.f, 0.f, 0.f);
+    int bme = 0;
+    if (lane < ncen) { cme = coord4[base + lane]; bme = (int)bin_of_atom[base + lane]; }
+    int my_n = 0;   // lane c: row length of centre c
+
+    int c = 0;
+    while (c < ncen) {
+        // group of consecutive centres sharing one bin (cell-sorted order makes groups long)
+        int b = __shfl(bme, c, 64);
+        u64 same = __ballot(lane >= c && lane < ncen && bme == b);
+        // centres c..ce-1 share the bin: length of the run of ones starting at bit c
+        u64 run = ~(same >> c);
+        int glen = run ? __ffsll((long long)run) - 1 : 64 - c;
+        int ce = c + glen;
+        int bx = b % g.mbin[0], by = (b / g.mbin[0]) % g.mbin[1], bz = b / (g.mbin[0] * g.mbin[1]);
+        // the 27-bin stencil is 9 contiguous runs of the cell-sorted array (3 x-adjacent bins each);
+        // concatenate them into one virtual candidate range so every 64-lane batch is full
+        int rs[9], rl[9], total = 0;
+        int x0 = bx - 1 < 0 ? 0 : bx - 1, x1 = bx + 1 >= g.mbin[0] ? g.mbin[0] - 1 : bx + 1;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int z2 = bz + k / 3 - 1, y2 = by + k % 3 - 1;
+            bool ok = z2 >= 0 && z2 < g.mbin[2] && y2 >= 0 && y2 < g.mbin[1];
+            int row = ok ? g.mbin[0] * (y2 + z2 * g.mbin[1]) : 0;
+            int pb = bin_start[row + x0], pe = bin_start[row + x1 + 1];
+            rs[k] = pb;
+            rl[k] = ok ? pe - pb : 0;
+            total += rl[k];
+        }
+        for (int v0 = 0; v0 < total; v0 += 64) {
+            int off = v0 + lane, p = -1;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                if (p < 0) {
+                    if (off < rl[k]) p = rs[k] + off;
+                    else off -= rl[k];
+                }
+            }
+            int j = -1;
+            float4 cj = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+            if (p >= 0) { j = sorted_atom[p]; cj = coord4[j]; }
+            for (int q = c; q < ce; q++) {
+                float4 cq;
+                cq.x = __shfl(cme.x, q, 64);
+                cq.y = __shfl(cme.y, q, 64);
+                cq.z = __shfl(cme.z, q, 64);
+                float d2 = dist2(cq, cj);
+                bool hit = (j >= 0) && (j != base + q) && (d2 <= rc2);
+                u64 m = __ballot(hit);
+                if (m == 0) continue;
+                int nq = __shfl(my_n, q, 64);
+                int slot = nq + __popcll(m & lt);
+                if (hit) {
+                    if (slot < NB_LDS_ROWS) rows[slot][q] = j;
+                    else if (slot < n_col) tcol[(size_t)slot * 64 + q] = j;
+                }
+                if (lane == q) my_n = nq + __popcll(m);
+            }
+        }
+        c = ce;
+    }
+    // overflow check + counts
+    int nfin = my_n;
+    if (nfin > n_col) { atomicMax(overflow, nfin); nfin = n_col; }
+    if (lane < ncen) count[base + lane] = nfin;
+    // write staged rows: slot-major, one coalesced 256-B line per slot
+    int nmax = nfin;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    int lim = nmax < NB_LDS_ROWS ? nmax : NB_LDS_ROWS;
+    __syncthreads();
+    for (int sidx = 0; sidx < lim; sidx++)
+        if (sidx < nfin) tcol[(size_t)sidx * 64 + lane] = rows[sidx][lane];
+}
+
+void launch_neigh_build_wave(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
+                              const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col, int *count,
+                              int *table, int *overflow, hipStream_t s)
+{
+    if (nlocal > 0)
+        hipLaunchKernelGGL(k_neigh_wave, dim3(nblk(nlocal, 64)), dim3(64), 0, s, coord4, bin_of_atom, bin_start,
+                           sorted_atom, g, rc2, nlocal, n_col, count, table, overflow);
+}
+
+// =========================================================================================
+// pair force, v1: one lane per i-particle over the transposed table
+// =========================================================================================
+template <bool FAST, bool EV>
+__global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
+{
+    extern __shared__ double smem[];
+    double *cf64 = smem;
+    float *cf32 = (float *)smem;
+    const int ncf = a.ntypes * a.ntypes * N_COEFF;
+    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
+        if (FAST) cf32[p] = a.coeff32[p];
+        else cf64[p] = a.coeff64[p];
+    }
+    __syncthreads();
+    int i = a.beg + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.end) return;
+
+    const float4 c1 = a.coord4[i];
+    const float4 v1 = a.veloc4[i];
+    const u32 t1 = __float_as_uint(c1.w), s1 = __float_as_uint(v1.w);
+    const int n = a.count[i];
+    const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
+
+    if (FAST) {
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        const float dtis = (float)a.dt_inv_sqrt;
+        for (int p = 0; p < n; p++) {
+            int j = col[(size_t)p * 64];
+            float4 c2 = a.coord4[j];
+            float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
+            float rsq = dx * dx + dy * dy + dz * dz;
+            const float *cf = cf32 + (t1 * a.ntypes + __float_as_uint(c2.w)) * N_COEFF;
+            if (rsq < cf[P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ) {
+                float4 v2 = a.veloc4[j];
+                float rn = gaussian_tea_fast(s1, __float_as_uint(v2.w));
+                float rinv = __builtin_amdgcn_rsqf(rsq);
+                float r = rsq * rinv;
+                float dvx = v1.x - v2.x, dvy = v1.y - v2.y, dvz = v1.z - v2.z;
+                float dot = dx * dvx + dy * dvy + dz * dvz;
+                float wc = 1.0f - r * cf[P_CUTINV];
+                float ew = cf[P_EXPW];
+                float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
+                float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis);
+                fpair *= rinv;
+                fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+            }
+        }
+        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
+        else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
+    } else {
+        double fx = 0., fy = 0., fz = 0., energy = 0.;
+        double vr[6] = {0., 0., 0., 0., 0., 0.};
+        for (int p = 0; p < n; p++) {
+            int j = col[(size_t)p * 64];
+            float4 c2 = a.coord4[j];
+            double dx = (double)c1.x - (double)c2.x;
+            double dy = (double)c1.y - (double)c2.y;
+            double dz = (double)c1.z - (double)c2.z;
+            double rsq = dx * dx + dy * dy + dz * dz;
+            const double *cf = cf64 + (t1 * a.ntypes + __float_as_uint(c2.w)) * N_COEFF;
+            if (rsq < cf[P_CUTSQ] && rsq >= MESO_EPSILON_SQ) {
+                float4 v2 = a.veloc4[j];
+                double rn = gaussian_tea(s1, __float_as_uint(v2.w));
+                double rinv = rsqrt(rsq);
+                double r = rsq * rinv;
+                double dvx = (double)v1.x - (double)v2.x;
+                double dvy = (double)v1.y - (double)v2.y;
+                double dvz = (double)v1.z - (double)v2.z;
+                double dot = dx * dvx + dy * dvy + dz * dvz;
+                double wc = 1.0 - r * cf[P_CUTINV];
+                double ew = cf[P_EXPW];
+                double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
+                double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) +
+                               (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
+                fpair *= rinv;
+                fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+                if (EV) {
+                    vr[0] += dx * dx * fpair; vr[1] += dy * dy * fpair; vr[2] += dz * dz * fpair;
+                    vr[3] += dx * dy * fpair; vr[4] += dx * dz * fpair; vr[5] += dy * dz * fpair;
+                    energy += 0.5 * cf[P_A0] * cf[P_CUT] * wc * wc;
+                }
+            }
+        }
+        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
+        else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
+        if (EV) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (a.accumulate) a.virial[k][i] += vr[k] * 0.5;
+                else a.virial[k][i] = vr[k] * 0.5;
+            }
+            a.e_pair[i] = energy * 0.5;
+        }
+    }
+}
+
+void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s)
+{
+    int n = p.end - p.beg;
+    if (n <= 0) return;
+    size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? sizeof(float) : sizeof(double));
+    dim3 grid(nblk(n, 256)), block(256);
+    if (fast) hipLaunchKernelGGL((k_pair_dpd<true, false>), grid, block, sm, s, p);
+    else if (evflag) hipLaunchKernelGGL((k_pair_dpd<false, true>), grid, block, sm, s, p);
+    else hipLaunchKernelGGL((k_pair_dpd<false, false>), grid, block, sm, s, p);
+}
+
+// =========================================================================================
+// known-answer test kernels
+// =========================================================================================
+__global__ void k_test_tea(const u32 *u, const u32 *v, int n, int rounds, u32 *o0, u32 *o1)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 a = u[i], b = v[i];
+    switch (rounds) {
+    case 4: tea_core<4>(a, b); break;
+    case 8: tea_core<8>(a, b); break;
+    case 16: tea_core<16>(a, b); break;
+    case 64: tea_core<64>(a, b); break;
+    default: for (int r = 0; r < rounds; r++) { u32 sum = MESO_TEA_DT * (u32)(r + 1);
+            a += ((b << 4) + MESO_TEA_K0) ^ (b + sum) ^ ((b >> 5) + MESO_TEA_K1);
+            b += ((a << 4) + MESO_TEA_K2) ^ (a + sum) ^ ((a >> 5) + MESO_TEA_K3); }
+    }
+    o0[i] = a; o1[i] = b;
+}
+void launch_test_tea(const uint32_t *u, const uint32_t *v, int n, int rounds, uint32_t *out0, uint32_t *out1,
+                     hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_test_tea, dim3(nblk(n, 256)), dim3(256), 0, s, u, v, n, rounds, out0, out1);
+}
+
+__global__ void k_test_gaussian(const u32 *u, const u32 *v, int n, double *odp, float *osp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    odp[i] = gaussian_tea(u[i], v[i]);
+    osp[i] = gaussian_tea_fast(u[i], v[i]);
+}
+void launch_test_gaussian(const uint32_t *u, const uint32_t *v, int n, double *out_dp, float *out_sp, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_test_gaussian, dim3(nblk(n, 256)), dim3(256), 0, s, u, v, n, out_dp, out_sp);
+}
+
+} // namespace meso

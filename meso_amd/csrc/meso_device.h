@@ -1,0 +1,215 @@
+// Device-side math for the DPD hot path on gfx950 (wave64).
+//
+// Restates, for CDNA4, the arithmetic of /root/reference/src/USER-MESO/math_meso.h:
+//   TEA block cipher            :444-464      gaussian_TEA<4>        :466-474
+//   gaussian_TEA_fast<4>        :476-484      __cospi / __log2u      :380-424
+//   __rsqrt / __sqrtd / __rcp   :210-238      __powd                 :332-344
+//   bit_space3 / interleave3    :166-183      __mantissa             :436-442
+// Every fused multiply-add is an explicit fma(); the translation unit is compiled with
+// -ffp-contract=off so that the CPU oracle (oracle/meso_ref.c) can reproduce each per-pair
+// quantity bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace meso {
+
+typedef uint32_t u32;
+typedef unsigned long long u64;
+
+#define MESO_WAVE 64
+#define MESO_EPSILON_SQ 1.0E-20
+#define MESO_LN_2 6.9314718055994528623E-1
+#define MESO_1_OVER_SQ2 7.0710678118654757274E-1
+#define MESO_SQRT_2 1.4142135623730950488
+#define MESO_2_TO_MINUS_31 4.6566128730773925781E-10
+#define MESO_2_TO_MINUS_32 2.3283064365386962891E-10
+
+// coefficient table layout, pair_dpd_meso.h:15-24
+enum { P_CUT = 0, P_CUTSQ = 1, P_CUTINV = 2, P_EXPW = 3, P_A0 = 4, P_GAMMA = 5, P_SIGMA = 6, N_COEFF = 7 };
+
+__host__ __device__ inline u32 bit_space3(u32 x)
+{
+    x = (x | (x << 12)) & 0X00FC003FU;
+    x = (x | (x << 6)) & 0X381C0E07U;
+    x = (x | (x << 4)) & 0X190C8643U;
+    x = (x | (x << 2)) & 0X49249249U;
+    return x;
+}
+__host__ __device__ inline u32 interleave3(u32 i, u32 j, u32 k)
+{
+    return bit_space3(i) | (bit_space3(j) << 1) | (bit_space3(k) << 2);
+}
+
+__device__ inline u32 mantissa3(float u, float v, float w)
+{
+    u32 i = __float_as_uint(u) & 0X7FF000U;
+    u32 j = __float_as_uint(v) & 0X7FF000U;
+    u32 k = __float_as_uint(w) & 0X7FF000U;
+    return interleave3(i >> 12, j >> 12, k >> 12);
+}
+
+#define MESO_TEA_K0 0xA341316Cu
+#define MESO_TEA_K1 0xC8013EA4u
+#define MESO_TEA_K2 0xAD90777Du
+#define MESO_TEA_K3 0x7E95761Eu
+#define MESO_TEA_DT 0x9E3779B9u
+
+template <int N>
+__host__ __device__ inline void tea_core(u32 &v0, u32 &v1)
+{
+    u32 sum = 0;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        sum += MESO_TEA_DT;
+        v0 += ((v1 << 4) + MESO_TEA_K0) ^ (v1 + sum) ^ ((v1 >> 5) + MESO_TEA_K1);
+        v1 += ((v0 << 4) + MESO_TEA_K2) ^ (v0 + sum) ^ ((v0 >> 5) + MESO_TEA_K3);
+    }
+}
+
+template <int N>
+__host__ __device__ inline u32 premix_tea(u32 v0, u32 v1)
+{
+    tea_core<N>(v0, v1);
+    return v0 ^ v1;
+}
+
+// per-particle signature, atom_vec_meso.cu:164
+__device__ inline u32 signature(u32 step_seed, int tag, float vx, float vy, float vz)
+{
+    return step_seed ^ premix_tea<16>(__brev((u32)tag), mantissa3(vx, vy, vz));
+}
+
+__device__ inline double two_to_n(int n) { return __longlong_as_double(((long long)(1023 + n)) << 52); }
+
+__device__ inline double rsqrt_poly(double x)
+{
+    double xr = __longlong_as_double(0X5FE660FCB5422422LL - (__double_as_longlong(x) >> 1));
+    double x2m = x * -0.5;
+    xr *= fma(xr * xr, x2m, 1.5);
+    xr *= fma(xr * xr, x2m, 1.5);
+    xr *= fma(xr * xr, x2m, 1.5);
+    xr *= fma(xr * xr, x2m, 1.5);
+    return xr;
+}
+__device__ inline double sqrtd_poly(double x) { return x * rsqrt_poly(x); }
+
+__device__ inline double rcp_poly(double x)
+{
+    double xinv = __longlong_as_double(0X7FDE62361B1C4042LL - __double_as_longlong(x));
+    xinv -= fma(x, xinv, -1.) * xinv;
+    xinv -= fma(x, xinv, -1.) * xinv;
+    xinv -= fma(x, xinv, -1.) * xinv;
+    xinv -= fma(x, xinv, -1.) * xinv;
+    return xinv;
+}
+
+__device__ inline double log2d_frac(double x)
+{
+    bool pred = x > MESO_SQRT_2;
+    x *= pred ? 0.5 : MESO_1_OVER_SQ2;
+    double z = (x - 1.) * rcp_poly(x + 1.);
+    double y = z * z * 33.9705627484771406;
+    double s = 4.0928048937567843469E-12;
+    s = fma(s, y, 1.4374842194796670219E-10);
+    s = fma(s, y, 5.7988453014506741861E-9);
+    s = fma(s, y, 2.4074128088151586443E-7);
+    s = fma(s, y, 1.0514733588011180538E-5);
+    s = fma(s, y, 5.0006798065881969549E-4);
+    s = fma(s, y, 2.8312651192953993354E-2);
+    s = fma(s, y, 2.8853900817779268114E+0);
+    return fma(z, s, (pred ? 1.0 : 0.5));
+}
+
+__device__ inline double exp2d_frac(double x)
+{
+    double s = 6.3026908837748924689E-10;
+    s = fma(s, x, 6.5379419072372670333E-9);
+    s = fma(s, x, 1.0258347084283025531E-7);
+    s = fma(s, x, 1.3207676270599404858E-6);
+    s = fma(s, x, 1.5253232908458899497E-5);
+    s = fma(s, x, 1.5403509189194102748E-4);
+    s = fma(s, x, 1.3333558738165095559E-3);
+    s = fma(s, x, 9.6181290971755593396E-3);
+    s = fma(s, x, 5.5504108665909870679E-2);
+    s = fma(s, x, 2.4022650695904222220E-1);
+    s = fma(s, x, 6.9314718055994653980E-1);
+    s = fma(s, x, 9.9999999999999999572E-1);
+    return s;
+}
+
+__device__ inline double powd_poly(double a, double b)
+{
+    long long bits = __double_as_longlong(a);
+    int hi = (int)(bits >> 32);
+    u32 lo = (u32)bits;
+    double I = (hi >> 20) - 1023;
+    long long fb = ((long long)((hi & 0X000FFFFF) | 0X3FF00000) << 32) | lo;
+    double F = log2d_frac(__longlong_as_double(fb));
+    double II = floor(b * (I + F));
+    return two_to_n((int)II) * exp2d_frac(fma(b, F, fma(b, I, -II)));
+}
+
+__device__ inline double cospi_poly(double x)
+{
+    x = 2.0 * x - 1.0;
+    double x2 = x * x;
+    double s = 3.41817283473266926E-6;
+    s = fma(s, x2, -1.60217135750921262E-4);
+    s = fma(s, x2, 4.68162024021793872E-3);
+    s = fma(s, x2, -7.96925872866600517E-2);
+    s = fma(s, x2, 6.45964092644060746E-1);
+    s = fma(s, x2, -1.57079632662144460E+0);
+    return s * x;
+}
+
+__device__ inline double log2u_poly(u32 x)
+{
+    int I = 31 - __clz((int)x);
+    double xx = (double)x * two_to_n(-I);
+    double ex = I - 32;
+    bool pred = xx > MESO_SQRT_2;
+    xx *= pred ? 0.5 : MESO_1_OVER_SQ2;
+    double z = (xx - 1.) * rcp_poly(xx + 1.);
+    double y = z * z * 33.9705627484771406;
+    double s = 2.55854634203511155E-7;
+    s = fma(s, y, 1.05013262724846015E-5);
+    s = fma(s, y, 5.00072802051539862E-4);
+    s = fma(s, y, 2.83126505877817866E-2);
+    s = fma(s, y, 2.88539008179006374E+0);
+    return fma(z, s, (pred ? 1.0 : 0.5) + ex);
+}
+
+// xi_ij in [-4,4], symmetric in (u,v): the larger signature is always v0.
+__device__ inline double gaussian_tea(u32 u, u32 v)
+{
+    bool pred = u > v;
+    u32 v0 = pred ? u : v, v1 = pred ? v : u;
+    tea_core<4>(v0, v1);
+    double f = cospi_poly((v0 & 0X7FFFFFFFu) * MESO_2_TO_MINUS_31) * ((v0 & 0X80000000u) ? 1.0 : -1.0);
+    double r = sqrtd_poly(-2.0 * MESO_LN_2 * log2u_poly(v1 > 1u ? v1 : 1u));
+    return fmax(-4.0, fmin(r * f, 4.0));
+}
+
+// fp32 variant: CUDA's sinpif/log2f/sqrtf become the gfx950 transcendental unit
+// (v_sin_f32 takes revolutions: sin(2*pi*x)), v_log_f32, v_sqrt_f32.
+__device__ inline float gaussian_tea_fast(u32 u, u32 v)
+{
+    bool pred = u > v;
+    u32 v0 = pred ? u : v, v1 = pred ? v : u;
+    tea_core<4>(v0, v1);
+    float t = (float)(int)v0 * (float)MESO_2_TO_MINUS_31;       // [-1,1)
+    float f = __builtin_amdgcn_sinf(0.5f * t);                  // sin(pi*t)
+    float lg = __builtin_amdgcn_logf((float)v1 * (float)MESO_2_TO_MINUS_32);
+    float r = __builtin_amdgcn_sqrtf(-2.0f * (float)MESO_LN_2 * lg);
+    return fmaxf(-4.0f, fminf(r * f, 4.0f));
+}
+
+// bins: neighbor_meso.cu:410-412 clamp at [nmin,nmax)
+__host__ __device__ inline int clampi(int i, int nmin, int nmax)
+{
+    int a = i < nmax - 1 ? i : nmax - 1;
+    return a > nmin ? a : nmin;
+}
+
+} // namespace meso

@@ -1,0 +1,93 @@
+"""Synthetic DPD input decks.
+
+The reference ships only ``example/simple/25.data`` (``48.data``/``64.data`` are missing
+blobs, ``/root/reference/.MISSING_LARGE_BLOBS``).  ``25.data`` is laid out as 4 atoms per unit
+cell, cells x-fastest, each atom at cell + U[0,1)^3; this generator reproduces that layout
+for any edge length so the 48^3 / 64^3 / 128^3 cases of ``README.md:27-35`` can be run.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RHO = 4
+
+
+def make_positions(L: int, seed: int | None = None, rho: int = RHO) -> np.ndarray:
+    """(N,3) float64 positions in [0,L)^3, N = rho*L^3, atom k (0-based) in cell k//rho."""
+    rng = np.random.default_rng(L if seed is None else seed)
+    n = rho * L ** 3
+    c = np.arange(n) // rho
+    cell = np.stack([c % L, (c // L) % L, c // (L * L)], axis=1).astype(np.float64)
+    x = cell + rng.random((n, 3))
+    # guard the (measure-zero) case cell+u == L after rounding
+    return np.minimum(x, np.nextafter(float(L), 0.0))
+
+
+def make_velocities(n: int, seed: int, temperature: float = 1.0, mass: float = 1.0) -> np.ndarray:
+    """U(-0.5,0.5)^3, momentum zeroed, rescaled to T (dof = 3N-3) - SURVEY.md 8d."""
+    rng = np.random.default_rng(seed)
+    v = rng.random((n, 3)) - 0.5
+    v -= v.mean(axis=0)
+    t = mass * (v * v).sum() / (3.0 * n - 3.0)
+    return v * np.sqrt(temperature / t)
+
+
+def make_box(L: int, seed: int | None = None):
+    """positions, velocities, box_lo, box_hi for the rho=4 cube of edge L."""
+    x = make_positions(L, seed)
+    v = make_velocities(len(x), (L if seed is None else seed) + 1000)
+    return x, v, np.zeros(3), np.full(3, float(L))
+
+
+def write_data(path: str, x: np.ndarray, lo, hi, v: np.ndarray | None = None,
+               types: np.ndarray | None = None, ntypes: int = 1) -> None:
+    """LAMMPS ``read_data`` file (atom_style atomic / dpd/atomic/meso), optional Velocities."""
+    n = len(x)
+    if types is None:
+        types = np.ones(n, dtype=np.int64)
+    with open(path, "w") as f:
+        f.write("LAMMPS\n\n%d atoms\n\n%d atom types\n\n" % (n, ntypes))
+        for d, a in enumerate("xyz"):
+            f.write("%.17g %.17g %slo %shi\n" % (lo[d], hi[d], a, a))
+        f.write("\nMasses\n\n")
+        for t in range(1, ntypes + 1):
+            f.write("%d 1.000000\n" % t)
+        f.write("\nAtoms\n\n")
+        for i in range(n):
+            f.write("%d %d %.17g %.17g %.17g\n" % (i + 1, types[i], x[i, 0], x[i, 1], x[i, 2]))
+        if v is not None:
+            f.write("\nVelocities\n\n")
+            for i in range(n):
+                f.write("%d %.17g %.17g %.17g\n" % (i + 1, v[i, 0], v[i, 1], v[i, 2]))
+
+
+def read_data(path: str):
+    """Minimal reader for the files above and the reference's 25.data."""
+    with open(path) as f:
+        lines = [ln.strip() for ln in f]
+    n = ntypes = 0
+    lo, hi = np.zeros(3), np.zeros(3)
+    for ln in lines[:40]:
+        w = ln.split()
+        if len(w) == 2 and w[1] == "atoms":
+            n = int(w[0])
+        elif len(w) == 3 and w[1] == "atom" and w[2] == "types":
+            ntypes = int(w[0])
+        elif len(w) == 4 and w[2] in ("xlo", "ylo", "zlo"):
+            d = "xyz".index(w[2][0])
+            lo[d], hi[d] = float(w[0]), float(w[1])
+    ia = lines.index("Atoms")
+    rows = [ln.split() for ln in lines[ia + 1:] if ln][:n]
+    arr = np.array(rows, dtype=np.float64)
+    order = np.argsort(arr[:, 0].astype(np.int64), kind="stable")
+    arr = arr[order]
+    x = np.ascontiguousarray(arr[:, 2:5])
+    types = arr[:, 1].astype(np.int32)
+    v = None
+    if "Velocities" in lines:
+        iv = lines.index("Velocities")
+        rows = [ln.split() for ln in lines[iv + 1:] if ln][:n]
+        va = np.array(rows, dtype=np.float64)
+        va = va[np.argsort(va[:, 0].astype(np.int64), kind="stable")]
+        v = np.ascontiguousarray(va[:, 1:4])
+    return x, v, types, ntypes, lo, hi

@@ -1,0 +1,142 @@
+"""CPU mirror of one-rank ``run_style mvv/meso`` built from the oracle's C pieces
+(TEST INFRASTRUCTURE ONLY - see oracle/meso_ref.c header; parity unpinned vs the CUDA path).
+
+Follows ModifiedVerlet::setup/run (/root/reference/src/USER-MESO/mvv_meso.cu:139-219, 243-425)
+for a periodic box on a single rank: ghosts are the periodic images inside
+[lo-cutghost, hi+cutghost] (Comm::borders slab rule ``x >= lo && x <= hi``,
+/root/reference/src/comm.cpp:994-998, shift added once per dimension as
+pack_border_vel does, atom_vec_dpd_atomic_meso.cu:61-135).  Atom order is never
+permuted here (the reference's reorder only changes summation order).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import bindings as ob
+
+
+def periodic_ghosts(x, lo, hi, cut):
+    """Return (src, shift) of ghost images: 3-stage scheme (x, then y incl. x-ghosts, then z)."""
+    prd = hi - lo
+    src = np.arange(len(x))
+    sh = np.zeros((len(x), 3))
+    pos = x.copy()
+    nloc = len(x)
+    for d in range(3):
+        m_lo = pos[:, d] <= lo[d] + cut      # sent "down": appears above the high face
+        m_hi = pos[:, d] >= hi[d] - cut
+        add_src = np.concatenate([src[m_lo], src[m_hi]])
+        s_lo = sh[m_lo].copy(); s_lo[:, d] = prd[d]
+        s_hi = sh[m_hi].copy(); s_hi[:, d] = -prd[d]
+        add_sh = np.concatenate([s_lo, s_hi])
+        p_lo = pos[m_lo].copy(); p_lo[:, d] += prd[d]
+        p_hi = pos[m_hi].copy(); p_hi[:, d] -= prd[d]
+        src = np.concatenate([src, add_src])
+        sh = np.concatenate([sh, add_sh])
+        pos = np.concatenate([pos, p_lo, p_hi])
+    return src[nloc:], sh[nloc:]
+
+
+class MesoRefSim:
+    def __init__(self, x, v, lo, hi, types=None, ntypes=1, mass=None, skin=0.3, every=5,
+                 dt=0.005, seed=419084618, fast=False, stride=160):
+        self.n = len(x)
+        self.x = np.array(x, dtype=np.float64)
+        self.v = np.array(v, dtype=np.float64)
+        self.f = np.zeros((self.n, 3))
+        self.lo = np.array(lo, dtype=np.float64)
+        self.hi = np.array(hi, dtype=np.float64)
+        self.types = np.ones(self.n, np.int32) if types is None else np.array(types, np.int32)
+        self.tags = np.arange(1, self.n + 1, dtype=np.int32)
+        self.mask = np.ones(self.n, np.int32)
+        self.ntypes = ntypes
+        self.mass_type = np.ones(ntypes + 1) if mass is None else np.array(mass, dtype=np.float64)
+        self.skin, self.every, self.dt, self.seed, self.fast = skin, every, dt, seed, fast
+        self.stride = stride
+        self.coeffs = {}
+        self.ntimestep = 0
+        self.ago = 0
+        self.M = ob.meso_lib()
+
+    def pair_coeff(self, i, j, a0, gamma, sigma, expw=1.0, cut=1.0):
+        self.coeffs[(min(i, j), max(i, j))] = (a0, gamma, sigma, expw, cut)
+
+    # -- pieces -------------------------------------------------------------
+    def _pbc(self):
+        prd = self.hi - self.lo
+        for d in range(3):
+            c = self.x[:, d]
+            c[c < self.lo[d]] += prd[d]
+            m = c >= self.hi[d]
+            c[m] -= prd[d]
+            c[m] = np.maximum(c[m], self.lo[d])
+
+    def _borders(self):
+        self.gsrc, self.gshift = periodic_ghosts(self.x, self.lo, self.hi, self.cutghost)
+
+    def _all(self):
+        xa = np.concatenate([self.x, self.x[self.gsrc] + self.gshift])
+        va = np.concatenate([self.v, self.v[self.gsrc]])
+        ta = np.concatenate([self.types, self.types[self.gsrc]])
+        ga = np.concatenate([self.tags, self.tags[self.gsrc]])
+        return xa, va, ta, ga
+
+    def _merge(self, seed):
+        xa, va, ta, ga = self._all()
+        center = 0.5 * (self.hi + self.lo)
+        return ob.merge_xvt(xa, va, ta, ga, center, seed)
+
+    def _build(self):
+        c4, _ = self._merge(0)
+        self.count, self.table, self.maxlen = ob.neigh_full(self.n, c4, self.cutmax + self.skin, self.stride)
+        if self.maxlen > self.stride:
+            raise RuntimeError("pair table overflow")
+        self.ago = 0
+
+    def _force(self):
+        seed = self.M.meso_seed_now(self.seed, self.ntimestep)
+        self.c4, self.v4 = self._merge(seed)
+        self.f = ob.pair_dpd(self.n, self.c4, self.v4, self.count, self.table, self.coeff, self.ntypes,
+                             self.dt, fast=self.fast)
+
+    def setup(self):
+        self.cutmax = max(c[4] for c in self.coeffs.values())
+        self.cutghost = self.cutmax + self.skin
+        self.coeff = ob.make_coeff(self.ntypes, self.coeffs)
+        self.mass = self.mass_type[self.types]
+        self._pbc()
+        self._borders()
+        self._build()
+        self._force()
+
+    def _cols(self, a):
+        return [np.ascontiguousarray(a[:, d]) for d in range(3)]
+
+    def step(self):
+        M = self.M
+        self.ntimestep += 1
+        dtf, dtv = 0.5 * self.dt, self.dt
+        xs, vs, fs = self._cols(self.x), self._cols(self.v), self._cols(self.f)
+        P = ob._ptr
+        M.meso_nve_initial(self.n, *[P(a) for a in xs], *[P(a) for a in vs], *[P(a) for a in fs],
+                           P(self.mask), P(self.mass), dtf, dtv, 1)
+        self.x = np.stack(xs, axis=1); self.v = np.stack(vs, axis=1)
+        self.ago += 1
+        if self.ago % self.every == 0:
+            self._pbc()
+            self._borders()
+            self._build()
+        self._force()
+        vs, fs = self._cols(self.v), self._cols(self.f)
+        M.meso_nve_final(self.n, *[P(a) for a in vs], *[P(a) for a in fs], P(self.mask), P(self.mass), dtf, 1)
+        self.v = np.stack(vs, axis=1)
+
+    def run(self, n):
+        for _ in range(n):
+            self.step()
+
+    @property
+    def temperature(self):
+        vs = self._cols(self.v)
+        P = ob._ptr
+        return self.M.meso_sum_mv2(self.n, *[P(a) for a in vs], P(self.mass), P(self.mask), 1) / (3.0 * self.n - 3.0)
