@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0 = auto)")
     ap.add_argument("--profile-steps", type=int, default=200)
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     return ap.parse_args()
 
 
@@ -88,6 +89,9 @@ def main():
     x, v, lo, hi = make_box(L)
     n = len(x)
     m = Meso(local_rank)
+    for kv in a.opt:
+        k, val = kv.split("=")
+        m.set_option(k, float(val))
     m.read_atoms(x, v, lo, hi)
     m.neighbor(0.3)
     m.neigh_modify(delay=0, every=a.every, check=False)

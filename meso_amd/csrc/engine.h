@@ -123,6 +123,7 @@ private:
     std::vector<int> coeff_set;
     std::vector<double> mass_type;  // ntypes+1
     int neigh_kernel = 1;           // 0 simple, 1 wave/LDS
+    int pair_kernel = 1;            // 0 lane-per-atom, 1 wave-per-tile with ballot compaction
     int fuse_clear = 1;             // pair kernel writes f instead of clear + accumulate
     long natoms_total = 0;
 

@@ -223,6 +223,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
     if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
+    if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
     return fail(1, "Unknown option '" + key + "'");
 }
@@ -688,9 +689,8 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.beg = beg; p.end = end;
     p.accumulate = 1;
     tbegin("pair");
-    // energy/virial exist only in the fp64 kernel (the reference's fast style accumulates them in fp32;
-    // thermo output steps are rare, so they take the fp64 path here)
-    launch_pair_dpd(p, ev ? 0 : pair_style, ev, stream);
+    if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
+    else launch_pair_dpd_tile(p, pair_style, stream);
     tend("pair");
     if (ev) ev_valid = true;
     return 0;
@@ -734,7 +734,8 @@ int Engine::run(int nsteps)
         p.accumulate = fuse_clear ? 0 : 1;
         if (!fuse_clear) TRY(force_clear(0));
         tbegin("pair");
-        launch_pair_dpd(p, pair_style, 0, stream);
+        if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
+        else launch_pair_dpd_tile(p, pair_style, stream);
         tend("pair");
         TRY(nve_final());
         ev_valid = false;

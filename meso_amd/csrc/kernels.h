@@ -96,6 +96,8 @@ struct PairArgs {
     int accumulate;       // 1: f += (reference semantics), 0: f = (force_clear fused)
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
+// wave-per-tile, ballot-compacted variant (forces only)
+void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s);
 
 // ---- unit kernels for known-answer tests --------------------------------------------------------------
 void launch_test_tea(const uint32_t *u, const uint32_t *v, int n, int rounds, uint32_t *out0, uint32_t *out1,

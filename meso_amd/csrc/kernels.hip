@@ -2,6 +2,7 @@
 // reference kernels.  Compiled with -ffp-contract=off; fused ops are written as fma()/fmaf().
 #include "kernels.h"
 #include "meso_device.h"
+#include <type_traits>
 
 namespace meso {
 
@@ -755,7 +756,8 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
     const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
 
     if (FAST) {
-        float fx = 0.f, fy = 0.f, fz = 0.f;
+        float fx = 0.f, fy = 0.f, fz = 0.f, energy = 0.f;
+        float vr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float dtis = (float)a.dt_inv_sqrt;
         for (int p = 0; p < n; p++) {
             int j = col[(size_t)p * 64];
@@ -776,10 +778,23 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
                 float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis);
                 fpair *= rinv;
                 fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+                if (EV) {
+                    vr[0] += dx * dx * fpair; vr[1] += dy * dy * fpair; vr[2] += dz * dz * fpair;
+                    vr[3] += dx * dy * fpair; vr[4] += dx * dz * fpair; vr[5] += dy * dz * fpair;
+                    energy += 0.5f * cf[P_A0] * cf[P_CUT] * wc * wc;
+                }
             }
         }
         if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
+        if (EV) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (a.accumulate) a.virial[k][i] += vr[k] * 0.5f;
+                else a.virial[k][i] = vr[k] * 0.5f;
+            }
+            a.e_pair[i] = energy * 0.5f;
+        }
     } else {
         double fx = 0., fy = 0., fz = 0., energy = 0.;
         double vr[6] = {0., 0., 0., 0., 0., 0.};
@@ -827,13 +842,194 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
     }
 }
 
+
+// =========================================================================================
+// pair force, v2: wave-per-tile, ballot-compacted heavy phase
+// =========================================================================================
+// One wave owns a 64-atom tile.  Phase A walks the transposed rows exactly like v1 (coalesced 256-B row
+// reads, one candidate per lane) but only tests the cutoff; hits are compacted with ballot + popcount
+// into a 128-entry LDS ring.  Phase B drains the ring 64 pairs at a time, so the expensive part (TEA,
+// Gaussian, weights) runs with every lane busy instead of the ~45 % in-range fraction of the list.
+// Per-atom sums are kept in LDS and combined with wave-scope ds_add (one wave per tile -> fixed order
+// -> bit-reproducible run to run; no global atomics).
+template <typename T> struct PairAcc;
+template <> struct PairAcc<float> { typedef float type; };
+template <> struct PairAcc<double> { typedef double type; };
+
+#define PAIR2_WAVES 4
+#define PAIR2_RING 128
+
+template <bool FAST>
+__global__ void __launch_bounds__(64 * PAIR2_WAVES) k_pair_dpd_tile(PairArgs a, int ntiles, int tile0)
+{
+    typedef typename PairAcc<typename std::conditional<FAST, float, double>::type>::type acc_t;
+    extern __shared__ double smem[];
+    const int ncf = a.ntypes * a.ntypes * N_COEFF;
+    double *cf64 = smem;
+    float *cf32 = (float *)smem;
+    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
+        if (FAST) cf32[p] = a.coeff32[p];
+        else cf64[p] = a.coeff64[p];
+    }
+    // per-wave LDS carve (after the coefficient table, 16-B aligned)
+    size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
+    char *base = (char *)smem + off;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t per_wave = 64 * 16 * 2 + PAIR2_RING * 16 + PAIR2_RING * 4 + 64 * 3 * sizeof(acc_t);
+    char *wb = base + (size_t)w * per_wave;
+    float4 *own_c = (float4 *)wb;
+    float4 *own_v = own_c + 64;
+    float4 *ring = own_v + 64;
+    int *ring_a = (int *)(ring + PAIR2_RING);
+    acc_t *facc = (acc_t *)(ring_a + PAIR2_RING);
+    __syncthreads();
+
+    // XCD-aware tile order: blocks b and b+8 share an L2, so hand each XCD a contiguous run of tiles
+    int wid = blockIdx.x * PAIR2_WAVES + w;
+    int nw = gridDim.x * PAIR2_WAVES;
+    int per = nw / 8;
+    int tile = (nw % 8 == 0) ? ((blockIdx.x & 7) * per + (blockIdx.x >> 3) * PAIR2_WAVES + w) : wid;
+    if (tile >= ntiles) return;
+    tile += tile0;
+    const int i = tile * 64 + lane;
+    const bool mine = i >= a.beg && i < a.end;
+    const u64 lt = (1ULL << lane) - 1ULL;
+
+    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
+    int n = 0;
+    if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
+    own_c[lane] = c1;
+    own_v[lane] = v1;
+    facc[lane] = 0; facc[64 + lane] = 0; facc[128 + lane] = 0;
+    const u32 t1 = __float_as_uint(c1.w);
+    const int *col = a.table + ((size_t)tile * a.n_col) * 64 + lane;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    __builtin_amdgcn_wave_barrier();
+
+    int qhead = 0, qtail = 0;
+    const float dtis32 = (float)a.dt_inv_sqrt;
+
+    auto drain = [&](int nb) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nb) {
+            int slot = (qhead + lane) & (PAIR2_RING - 1);
+            float4 e = ring[slot];
+            int pk = ring_a[slot];
+            int ai = pk & 63, cidx = pk >> 6;
+            int j = __float_as_int(e.w);
+            float4 ci = own_c[ai], vi = own_v[ai];
+            float4 v2 = a.veloc4[j];
+            u32 si = __float_as_uint(vi.w), sj = __float_as_uint(v2.w);
+            if (FAST) {
+                const float *cf = cf32 + cidx * N_COEFF;
+                float dx = ci.x - e.x, dy = ci.y - e.y, dz = ci.z - e.z;
+                float rsq = dx * dx + dy * dy + dz * dz;
+                float rn = gaussian_tea_fast(si, sj);
+                float rinv = __builtin_amdgcn_rsqf(rsq);
+                float r = rsq * rinv;
+                float dvx = vi.x - v2.x, dvy = vi.y - v2.y, dvz = vi.z - v2.z;
+                float dot = dx * dvx + dy * dvy + dz * dvz;
+                float wc = 1.0f - r * cf[P_CUTINV];
+                float ew = cf[P_EXPW];
+                float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
+                float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
+                fpair *= rinv;
+                __hip_atomic_fetch_add((float *)&facc[ai], dx * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add((float *)&facc[64 + ai], dy * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add((float *)&facc[128 + ai], dz * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {
+                const double *cf = cf64 + cidx * N_COEFF;
+                double dx = (double)ci.x - (double)e.x, dy = (double)ci.y - (double)e.y, dz = (double)ci.z - (double)e.z;
+                double rsq = dx * dx + dy * dy + dz * dz;
+                double rn = gaussian_tea(si, sj);
+                double rinv = rsqrt(rsq);
+                double r = rsq * rinv;
+                double dvx = (double)vi.x - (double)v2.x, dvy = (double)vi.y - (double)v2.y, dvz = (double)vi.z - (double)v2.z;
+                double dot = dx * dvx + dy * dvy + dz * dvz;
+                double wc = 1.0 - r * cf[P_CUTINV];
+                double ew = cf[P_EXPW];
+                double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
+                double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
+                fpair *= rinv;
+                __hip_atomic_fetch_add((double *)&facc[ai], dx * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add((double *)&facc[64 + ai], dy * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add((double *)&facc[128 + ai], dz * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        qhead += nb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    for (int p = 0; p < nmax; p++) {
+        bool active = p < n;
+        int j = 0;
+        float4 c2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) { j = col[(size_t)p * 64]; c2 = a.coord4[j]; }
+        int cidx = t1 * a.ntypes + __float_as_uint(c2.w);
+        bool hit;
+        if (FAST) {
+            float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
+            float rsq = dx * dx + dy * dy + dz * dz;
+            hit = active && rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
+        } else {
+            double dx = (double)c1.x - (double)c2.x, dy = (double)c1.y - (double)c2.y, dz = (double)c1.z - (double)c2.z;
+            double rsq = dx * dx + dy * dy + dz * dz;
+            hit = active && rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
+        }
+        u64 m = __ballot(hit);
+        if (m) {
+            if (hit) {
+                int slot = (qtail + __popcll(m & lt)) & (PAIR2_RING - 1);
+                ring[slot] = make_float4(c2.x, c2.y, c2.z, __int_as_float(j));
+                ring_a[slot] = lane | (cidx << 6);
+            }
+            qtail += __popcll(m);
+            if (qtail - qhead >= 64) drain(64);
+        }
+    }
+    if (qtail > qhead) drain(qtail - qhead);
+
+    if (mine) {
+        double fx = (double)facc[lane], fy = (double)facc[64 + lane], fz = (double)facc[128 + lane];
+        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
+        else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
+    }
+}
+
+static size_t pair2_smem(int ntypes, int fast)
+{
+    size_t ncf = (size_t)ntypes * ntypes * N_COEFF * (fast ? 4 : 8);
+    size_t off = (ncf + 15) & ~(size_t)15;
+    size_t per_wave = 64 * 16 * 2 + PAIR2_RING * 16 + PAIR2_RING * 4 + 64 * 3 * (fast ? 4 : 8);
+    return off + per_wave * PAIR2_WAVES;
+}
+
+void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s)
+{
+    if (p.end <= p.beg) return;
+    int tile0 = p.beg >> 6, tile1 = (p.end + 63) >> 6;
+    int ntiles = tile1 - tile0;
+    int nb = (ntiles + PAIR2_WAVES - 1) / PAIR2_WAVES;
+    nb = (nb + 7) / 8 * 8;   // multiple of 8 so the XCD remap is a bijection onto [0, 8*per)
+    size_t sm = pair2_smem(p.ntypes, fast);
+    if (fast) hipLaunchKernelGGL((k_pair_dpd_tile<true>), dim3(nb), dim3(64 * PAIR2_WAVES), sm, s, p, ntiles, tile0);
+    else hipLaunchKernelGGL((k_pair_dpd_tile<false>), dim3(nb), dim3(64 * PAIR2_WAVES), sm, s, p, ntiles, tile0);
+}
+
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s)
 {
     int n = p.end - p.beg;
     if (n <= 0) return;
     size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? sizeof(float) : sizeof(double));
     dim3 grid(nblk(n, 256)), block(256);
-    if (fast) hipLaunchKernelGGL((k_pair_dpd<true, false>), grid, block, sm, s, p);
+    if (fast && evflag) hipLaunchKernelGGL((k_pair_dpd<true, true>), grid, block, sm, s, p);
+    else if (fast) hipLaunchKernelGGL((k_pair_dpd<true, false>), grid, block, sm, s, p);
     else if (evflag) hipLaunchKernelGGL((k_pair_dpd<false, true>), grid, block, sm, s, p);
     else hipLaunchKernelGGL((k_pair_dpd<false, false>), grid, block, sm, s, p);
 }
