@@ -148,6 +148,16 @@ private:
     int64_t nbuild = 0;
     int ago = 0;
 
+    // brick layout
+    int layout = 1;                 // 0: global-index rows + L2 gathers, 1: bricks with LDS-staged halos
+    int *estart = nullptr, *gstart = nullptr, *gslot = nullptr;
+    size_t estart_cap = 0;
+    unsigned short *table16 = nullptr;
+    bool table32_valid = false;
+    BrickArgs bargs{};
+    int l1bits = 0;
+    int ensure_table32();
+
     // reorder
     uint64_t *rkey = nullptr, *rkey_alt = nullptr;
     int *rval = nullptr, *rval_alt = nullptr;

@@ -76,6 +76,7 @@ void Engine::free_all()
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
+    dfree(estart); dfree(gstart); dfree(gslot); dfree(table16);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
     dfree(d_partial); dfree(d_scalar); dfree(d_flags);
     if (h_flags) (void)hipHostFree(h_flags);
@@ -224,6 +225,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
     if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
     if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
+    if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
     return fail(1, "Unknown option '" + key + "'");
 }
@@ -298,6 +300,7 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(rkey, 0, c, stream)); HIPCHK(regrow(rkey_alt, 0, c, stream));
     HIPCHK(regrow(rval, 0, c, stream)); HIPCHK(regrow(rval_alt, 0, c, stream));
     HIPCHK(regrow(sendlist, 0, c, stream));
+    HIPCHK(regrow(gslot, 0, c, stream));
     send_cap = cap;
     chunk_cap = (cap + 255) / 256 + 1;
     HIPCHK(regrow(chunk_count, 0, (size_t)27 * chunk_cap + 1, stream));
@@ -314,6 +317,8 @@ int Engine::alloc_atoms(int cap)
         table_tiles = ((size_t)cap + 63) / 64;
         dfree(pair_table);
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
+        dfree(table16);
+        HIPCHK(dalloc(table16, table_tiles * 64 * (size_t)n_col));
     }
     nmax = cap;
     return 0;
@@ -452,6 +457,22 @@ int Engine::init_params()
         table_tiles = ((size_t)nmax + 63) / 64;
         dfree(pair_table);
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
+        dfree(table16);
+        HIPCHK(dalloc(table16, table_tiles * 64 * (size_t)n_col));
+    }
+    {
+        int max_bin = std::max(geom.mbin[0], std::max(geom.mbin[1], geom.mbin[2]));
+        l1bits = 0;
+        while ((1 << (l1bits + 1)) <= max_bin * 2) l1bits++;
+        size_t M = (size_t)1 << (3 * l1bits);
+        if (2 * M + 1 > estart_cap) {
+            dfree(estart); dfree(gstart);
+            estart_cap = 2 * M + 1;
+            HIPCHK(dalloc(estart, estart_cap));
+            HIPCHK(dalloc(gstart, M + 1));
+        }
+        bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / 32);
+        for (int d = 0; d < 3; d++) bargs.mbin[d] = geom.mbin[d];
     }
     if (geom.nbin + 1 > bin_cap) {
         dfree(bin_start);
@@ -504,7 +525,7 @@ int Engine::reorder_locals()
     HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
     HIPCHK(hipStreamSynchronize(stream));
-    if (h_flags[0]) return fail(4, "Pair table overflow: local density too high");
+    if (h_flags[0]) return check_overflow();
     n_bulk = h_flags[1];
     return 0;
 }
@@ -556,7 +577,7 @@ int Engine::halo_forward_seed(uint32_t sd)
     if (nsend <= 0) return 0;
     tbegin("halo");
     launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,
-                        stream);
+                        layout == 1 ? gslot : nullptr, stream);
     tend("halo");
     return 0;
 }
@@ -574,6 +595,28 @@ int Engine::merge_locals(uint32_t sd)
 int Engine::build_cells_and_table()
 {
     int nall = nlocal + nghost;
+    float rc2 = (float)((cutmax + skin) * (cutmax + skin));
+    if (layout == 1) {
+        // locals are already cell-ordered by the reorder sort; only the ghosts need binning
+        tbegin("bin");
+        launch_estart(rkey, nlocal, 2 * bargs.M, estart, stream);
+        launch_ghost_morton(cur, geom, nlocal, nghost, bin_key, bin_val, stream);
+        if (nghost > 0)
+            HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nghost,
+                                  std::max(1, 3 * l1bits), stream));
+        launch_bin_bounds(bin_key, nghost, bargs.M, gstart, stream);
+        launch_invert_perm(bin_val, gslot, nghost, stream);
+        bargs.ghost_base = nlocal;
+        tend("bin");
+        TRY(merge_locals(0));
+        TRY(halo_forward_seed(0));
+        tbegin("neigh");
+        launch_brick_build(bargs, coord4, rc2, n_col, pair_count, table16, d_flags, stream);
+        tend("neigh");
+        table32_valid = false;
+        nbuild++;
+        return 0;
+    }
     tbegin("bin");
     launch_assign_bin(cur, geom, nlocal, nall, bin_id, bin_val, stream);
     HIPCHK(hipMemcpyAsync(bin_key, bin_id, (size_t)nall * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
@@ -585,7 +628,6 @@ int Engine::build_cells_and_table()
     TRY(merge_locals(0));
     TRY(halo_forward_seed(0));
     tbegin("neigh");
-    float rc2 = (float)((cutmax + skin) * (cutmax + skin));
     if (neigh_kernel == 0)
         launch_neigh_build_simple(coord4, bin_id, bin_start, bin_val, geom, rc2, nlocal, n_col, pair_count, pair_table,
                                   d_flags, stream);
@@ -593,7 +635,18 @@ int Engine::build_cells_and_table()
         launch_neigh_build_wave(coord4, bin_id, bin_start, bin_val, geom, rc2, nlocal, n_col, pair_count, pair_table,
                                 d_flags, stream);
     tend("neigh");
+    table32_valid = true;
     nbuild++;
+    return 0;
+}
+
+// brick rows hold halo-local 16-bit indices; the lane-per-atom kernels (energy/virial steps) and the
+// introspection calls want global indices
+int Engine::ensure_table32()
+{
+    if (layout != 1 || table32_valid) return 0;
+    launch_brick_convert(bargs, n_col, pair_count, table16, pair_table, d_flags, stream);
+    table32_valid = true;
     return 0;
 }
 
@@ -602,8 +655,12 @@ int Engine::check_overflow()
     HIPCHK(hipMemcpyAsync(h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     if (h_flags[0]) {
-        char buf[160];
-        snprintf(buf, sizeof buf, "Pair table overflow: %d > %d; local density too high", h_flags[0], n_col);
+        char buf[200];
+        if (h_flags[0] >= 100000)
+            snprintf(buf, sizeof buf, "Brick halo overflow: %d atoms in one brick neighbourhood; local density too high",
+                     h_flags[0] - 100000);
+        else
+            snprintf(buf, sizeof buf, "Pair table overflow: %d > %d; local density too high", h_flags[0], n_col);
         return fail(4, buf);
     }
     return 0;
@@ -688,6 +745,13 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
     p.beg = beg; p.end = end;
     p.accumulate = 1;
+    if (layout == 1 && !ev && pair_kernel != 0) {
+        tbegin("pair");
+        launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
+        tend("pair");
+        return 0;
+    }
+    TRY(ensure_table32());
     tbegin("pair");
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
     else launch_pair_dpd_tile(p, pair_style, stream);
@@ -733,10 +797,17 @@ int Engine::run(int nsteps)
         p.beg = 0; p.end = nlocal;
         p.accumulate = fuse_clear ? 0 : 1;
         if (!fuse_clear) TRY(force_clear(0));
-        tbegin("pair");
-        if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
-        else launch_pair_dpd_tile(p, pair_style, stream);
-        tend("pair");
+        if (layout == 1 && pair_kernel != 0) {
+            tbegin("pair");
+            launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
+            tend("pair");
+        } else {
+            TRY(ensure_table32());
+            tbegin("pair");
+            if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
+            else launch_pair_dpd_tile(p, pair_style, stream);
+            tend("pair");
+        }
         TRY(nve_final());
         ev_valid = false;
     }
@@ -828,6 +899,7 @@ int Engine::neigh_info(int *ncol, int *max_count, double *avg, int64_t *nb)
 
 int Engine::neigh_download(int *count, int *table, int stride)
 {
+    TRY(ensure_table32());
     HIPCHK(hipStreamSynchronize(stream));
     if (!nlocal) return 0;
     HIPCHK(hipMemcpy(count, pair_count, nlocal * sizeof(int), hipMemcpyDeviceToHost));

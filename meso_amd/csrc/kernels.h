@@ -63,7 +63,8 @@ void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const 
 // per-step payload: merged float4 pair in the receiver's frame (centre c_recv), signature included
 void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start /*dev [28]*/,
                          const double *shift27 /*host [27][3]*/, const double *center27 /*host [27][3]*/,
-                         uint32_t seed, float4 *dcoord, float4 *dveloc, hipStream_t s);
+                         uint32_t seed, float4 *dcoord, float4 *dveloc, const int *dest_slot /*nullable*/,
+                         hipStream_t s);
 
 // ---- cell binning (neighbor_meso.cu:386-475) ----------------------------------------------------------
 void launch_assign_bin(const AtomSoA &a, const BinGeom &g, int nlocal, int nall, uint32_t *bin_id, int *atom_id,
@@ -98,6 +99,25 @@ struct PairArgs {
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // wave-per-tile, ballot-compacted variant (forces only)
 void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s);
+
+// ---- brick layout (brick.hip): Morton-aligned 4x4x2-bin bricks, halo staged in LDS, 16-bit rows ---------
+struct BrickArgs {
+    const int *estart;   // [2M+1] first local index per extended code (border*M + Morton(bin))
+    const int *gstart;   // [M+1]  first sorted-ghost slot per Morton(bin)
+    int ghost_base;      // == nlocal: ghosts live behind the locals in the merged arrays
+    int M;               // Morton codes per section (power of 8)
+    int mbin[3];
+    int nbricks;         // M / 32
+};
+void launch_estart(const uint64_t *sorted_key, int n, int ncodes, int *estart, hipStream_t s);
+void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *key, int *val,
+                         hipStream_t s);
+void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,
+                        unsigned short *table16, int *overflow, hipStream_t s);
+void launch_brick_convert(const BrickArgs &g, int n_col, const int *count, const unsigned short *table16,
+                          int *table32, int *overflow, hipStream_t s);
+void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, int fast,
+                       int *overflow, hipStream_t s);
 
 // ---- unit kernels for known-answer tests --------------------------------------------------------------
 void launch_test_tea(const uint32_t *u, const uint32_t *v, int n, int rounds, uint32_t *out0, uint32_t *out1,

@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256) k_pack_border(AtomSoA a, const int *__res
 __global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__restrict__ sendlist, int nsend,
                                                       const int *__restrict__ dir_start, Shift27 sh, Center27 ce,
                                                       u32 seed, float4 *__restrict__ dcoord,
-                                                      float4 *__restrict__ dveloc)
+                                                      float4 *__restrict__ dveloc, const int *__restrict__ dest_slot)
 {
     __shared__ int ds[28];
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
@@ -494,13 +494,14 @@ __global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__re
     c.y = (float)((a.x[1][j] + sh.s[d][1]) - ce.c[d][1]);
     c.z = (float)((a.x[2][j] + sh.s[d][2]) - ce.c[d][2]);
     c.w = __uint_as_float((u32)(a.type[j] - 1));
-    dcoord[k] = c;
+    const int out = dest_slot ? dest_slot[k] : k;
+    dcoord[out] = c;
     float4 v;
     v.x = (float)a.v[0][j];
     v.y = (float)a.v[1][j];
     v.z = (float)a.v[2][j];
     v.w = __uint_as_float(signature(seed, a.tag[j], v.x, v.y, v.z));
-    dveloc[k] = v;
+    dveloc[out] = v;
 }
 
 void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start, const double *shift27,
@@ -515,7 +516,8 @@ void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const 
 }
 
 void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start, const double *shift27,
-                         const double *center27, uint32_t seed, float4 *dcoord, float4 *dveloc, hipStream_t s)
+                         const double *center27, uint32_t seed, float4 *dcoord, float4 *dveloc, const int *dest_slot,
+                         hipStream_t s)
 {
     if (nsend <= 0) return;
     Shift27 sh;
@@ -523,7 +525,7 @@ void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const
     for (int d = 0; d < 27; d++)
         for (int k = 0; k < 3; k++) { sh.s[d][k] = shift27[3 * d + k]; ce.c[d][k] = center27[3 * d + k]; }
     hipLaunchKernelGGL(k_pack_forward, dim3(nblk(nsend, 256)), dim3(256), 0, s, a, sendlist, nsend, dir_start, sh, ce,
-                       seed, dcoord, dveloc);
+                       seed, dcoord, dveloc, dest_slot);
 }
 
 // =========================================================================================

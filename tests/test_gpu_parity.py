@@ -16,6 +16,11 @@ from meso_amd.datagen import make_box
 
 pytestmark = pytest.mark.gpu
 
+# engine code paths: (layout, pair_kernel).  layout 0 = global-index rows gathered through L2, layout 1 = bricks
+# with LDS-staged halos and 16-bit rows; pair_kernel 0 = lane per atom, 1 = ballot-compacted (tile / brick).
+PATHS = {"lane": (("layout", 0), ("pair_kernel", 0)), "tile": (("layout", 0), ("pair_kernel", 1)),
+         "brick": (("layout", 1), ("pair_kernel", 1)), "brick-rows+lane": (("layout", 1), ("pair_kernel", 0))}
+
 
 @pytest.fixture(scope="module")
 def Meso():
@@ -78,10 +83,10 @@ def test_gaussian_tea(Meso, oracle):
     assert np.abs(dp).max() <= 4.0 and abs(dp.mean()) < 0.03 and abs(dp.var() - 1) < 0.03
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
-def test_merged_arrays_and_neighbor_sets(Meso, oracle, kernel):
+@pytest.mark.parametrize("kernel,layout", [(0, 0), (1, 0), (1, 1)])
+def test_merged_arrays_and_neighbor_sets(Meso, oracle, kernel, layout):
     L = 7
-    m, _ = _engine(Meso, L, kernel=kernel)
+    m, _ = _engine(Meso, L, kernel=kernel, opts=(("layout", layout),))
     s = _oracle_sim(L)
     nl, ng, nb = m.counts()
     assert nl == s.n and ng == len(s.gsrc)
@@ -111,12 +116,12 @@ def test_merged_arrays_and_neighbor_sets(Meso, oracle, kernel):
     m.close()
 
 
-@pytest.mark.parametrize("pair_kernel", [0, 1])
+@pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-9), ("dpd/fast/meso", 2e-3)])
-def test_forces_vs_meso_oracle(Meso, oracle, style, tol, pair_kernel):
-    """Both force kernels (lane-per-atom, wave-per-tile with ballot compaction) against the oracle."""
+def test_forces_vs_meso_oracle(Meso, oracle, style, tol, path):
+    """Every force kernel (lane-per-atom, wave-per-tile, brick) against the oracle."""
     L = 8
-    m, _ = _engine(Meso, L, style=style, opts=(("pair_kernel", pair_kernel),))
+    m, _ = _engine(Meso, L, style=style, opts=PATHS[path])
     s = _oracle_sim(L, fast=(style != "dpd/meso"))
     scale = np.abs(s.f).max()
     assert scale > 50
@@ -153,17 +158,17 @@ def test_sigma0_vs_stock_lammps_cpu(Meso, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("pair_kernel", [0, 1])
+@pytest.mark.parametrize("path", ["lane", "tile", "brick"])
 @pytest.mark.parametrize("style,every,sigma,steps", [("dpd/meso", 5, 3.0, 12), ("dpd/meso", 1, 3.0, 12),
                                                      ("dpd/fast/meso", 5, 0.0, 12), ("dpd/fast/meso", 5, 3.0, 1)])
-def test_trajectory_vs_meso_oracle(Meso, oracle, style, every, sigma, steps, pair_kernel):
+def test_trajectory_vs_meso_oracle(Meso, oracle, style, every, sigma, steps, path):
     """NVE trajectory against the CPU mirror of mvv/meso.  The per-particle TEA signature hashes the top 11
     mantissa bits of the fp32 velocity (math_meso.h:436-442), so in the fp32 style a 1-ulp velocity difference
     re-keys a particle's random numbers: with the thermostat on, dpd/fast/meso is compared over one step only
     and over 12 steps with sigma = 0; the fp64 style stays bit-close over the whole run."""
     L = 7
     fast = style != "dpd/meso"
-    m, _ = _engine(Meso, L, style=style, every=every, sigma=sigma, opts=(("pair_kernel", pair_kernel),))
+    m, _ = _engine(Meso, L, style=style, every=every, sigma=sigma, opts=PATHS[path])
     s = _oracle_sim(L, sigma=sigma, fast=fast, every=every)
     m.run(steps)
     s.run(steps)
@@ -194,9 +199,13 @@ def test_momentum_and_thermostat(Meso):
     m.close()
 
 
-def test_split_ranges_equal_full_compute(Meso):
-    """compute_bulk + compute_border == compute (pair_dpd_meso.cu:241-266)."""
-    m, _ = _engine(Meso, 8)
+@pytest.mark.parametrize("path", list(PATHS))
+def test_split_ranges_equal_full_compute(Meso, path):
+    """compute_bulk + compute_border == compute (pair_dpd_meso.cu:241-266), bit for bit per kernel."""
+    m, _ = _engine(Meso, 8, opts=PATHS[path])
+    f_setup = m.gather(by_tag=False)[2]
+    m.force_clear("local")
+    m.compute()
     f_full = m.gather(by_tag=False)[2]
     nl, ng, nb = m.counts()
     assert 0 < nb < nl
@@ -204,6 +213,7 @@ def test_split_ranges_equal_full_compute(Meso):
     m.compute(which="bulk")
     m.compute(which="border")
     assert np.array_equal(m.gather(by_tag=False)[2], f_full)
+    assert np.abs(f_full - f_setup).max() < 1e-9 * np.abs(f_setup).max()
     m.close()
 
 
