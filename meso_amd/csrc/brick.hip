@@ -36,6 +36,16 @@ struct BrickHdr {
     int nh, n_own, o0, sec;
 };
 
+// Row layout: 8 consecutive 16-bit entries of one atom are one 16-byte word; a wave reads 64 such words
+// (1 KiB, fully coalesced) per 8 candidates:  word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63),  c = p>>3.
+__device__ inline size_t row_word(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
+
+__device__ inline float dist2(float4 a, float4 b)
+{
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
 __device__ inline u32 compact3(u32 x)
 {
     x &= 0x09249249;
@@ -50,9 +60,11 @@ __device__ inline u32 compact3(u32 x)
 __device__ inline bool brick_setup(const BrickArgs &g, BrickHdr &H, int *overflow)
 {
     const int tid = threadIdx.x;
-    // XCD-aware order: blocks b and b+8 share an L2, so each XCD walks a contiguous run of bricks
-    const int nb2 = 2 * g.nbricks;
-    const int blk = (nb2 & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nb2 >> 3) + (blockIdx.x >> 3));
+    // XCD-aware order: blocks b and b+8 share an L2, so each XCD walks a contiguous run of the active list
+    const int nb2 = gridDim.x;
+    int slot = (nb2 & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nb2 >> 3) + (blockIdx.x >> 3));
+    if (slot >= g.nactive) return false;
+    const int blk = g.active[slot];
     const int sec = blk / g.nbricks, B = blk % g.nbricks;
     if (tid <= 32) H.ostart[tid] = g.estart[(size_t)sec * g.M + 32 * B + tid];
     __syncthreads();
@@ -150,23 +162,39 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const 
         const int loc = own_loc(H, o, hb);
         const int i = H.o0 + o;
         const float4 ci = hc[loc];
-        unsigned short *col = table16 + ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
+        uint4 *rows = (uint4 *)table16;
         int n = 0;
+        u64 lo = 0, hi = 0;
+        auto push = [&](int k) {
+            int q = n & 7;
+            if (q < 4) lo |= (u64)(u32)k << (16 * q);
+            else hi |= (u64)(u32)k << (16 * (q - 4));
+            if (q == 7) {
+                if (n < n_col) rows[row_word(i, n >> 3, n_col)] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+                lo = 0; hi = 0;
+            }
+            n++;
+        };
 #pragma unroll 1
         for (int r = 0; r < 9; r++) {
             // x-adjacent halo bins are consecutive halo-bin indices: one contiguous run of halo-local slots
             const int hrow = hb + (r % 3 - 1) * BRK_HX + (r / 3 - 1) * BRK_HX * BRK_HY;
             const int kb = H.hoff[hrow - 1], ke = H.hoff[hrow + 2];
-            for (int k = kb; k < ke; k++) {
-                float4 cj = hc[k];
-                float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
-                float d2 = dx * dx + dy * dy + dz * dz;
-                if (k != loc && d2 <= rc2) {
-                    if (n < n_col) col[(size_t)n * 64] = (unsigned short)k;
-                    n++;
-                }
+            int k = kb;
+            for (; k + 4 <= ke; k += 4) {       // 4 LDS gathers in flight per lane
+                float4 c0 = hc[k], c1 = hc[k + 1], c2 = hc[k + 2], c3 = hc[k + 3];
+                float d0 = dist2(ci, c0), d1 = dist2(ci, c1), d2 = dist2(ci, c2), d3 = dist2(ci, c3);
+                if (k != loc && d0 <= rc2) push(k);
+                if (k + 1 != loc && d1 <= rc2) push(k + 1);
+                if (k + 2 != loc && d2 <= rc2) push(k + 2);
+                if (k + 3 != loc && d3 <= rc2) push(k + 3);
+            }
+            for (; k < ke; k++) {
+                float d0 = dist2(ci, hc[k]);
+                if (k != loc && d0 <= rc2) push(k);
             }
         }
+        if ((n & 7) && n < n_col) rows[row_word(i, n >> 3, n_col)] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
         if (n > n_col) { atomicMax(overflow, n); n = n_col; }
         count[i] = n;
     }
@@ -183,7 +211,8 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_convert(BrickArgs g, int 
         const int i = H.o0 + o;
         const size_t base = ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
         const int n = count[i];
-        for (int p = 0; p < n; p++) table32[base + (size_t)p * 64] = halo_src(H, (int)table16[base + (size_t)p * 64]);
+        for (int p = 0; p < n; p++)
+            table32[base + (size_t)p * 64] = halo_src(H, (int)table16[row_word(i, p >> 3, n_col) * 8 + (p & 7)]);
     }
 }
 
@@ -225,6 +254,7 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
         facc[0][o] = 0; facc[1][o] = 0; facc[2][o] = 0;
     }
     __syncthreads();
+    if (a.debug == 1) return;
 
     const u64 lt = (1ULL << lane) - 1ULL;
     const float dtis32 = (float)a.dt_inv_sqrt;
@@ -238,7 +268,7 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
         float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mine) { loc = oloc[o]; c1 = hc[loc]; n = a.count[i]; }
         const u32 t1 = __float_as_uint(c1.w);
-        const unsigned short *col = table16 + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
+        const uint4 *rows = (const uint4 *)table16;
         int nmax = n;
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) nmax = max(nmax, __shfl_xor(nmax, s, 64));
@@ -248,7 +278,7 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < nb) {
+            if (lane < nb && a.debug != 2) {
                 int pk = myring[(qhead + lane) & (BRK_RING - 1)];
                 int j = pk & 0xFFFF, oo = pk >> 16;
                 int li = oloc[oo];
@@ -297,28 +327,44 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
 
-        for (int p = 0; p < nmax; p++) {
-            const bool active = p < n;
-            int j = 0;
-            float4 c2 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active) { j = (int)col[(size_t)p * 64]; c2 = hc[j]; }
-            const int cidx = t1 * a.ntypes + __float_as_uint(c2.w);
-            bool hit;
-            if (FAST) {
-                float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
-                float rsq = dx * dx + dy * dy + dz * dz;
-                hit = active && rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
-            } else {
-                double dx = (double)c1.x - (double)c2.x, dy = (double)c1.y - (double)c2.y, dz = (double)c1.z - (double)c2.z;
-                double rsq = dx * dx + dy * dy + dz * dz;
-                hit = active && rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
+        const int nchunk = (nmax + 7) >> 3;
+        uint4 wcur = make_uint4(0, 0, 0, 0);
+        if (mine && n > 0) wcur = rows[row_word(i, 0, a.n_col)];
+        for (int c = 0; c < nchunk; c++) {
+            // prefetch the next 8 entries of my row while this chunk is tested
+            uint4 wnext = make_uint4(0, 0, 0, 0);
+            if (mine && (c + 1) * 8 < n) wnext = rows[row_word(i, c + 1, a.n_col)];
+            const u32 ww[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
+            int jj[8];
+            float4 cc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                jj[q] = (int)((ww[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
+                cc[q] = hc[jj[q]];            // entries past my count are 0: a valid slot, masked below
             }
-            const u64 m = __ballot(hit);
-            if (m) {
-                if (hit) myring[(qtail + __popcll(m & lt)) & (BRK_RING - 1)] = j | (o << 16);
-                qtail += __popcll(m);
-                if (qtail - qhead >= 64) drain(64);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const bool active = c * 8 + q < n;
+                const float4 c2 = cc[q];
+                const int cidx = t1 * a.ntypes + __float_as_uint(c2.w);
+                bool hit;
+                if (FAST) {
+                    float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
+                    float rsq = dx * dx + dy * dy + dz * dz;
+                    hit = active && rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
+                } else {
+                    double dx = (double)c1.x - (double)c2.x, dy = (double)c1.y - (double)c2.y, dz = (double)c1.z - (double)c2.z;
+                    double rsq = dx * dx + dy * dy + dz * dz;
+                    hit = active && rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
+                }
+                const u64 m = __ballot(hit);
+                if (m) {
+                    if (hit) myring[(qtail + __popcll(m & lt)) & (BRK_RING - 1)] = jj[q] | (o << 16);
+                    qtail += __popcll(m);
+                    if (qtail - qhead >= 64) drain(64);
+                }
             }
+            wcur = wnext;
         }
         if (qtail > qhead) drain(qtail - qhead);
 
@@ -334,14 +380,20 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
 // cell structure kernels
 // =========================================================================================
 // estart[e] = first local index whose extended code (sorted reorder key >> 12) is >= e, e in [0, ncodes]
-__global__ void __launch_bounds__(256) k_estart(const u64 *__restrict__ key, int n, int ncodes, int *__restrict__ estart)
+// (one thread per code, binary search: codes of the border section and of the ghosts are sparse, so the
+// "fill the gap" formulation of gpu_find_bin_boundary would serialise on single threads)
+template <typename K>
+__global__ void __launch_bounds__(256) k_code_starts(const K *__restrict__ key, int n, int shift, int ncodes,
+                                                     int *__restrict__ start)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    long prev = (i == 0) ? -1 : (long)(key[i - 1] >> 12);
-    long cur = (i == n) ? (long)ncodes : (long)(key[i] >> 12);
-    if (cur > ncodes) cur = ncodes;
-    for (long e = prev + 1; e <= cur; e++) estart[e] = i;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > ncodes) return;
+    int lo = 0, hi = n;                       // first index with (key >> shift) >= e
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((long)(key[mid] >> shift) < (long)e) lo = mid + 1; else hi = mid;
+    }
+    start[e] = lo;
 }
 
 // Morton code of each ghost's bin (ghost rule of gpu_assign_bin_id, neighbor_meso.cu:413-417)
@@ -362,9 +414,45 @@ __global__ void __launch_bounds__(256) k_ghost_morton(const double *__restrict__
     val[k] = k;
 }
 
+static inline int brick_grid(const BrickArgs &g) { return (g.nactive + 7) / 8 * 8; }
+
+// flag[b] = 1 if (section, brick) b owns atoms; the engine scans the flags and compacts the ids
+__global__ void __launch_bounds__(256) k_brick_flags(const int *__restrict__ estart, int M, int nb2, int *__restrict__ flag)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb2) return;
+    int nbricks = M / 32, sec = b / nbricks, B = b % nbricks;
+    size_t e0 = (size_t)sec * M + 32 * (size_t)B;
+    flag[b] = estart[e0 + 32] > estart[e0] ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_brick_compact(const int *__restrict__ flag, const int *__restrict__ pos, int nb2,
+                                                       int *__restrict__ active, int *__restrict__ nactive)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb2) return;
+    if (flag[b]) active[pos[b]] = b;
+    if (b == nb2 - 1) *nactive = pos[b] + flag[b];
+}
+void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s)
+{
+    int nb2 = 2 * (M / 32);
+    hipLaunchKernelGGL(k_brick_flags, dim3((nb2 + 255) / 256), dim3(256), 0, s, estart, M, nb2, flag);
+}
+void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s)
+{
+    int nb2 = 2 * (M / 32);
+    hipLaunchKernelGGL(k_brick_compact, dim3((nb2 + 255) / 256), dim3(256), 0, s, flag, pos, nb2, active, nactive);
+}
+
 void launch_estart(const uint64_t *sorted_key, int n, int ncodes, int *estart, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_estart, dim3((n + 1 + 255) / 256), dim3(256), 0, s, (const u64 *)sorted_key, n, ncodes, estart);
+    hipLaunchKernelGGL(k_code_starts<u64>, dim3((ncodes + 1 + 255) / 256), dim3(256), 0, s, (const u64 *)sorted_key, n, 12,
+                       ncodes, estart);
+}
+
+void launch_code_starts_u32(const uint32_t *sorted_key, int n, int ncodes, int *start, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_code_starts<u32>, dim3((ncodes + 1 + 255) / 256), dim3(256), 0, s, sorted_key, n, 0, ncodes, start);
 }
 
 void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *key, int *val,
@@ -378,24 +466,26 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
 void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,
                         unsigned short *table16, int *overflow, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_brick_build, dim3(2 * g.nbricks), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table16,
+    if (g.nactive <= 0) return;
+    hipLaunchKernelGGL(k_brick_build, dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table16,
                        overflow);
 }
 
 void launch_brick_convert(const BrickArgs &g, int n_col, const int *count, const unsigned short *table16, int *table32,
                           int *overflow, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_brick_convert, dim3(2 * g.nbricks), dim3(BRK_THREADS), 0, s, g, n_col, count, table16, table32,
+    if (g.nactive <= 0) return;
+    hipLaunchKernelGGL(k_brick_convert, dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, n_col, count, table16, table32,
                        overflow);
 }
 
 void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, int fast, int *overflow,
                        hipStream_t s)
 {
-    if (p.end <= p.beg) return;
+    if (p.end <= p.beg || g.nactive <= 0) return;
     size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? 4 : 8);
-    if (fast) hipLaunchKernelGGL((k_brick_pair<true>), dim3(2 * g.nbricks), dim3(BRK_THREADS), sm, s, g, p, table16, overflow);
-    else hipLaunchKernelGGL((k_brick_pair<false>), dim3(2 * g.nbricks), dim3(BRK_THREADS), sm, s, g, p, table16, overflow);
+    if (fast) hipLaunchKernelGGL((k_brick_pair<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16, overflow);
+    else hipLaunchKernelGGL((k_brick_pair<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16, overflow);
 }
 
 } // namespace meso

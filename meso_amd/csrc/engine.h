@@ -123,7 +123,8 @@ private:
     std::vector<int> coeff_set;
     std::vector<double> mass_type;  // ntypes+1
     int neigh_kernel = 1;           // 0 simple, 1 wave/LDS
-    int pair_kernel = 1;            // 0 lane-per-atom, 1 wave-per-tile with ballot compaction
+    int pair_kernel = 2;            // 0 lane-per-atom, 1 ballot-compacted (tile / brick), 2 lane-per-atom, 8-deep MLP
+    int pair_debug = 0;             // timing ablations (bench only)
     int fuse_clear = 1;             // pair kernel writes f instead of clear + accumulate
     long natoms_total = 0;
 
@@ -149,8 +150,9 @@ private:
     int ago = 0;
 
     // brick layout
-    int layout = 1;                 // 0: global-index rows + L2 gathers, 1: bricks with LDS-staged halos
+    int layout = 2;                 // 0: bin-sorted cell list, 1: bricks with LDS-staged halos, 2: cell-ordered atoms
     int *estart = nullptr, *gstart = nullptr, *gslot = nullptr;
+    int *brick_flag = nullptr, *brick_pos = nullptr, *brick_active = nullptr;
     size_t estart_cap = 0;
     unsigned short *table16 = nullptr;
     bool table32_valid = false;

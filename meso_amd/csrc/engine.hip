@@ -77,6 +77,7 @@ void Engine::free_all()
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
     dfree(estart); dfree(gstart); dfree(gslot); dfree(table16);
+    dfree(brick_flag); dfree(brick_pos); dfree(brick_active);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
     dfree(d_partial); dfree(d_scalar); dfree(d_flags);
     if (h_flags) (void)hipHostFree(h_flags);
@@ -225,6 +226,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
     if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
     if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
+    if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
     return fail(1, "Unknown option '" + key + "'");
@@ -466,10 +468,20 @@ int Engine::init_params()
         while ((1 << (l1bits + 1)) <= max_bin * 2) l1bits++;
         size_t M = (size_t)1 << (3 * l1bits);
         if (2 * M + 1 > estart_cap) {
-            dfree(estart); dfree(gstart);
+            dfree(estart); dfree(gstart); dfree(brick_flag); dfree(brick_pos); dfree(brick_active);
             estart_cap = 2 * M + 1;
             HIPCHK(dalloc(estart, estart_cap));
             HIPCHK(dalloc(gstart, M + 1));
+            HIPCHK(dalloc(brick_flag, M / 16 + 1));
+            HIPCHK(dalloc(brick_pos, M / 16 + 1));
+            HIPCHK(dalloc(brick_active, M / 16 + 1));
+            size_t tb = scan_temp_bytes((int)(M / 16 + 1));
+            if (tb > sort_temp_bytes) {
+                if (sort_temp) (void)hipFree(sort_temp);
+                sort_temp = nullptr;
+                HIPCHK(hipMalloc(&sort_temp, tb));
+                sort_temp_bytes = tb;
+            }
         }
         bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / 32);
         for (int d = 0; d < 3; d++) bargs.mbin[d] = geom.mbin[d];
@@ -577,7 +589,7 @@ int Engine::halo_forward_seed(uint32_t sd)
     if (nsend <= 0) return 0;
     tbegin("halo");
     launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,
-                        layout == 1 ? gslot : nullptr, stream);
+                        layout >= 1 ? gslot : nullptr, stream);
     tend("halo");
     return 0;
 }
@@ -596,24 +608,41 @@ int Engine::build_cells_and_table()
 {
     int nall = nlocal + nghost;
     float rc2 = (float)((cutmax + skin) * (cutmax + skin));
-    if (layout == 1) {
+    if (layout >= 1) {
         // locals are already cell-ordered by the reorder sort; only the ghosts need binning
         tbegin("bin");
         launch_estart(rkey, nlocal, 2 * bargs.M, estart, stream);
+        if (layout == 1) {
+            launch_brick_flags(estart, bargs.M, brick_flag, stream);
+            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, brick_flag, brick_pos, 2 * bargs.nbricks, stream));
+            launch_brick_compact(brick_flag, brick_pos, bargs.M, brick_active, d_flags + 2, stream);
+            HIPCHK(hipMemcpyAsync(h_flags + 2, d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
+        }
         launch_ghost_morton(cur, geom, nlocal, nghost, bin_key, bin_val, stream);
         if (nghost > 0)
             HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nghost,
                                   std::max(1, 3 * l1bits), stream));
-        launch_bin_bounds(bin_key, nghost, bargs.M, gstart, stream);
+        launch_code_starts_u32(bin_key, nghost, bargs.M, gstart, stream);
         launch_invert_perm(bin_val, gslot, nghost, stream);
         bargs.ghost_base = nlocal;
         tend("bin");
         TRY(merge_locals(0));
         TRY(halo_forward_seed(0));
-        tbegin("neigh");
-        launch_brick_build(bargs, coord4, rc2, n_col, pair_count, table16, d_flags, stream);
-        tend("neigh");
-        table32_valid = false;
+        if (layout == 1) {
+            HIPCHK(hipStreamSynchronize(stream));
+            bargs.active = brick_active;
+            bargs.nactive = h_flags[2];
+            tbegin("neigh");
+            launch_brick_build(bargs, coord4, rc2, n_col, pair_count, table16, d_flags, stream);
+            tend("neigh");
+            table32_valid = false;
+        } else {
+            tbegin("neigh");
+            launch_cell_build(coord4, rkey, estart, gstart, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count,
+                              pair_table, d_flags, stream);
+            tend("neigh");
+            table32_valid = true;
+        }
         nbuild++;
         return 0;
     }
@@ -745,7 +774,8 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
     p.beg = beg; p.end = end;
     p.accumulate = 1;
-    if (layout == 1 && !ev && pair_kernel != 0) {
+    p.debug = 0;
+    if (layout == 1 && !ev && pair_kernel == 1) {
         tbegin("pair");
         launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
         tend("pair");
@@ -754,6 +784,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     TRY(ensure_table32());
     tbegin("pair");
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
+    else if (pair_kernel == 2) launch_pair_dpd_mlp(p, pair_style, stream);
     else launch_pair_dpd_tile(p, pair_style, stream);
     tend("pair");
     if (ev) ev_valid = true;
@@ -796,8 +827,9 @@ int Engine::run(int nsteps)
         p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
         p.beg = 0; p.end = nlocal;
         p.accumulate = fuse_clear ? 0 : 1;
+        p.debug = pair_debug;
         if (!fuse_clear) TRY(force_clear(0));
-        if (layout == 1 && pair_kernel != 0) {
+        if (layout == 1 && pair_kernel == 1) {
             tbegin("pair");
             launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
             tend("pair");
@@ -805,6 +837,7 @@ int Engine::run(int nsteps)
             TRY(ensure_table32());
             tbegin("pair");
             if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
+            else if (pair_kernel == 2) launch_pair_dpd_mlp(p, pair_style, stream);
             else launch_pair_dpd_tile(p, pair_style, stream);
             tend("pair");
         }

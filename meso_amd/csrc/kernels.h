@@ -95,8 +95,15 @@ struct PairArgs {
     double dt_inv_sqrt;
     int beg, end;
     int accumulate;       // 1: f += (reference semantics), 0: f = (force_clear fused)
+    int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
+// lane-per-atom with 8-deep memory-level parallelism (forces only)
+void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
+// cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
+void launch_cell_build(const float4 *coord4, const uint64_t *sorted_key, const int *estart, const int *gstart, int M,
+                       const int *mbin, float rc2, int nlocal, int n_col, int *count, int *table, int *overflow,
+                       hipStream_t s);
 // wave-per-tile, ballot-compacted variant (forces only)
 void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s);
 
@@ -108,8 +115,13 @@ struct BrickArgs {
     int M;               // Morton codes per section (power of 8)
     int mbin[3];
     int nbricks;         // M / 32
+    const int *active;   // [nactive] ids (section*nbricks + brick) of bricks that own atoms
+    int nactive;
 };
+void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s);
+void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s);
 void launch_estart(const uint64_t *sorted_key, int n, int ncodes, int *estart, hipStream_t s);
+void launch_code_starts_u32(const uint32_t *sorted_key, int n, int ncodes, int *start, hipStream_t s);
 void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *key, int *val,
                          hipStream_t s);
 void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,

@@ -748,7 +748,10 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
         else cf64[p] = a.coeff64[p];
     }
     __syncthreads();
-    int i = a.beg + blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware order (blocks b and b+8 share an L2): each XCD walks a contiguous range of atoms
+    const int nbk = gridDim.x;
+    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
+    int i = a.beg + blk * blockDim.x + threadIdx.x;
     if (i >= a.end) return;
 
     const float4 c1 = a.coord4[i];
@@ -844,6 +847,188 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
     }
 }
 
+
+// =========================================================================================
+// cell-ordered list builder + pair force v3 (memory-level parallelism)
+// =========================================================================================
+// Locals are stored in cell order by the reorder sort ([border][Morton(bin)][sub-cell]) and ghosts are sorted by
+// Morton(bin) behind them, so the atoms of any bin are at most three contiguous runs of the merged arrays
+// (bulk, border, ghost) and a candidate's global index IS its position: no per-candidate indirection, and the
+// 27-bin walk of a lane reads contiguous float4 runs that its wave-mates (same or adjacent bins) share in L1.
+__device__ inline u32 compact3b(u32 x)
+{
+    x &= 0x09249249;
+    x = (x ^ (x >> 2)) & 0x030c30c3;
+    x = (x ^ (x >> 4)) & 0x0300f00f;
+    x = (x ^ (x >> 8)) & 0xff0000ff;
+    x = (x ^ (x >> 16)) & 0x000003ff;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) k_cell_build(const float4 *__restrict__ coord4, const u64 *__restrict__ key,
+                                                    const int *__restrict__ estart, const int *__restrict__ gstart,
+                                                    int M, int mbx, int mby, int mbz, float rc2, int nlocal, int n_col,
+                                                    int *__restrict__ count, int *__restrict__ table,
+                                                    int *__restrict__ overflow)
+{
+    const int nbk = gridDim.x;
+    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
+    const int i = blk * blockDim.x + threadIdx.x;
+    if (i >= nlocal) return;
+    const float4 ci = coord4[i];
+    const u32 m = (u32)(key[i] >> 12) & (u32)(M - 1);
+    const int bx = (int)compact3b(m), by = (int)compact3b(m >> 1), bz = (int)compact3b(m >> 2);
+    int *col = table + ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
+    int n = 0;
+#pragma unroll 1
+    for (int s = 0; s < 27; s++) {
+        const int x2 = bx + s % 3 - 1, y2 = by + (s / 3) % 3 - 1, z2 = bz + s / 9 - 1;
+        if (x2 < 0 || x2 >= mbx || y2 < 0 || y2 >= mby || z2 < 0 || z2 >= mbz) continue;
+        const u32 m2 = interleave3((u32)x2, (u32)y2, (u32)z2);
+#pragma unroll 1
+        for (int sec = 0; sec < 3; sec++) {
+            int kb, ke;
+            if (sec == 0) { kb = estart[m2]; ke = estart[m2 + 1]; }
+            else if (sec == 1) { kb = estart[(size_t)M + m2]; ke = estart[(size_t)M + m2 + 1]; }
+            else { kb = nlocal + gstart[m2]; ke = nlocal + gstart[m2 + 1]; }
+            int k = kb;
+            for (; k + 4 <= ke; k += 4) {     // four independent loads in flight per lane
+                float4 c0 = coord4[k], c1 = coord4[k + 1], c2 = coord4[k + 2], c3 = coord4[k + 3];
+                float d0 = dist2(ci, c0), d1 = dist2(ci, c1), d2 = dist2(ci, c2), d3 = dist2(ci, c3);
+                if (k != i && d0 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k; n++; }
+                if (k + 1 != i && d1 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k + 1; n++; }
+                if (k + 2 != i && d2 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k + 2; n++; }
+                if (k + 3 != i && d3 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k + 3; n++; }
+            }
+            for (; k < ke; k++) {
+                float d0 = dist2(ci, coord4[k]);
+                if (k != i && d0 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k; n++; }
+            }
+        }
+    }
+    if (n > n_col) { atomicMax(overflow, n); n = n_col; }
+    count[i] = n;
+}
+
+void launch_cell_build(const float4 *coord4, const uint64_t *sorted_key, const int *estart, const int *gstart, int M,
+                       const int *mbin, float rc2, int nlocal, int n_col, int *count, int *table, int *overflow,
+                       hipStream_t s)
+{
+    if (nlocal <= 0) return;
+    int g = (nblk(nlocal, 256) + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_cell_build, dim3(g), dim3(256), 0, s, coord4, (const u64 *)sorted_key, estart, gstart, M, mbin[0],
+                       mbin[1], mbin[2], rc2, nlocal, n_col, count, table, overflow);
+}
+
+// pair force v3: lane per atom like v1, but the row is consumed 8 entries at a time -- 8 index loads, then 8
+// coordinate gathers, then the velocity gathers of the hits are all in flight together, so a wave keeps ~8
+// L2 requests per lane outstanding instead of one (v1 measured 86 % of wave cycles waiting on memory).
+template <bool FAST, int PAIR3_CH, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
+{
+    extern __shared__ double smem[];
+    double *cf64 = smem;
+    float *cf32 = (float *)smem;
+    const int ncf = a.ntypes * a.ntypes * N_COEFF;
+    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
+        if (FAST) cf32[p] = a.coeff32[p];
+        else cf64[p] = a.coeff64[p];
+    }
+    __syncthreads();
+    const int nbk = gridDim.x;
+    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
+    const int i = a.beg + blk * blockDim.x + threadIdx.x;
+    if (i >= a.end) return;
+    const float4 c1 = a.coord4[i];
+    const float4 v1 = a.veloc4[i];
+    const u32 t1 = __float_as_uint(c1.w), s1 = __float_as_uint(v1.w);
+    const int n = a.count[i];
+    const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
+    const float dtis32 = (float)a.dt_inv_sqrt;
+    float fx32 = 0.f, fy32 = 0.f, fz32 = 0.f;
+    double fx = 0., fy = 0., fz = 0.;
+
+    for (int p0 = 0; p0 < n; p0 += PAIR3_CH) {
+        int j[PAIR3_CH];
+        float4 c2[PAIR3_CH], v2[PAIR3_CH];
+        bool hit[PAIR3_CH];
+#pragma unroll
+        for (int q = 0; q < PAIR3_CH; q++) j[q] = (p0 + q < n) ? col[(size_t)(p0 + q) * 64] : i;   // self: rsq = 0, rejected
+#pragma unroll
+        for (int q = 0; q < PAIR3_CH; q++) c2[q] = a.coord4[j[q]];
+#pragma unroll
+        for (int q = 0; q < PAIR3_CH; q++) {
+            const int cidx = t1 * a.ntypes + __float_as_uint(c2[q].w);
+            if (FAST) {
+                float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
+                float rsq = dx * dx + dy * dy + dz * dz;
+                hit[q] = rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
+            } else {
+                double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
+                double rsq = dx * dx + dy * dy + dz * dz;
+                hit[q] = rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
+            }
+            v2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hit[q]) v2[q] = a.veloc4[j[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < PAIR3_CH; q++) {
+            if (!hit[q]) continue;
+            const int cidx = t1 * a.ntypes + __float_as_uint(c2[q].w);
+            const u32 s2 = __float_as_uint(v2[q].w);
+            if (FAST) {
+                const float *cf = cf32 + cidx * N_COEFF;
+                float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
+                float rsq = dx * dx + dy * dy + dz * dz;
+                float rn = gaussian_tea_fast(s1, s2);
+                float rinv = __builtin_amdgcn_rsqf(rsq);
+                float r = rsq * rinv;
+                float dvx = v1.x - v2[q].x, dvy = v1.y - v2[q].y, dvz = v1.z - v2[q].z;
+                float dot = dx * dvx + dy * dvy + dz * dvz;
+                float wc = 1.0f - r * cf[P_CUTINV];
+                float ew = cf[P_EXPW];
+                float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
+                float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
+                fpair *= rinv;
+                fx32 += dx * fpair; fy32 += dy * fpair; fz32 += dz * fpair;
+            } else {
+                const double *cf = cf64 + cidx * N_COEFF;
+                double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
+                double rsq = dx * dx + dy * dy + dz * dz;
+                double rn = gaussian_tea(s1, s2);
+                double rinv = rsqrt(rsq);
+                double r = rsq * rinv;
+                double dvx = (double)v1.x - (double)v2[q].x, dvy = (double)v1.y - (double)v2[q].y, dvz = (double)v1.z - (double)v2[q].z;
+                double dot = dx * dvx + dy * dvy + dz * dvz;
+                double wc = 1.0 - r * cf[P_CUTINV];
+                double ew = cf[P_EXPW];
+                double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
+                double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
+                fpair *= rinv;
+                fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+            }
+            // keep the (long) per-pair arithmetic of different slots from being interleaved: the gathers above
+            // already provide the memory-level parallelism, interleaving only costs registers (occupancy)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (FAST) { fx = fx32; fy = fy32; fz = fz32; }
+    if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
+    else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
+}
+
+void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s)
+{
+    int n = p.end - p.beg;
+    if (n <= 0) return;
+    size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? sizeof(float) : sizeof(double));
+    dim3 grid((nblk(n, 256) + 7) / 8 * 8), block(256);
+    // fp64 math needs twice the registers per pair in flight: 4-deep keeps 4+ waves per SIMD
+    // depth x occupancy measured on 64^3 (profiles/r01_notes.md): fp32 8-deep at 4 waves/SIMD (112 VGPRs);
+    // fp64 keeps ~45 polynomial constants live, so 2-deep under a 128-VGPR budget wins there
+    if (fast) hipLaunchKernelGGL((k_pair_dpd_mlp<true, 8, 4>), grid, block, sm, s, p);
+    else hipLaunchKernelGGL((k_pair_dpd_mlp<false, 2, 4>), grid, block, sm, s, p);
+}
 
 // =========================================================================================
 // pair force, v2: wave-per-tile, ballot-compacted heavy phase
@@ -1029,7 +1214,7 @@ void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s)
     int n = p.end - p.beg;
     if (n <= 0) return;
     size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? sizeof(float) : sizeof(double));
-    dim3 grid(nblk(n, 256)), block(256);
+    dim3 grid((nblk(n, 256) + 7) / 8 * 8), block(256);
     if (fast && evflag) hipLaunchKernelGGL((k_pair_dpd<true, true>), grid, block, sm, s, p);
     else if (fast) hipLaunchKernelGGL((k_pair_dpd<true, false>), grid, block, sm, s, p);
     else if (evflag) hipLaunchKernelGGL((k_pair_dpd<false, true>), grid, block, sm, s, p);

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 # engine code paths: (layout, pair_kernel).  layout 0 = global-index rows gathered through L2, layout 1 = bricks
 # with LDS-staged halos and 16-bit rows; pair_kernel 0 = lane per atom, 1 = ballot-compacted (tile / brick).
 PATHS = {"lane": (("layout", 0), ("pair_kernel", 0)), "tile": (("layout", 0), ("pair_kernel", 1)),
-         "brick": (("layout", 1), ("pair_kernel", 1)), "brick-rows+lane": (("layout", 1), ("pair_kernel", 0))}
+         "brick": (("layout", 1), ("pair_kernel", 1)), "brick-rows+lane": (("layout", 1), ("pair_kernel", 0)),
+         "cell+mlp": (("layout", 2), ("pair_kernel", 2))}
 
 
 @pytest.fixture(scope="module")
@@ -83,7 +84,7 @@ def test_gaussian_tea(Meso, oracle):
     assert np.abs(dp).max() <= 4.0 and abs(dp.mean()) < 0.03 and abs(dp.var() - 1) < 0.03
 
 
-@pytest.mark.parametrize("kernel,layout", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("kernel,layout", [(0, 0), (1, 0), (1, 1), (1, 2)])
 def test_merged_arrays_and_neighbor_sets(Meso, oracle, kernel, layout):
     L = 7
     m, _ = _engine(Meso, L, kernel=kernel, opts=(("layout", layout),))
@@ -158,7 +159,7 @@ def test_sigma0_vs_stock_lammps_cpu(Meso, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("path", ["lane", "tile", "brick"])
+@pytest.mark.parametrize("path", ["lane", "tile", "brick", "cell+mlp"])
 @pytest.mark.parametrize("style,every,sigma,steps", [("dpd/meso", 5, 3.0, 12), ("dpd/meso", 1, 3.0, 12),
                                                      ("dpd/fast/meso", 5, 0.0, 12), ("dpd/fast/meso", 5, 3.0, 1)])
 def test_trajectory_vs_meso_oracle(Meso, oracle, style, every, sigma, steps, path):
