@@ -444,10 +444,10 @@ void launch_brick_compact(const int *flag, const int *pos, int M, int *active, i
     hipLaunchKernelGGL(k_brick_compact, dim3((nb2 + 255) / 256), dim3(256), 0, s, flag, pos, nb2, active, nactive);
 }
 
-void launch_estart(const uint64_t *sorted_key, int n, int ncodes, int *estart, hipStream_t s)
+void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_code_starts<u64>, dim3((ncodes + 1 + 255) / 256), dim3(256), 0, s, (const u64 *)sorted_key, n, 12,
-                       ncodes, estart);
+    hipLaunchKernelGGL(k_code_starts<u32>, dim3((ncodes + 1 + 255) / 256), dim3(256), 0, s, sorted_key, n, key_shift, ncodes,
+                       estart);
 }
 
 void launch_code_starts_u32(const uint32_t *sorted_key, int n, int ncodes, int *start, hipStream_t s)

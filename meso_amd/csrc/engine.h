@@ -152,6 +152,7 @@ private:
     // brick layout
     int layout = 2;                 // 0: bin-sorted cell list, 1: bricks with LDS-staged halos, 2: cell-ordered atoms
     int *estart = nullptr, *gstart = nullptr, *gslot = nullptr;
+    int4 *binrange = nullptr;
     int *brick_flag = nullptr, *brick_pos = nullptr, *brick_active = nullptr;
     size_t estart_cap = 0;
     unsigned short *table16 = nullptr;
@@ -161,7 +162,7 @@ private:
     int ensure_table32();
 
     // reorder
-    uint64_t *rkey = nullptr, *rkey_alt = nullptr;
+    uint32_t *rkey = nullptr, *rkey_alt = nullptr;
     int *rval = nullptr, *rval_alt = nullptr;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;

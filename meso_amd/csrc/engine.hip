@@ -77,7 +77,7 @@ void Engine::free_all()
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
     dfree(estart); dfree(gstart); dfree(gslot); dfree(table16);
-    dfree(brick_flag); dfree(brick_pos); dfree(brick_active);
+    dfree(brick_flag); dfree(brick_pos); dfree(brick_active); dfree(binrange);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
     dfree(d_partial); dfree(d_scalar); dfree(d_flags);
     if (h_flags) (void)hipHostFree(h_flags);
@@ -472,6 +472,8 @@ int Engine::init_params()
             estart_cap = 2 * M + 1;
             HIPCHK(dalloc(estart, estart_cap));
             HIPCHK(dalloc(gstart, M + 1));
+            dfree(binrange);
+            HIPCHK(dalloc(binrange, 2 * M));
             HIPCHK(dalloc(brick_flag, M / 16 + 1));
             HIPCHK(dalloc(brick_pos, M / 16 + 1));
             HIPCHK(dalloc(brick_active, M / 16 + 1));
@@ -529,7 +531,7 @@ int Engine::reorder_locals()
     tbegin("reorder");
     int bits = reorder_key_bits(geom);
     launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
-    HIPCHK(sort_pairs_u64(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
+    HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
     HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
     launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
     launch_permute_atoms(cur, alt, rval, nlocal, stream);
@@ -611,7 +613,7 @@ int Engine::build_cells_and_table()
     if (layout >= 1) {
         // locals are already cell-ordered by the reorder sort; only the ghosts need binning
         tbegin("bin");
-        launch_estart(rkey, nlocal, 2 * bargs.M, estart, stream);
+        launch_estart(rkey, nlocal, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);
         if (layout == 1) {
             launch_brick_flags(estart, bargs.M, brick_flag, stream);
             HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, brick_flag, brick_pos, 2 * bargs.nbricks, stream));
@@ -638,8 +640,9 @@ int Engine::build_cells_and_table()
             table32_valid = false;
         } else {
             tbegin("neigh");
-            launch_cell_build(coord4, rkey, estart, gstart, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count,
-                              pair_table, d_flags, stream);
+            launch_bin_ranges(estart, gstart, bargs.M, nlocal, binrange, stream);
+            launch_cell_build(coord4, rkey, reorder_sub_bits(geom), binrange, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count, pair_table,
+                              d_flags, stream);
             tend("neigh");
             table32_valid = true;
         }
@@ -775,6 +778,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.beg = beg; p.end = end;
     p.accumulate = 1;
     p.debug = 0;
+    p.chunked = layout == 2 ? 1 : 0;
     if (layout == 1 && !ev && pair_kernel == 1) {
         tbegin("pair");
         launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
@@ -784,7 +788,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     TRY(ensure_table32());
     tbegin("pair");
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
-    else if (pair_kernel == 2) launch_pair_dpd_mlp(p, pair_style, stream);
+    else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
     else launch_pair_dpd_tile(p, pair_style, stream);
     tend("pair");
     if (ev) ev_valid = true;
@@ -828,6 +832,7 @@ int Engine::run(int nsteps)
         p.beg = 0; p.end = nlocal;
         p.accumulate = fuse_clear ? 0 : 1;
         p.debug = pair_debug;
+        p.chunked = layout == 2 ? 1 : 0;
         if (!fuse_clear) TRY(force_clear(0));
         if (layout == 1 && pair_kernel == 1) {
             tbegin("pair");
@@ -837,7 +842,7 @@ int Engine::run(int nsteps)
             TRY(ensure_table32());
             tbegin("pair");
             if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
-            else if (pair_kernel == 2) launch_pair_dpd_mlp(p, pair_style, stream);
+            else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
             else launch_pair_dpd_tile(p, pair_style, stream);
             tend("pair");
         }
@@ -941,7 +946,10 @@ int Engine::neigh_download(int *count, int *table, int stride)
     HIPCHK(hipMemcpy(h.data(), pair_table, h.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < nlocal; i++) {
         int n = std::min(count[i], stride);
-        for (int p = 0; p < n; p++) table[(size_t)i * stride + p] = h[(((size_t)(i >> 6)) * n_col + p) * 64 + (i & 63)];
+        for (int p = 0; p < n; p++)
+            table[(size_t)i * stride + p] =
+                layout == 2 ? h[((((size_t)(i >> 6)) * (n_col >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)]
+                            : h[(((size_t)(i >> 6)) * n_col + p) * 64 + (i & 63)];
     }
     return 0;
 }

@@ -43,9 +43,10 @@ void launch_copy_hold(const AtomSoA &a, double *xhold, int n, int stride, hipStr
 // ---- reorder (atom_meso.cu:268-314, comm_meso.cu:188-254) ---------------------------------------------
 // key = [border][Morton(bin)][Morton(16^3 sub-cell)]; returns number of significant key bits.
 int reorder_key_bits(const BinGeom &g);
+int reorder_sub_bits(const BinGeom &g);
 void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi,
-                         const int *dim_active, uint64_t *key, int *val, int n, hipStream_t s);
-void launch_count_border(const uint64_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
+                         const int *dim_active, uint32_t *key, int *val, int n, hipStream_t s);
+void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, hipStream_t s);
 void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s);
 
@@ -95,13 +96,15 @@ struct PairArgs {
     double dt_inv_sqrt;
     int beg, end;
     int accumulate;       // 1: f += (reference semantics), 0: f = (force_clear fused)
+    int chunked;          // 1: chunked-8 rows (cell-ordered builder), 0: transposed 64-atom tiles
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // lane-per-atom with 8-deep memory-level parallelism (forces only)
 void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
-void launch_cell_build(const float4 *coord4, const uint64_t *sorted_key, const int *estart, const int *gstart, int M,
+void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
+void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key_shift, const int4 *binrange, int M,
                        const int *mbin, float rc2, int nlocal, int n_col, int *count, int *table, int *overflow,
                        hipStream_t s);
 // wave-per-tile, ballot-compacted variant (forces only)
@@ -120,7 +123,7 @@ struct BrickArgs {
 };
 void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s);
 void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s);
-void launch_estart(const uint64_t *sorted_key, int n, int ncodes, int *estart, hipStream_t s);
+void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s);
 void launch_code_starts_u32(const uint32_t *sorted_key, int n, int ncodes, int *start, hipStream_t s);
 void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *key, int *val,
                          hipStream_t s);

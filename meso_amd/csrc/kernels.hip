@@ -9,6 +9,12 @@ namespace meso {
 static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 static inline int capgrid(long n, int b, int cap = 256 * 8) { int g = nblk(n, b); return g < 1 ? 1 : (g > cap ? cap : g); }
 
+// Row layout of the cell-ordered table ("chunked-8"): 8 consecutive entries of one atom form one 32-byte word,
+// word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63).  A lane writes/reads whole 32-B sectors (no partial-sector
+// writes: the 4-byte scattered stores of the transposed layout cost 8x the bytes at HBM, profiles/r01_pmc_*),
+// and a wave's access to chunk c of its 64 atoms is one contiguous 2 KiB.
+__device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
+
 // =========================================================================================
 // atom kernels
 // =========================================================================================
@@ -261,60 +267,73 @@ void launch_unpack_mass(const int *type, const double *mass_type, int, double *m
 // =========================================================================================
 // reorder
 // =========================================================================================
-int reorder_key_bits(const BinGeom &g)
+static int reorder_l1(const BinGeom &g)
 {
     int max_bin = g.mbin[0] > g.mbin[1] ? g.mbin[0] : g.mbin[1];
     if (g.mbin[2] > max_bin) max_bin = g.mbin[2];
     int l1 = 0;
-    while ((1 << (l1 + 1)) <= max_bin * 2) l1++;   // floor(log2(2*max_bin))
-    return 1 + 3 * l1 + 12;
+    while ((1 << (l1 + 1)) <= max_bin * 2) l1++;   // floor(log2(2*max_bin)), as sort_local (atom_meso.cu:354)
+    return l1;
 }
+
+// Key = [border][Morton(bin): 3*l1 bits][Morton(sub-cell): sb bits].  The reference always spends 12 bits on a
+// 16^3 sub-cell grid and sorts 64-bit keys; here the sub-cell resolution shrinks (16^3, 8^3, 4^3 ...) so the
+// whole key fits 32 bits and rocPRIM's one-sweep radix sort applies.
+int reorder_sub_bits(const BinGeom &g)
+{
+    int room = 32 - 1 - 3 * reorder_l1(g);
+    int sb = room >= 12 ? 12 : (room / 3) * 3;
+    return sb < 0 ? 0 : sb;
+}
+
+int reorder_key_bits(const BinGeom &g) { return 1 + 3 * reorder_l1(g) + reorder_sub_bits(g); }
 
 // gpu_build_reorder_keypair<1> (atom_meso.cu:268-308) with borderness (comm_meso.cu:188-254) computed in place
 __global__ void __launch_bounds__(256) k_reorder_keys(const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ z, BinGeom g, double slx, double sly,
                                                       double slz, double shx, double shy, double shz, int border_bit,
-                                                      u64 *__restrict__ key, int *__restrict__ val, int n)
+                                                      int sub_bits, u32 *__restrict__ key, int *__restrict__ val, int n)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
     if (i >= n) return;
     const double c[3] = {x[i], y[i], z[i]};
+    const int res = 1 << (sub_bits / 3);
     u32 b[3], sc[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         b[d] = (u32)clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1), 0, g.mbin[d]);
-        sc[d] = (u32)clampi((int)((c[d] - g.lo[d] - ((double)b[d] - 1) * g.binsize[d]) * (16 * g.bininv[d])), 0, 16);
+        sc[d] = (u32)clampi((int)((c[d] - g.lo[d] - ((double)b[d] - 1) * g.binsize[d]) * (res * g.bininv[d])), 0, res);
     }
-    u64 k = ((u64)interleave3(b[0], b[1], b[2]) << 12) | (u64)interleave3(sc[0], sc[1], sc[2]);
+    u32 k = (interleave3(b[0], b[1], b[2]) << sub_bits) | interleave3(sc[0], sc[1], sc[2]);
     bool border = c[0] <= slx || c[0] >= shx || c[1] <= sly || c[1] >= shy || c[2] <= slz || c[2] >= shz;
-    if (border) k |= (1ULL << border_bit);
+    if (border) k |= (1u << border_bit);
     key[i] = k;
     val[i] = i;
 }
 
 void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi, const int *,
-                         uint64_t *key, int *val, int n, hipStream_t s)
+                         uint32_t *key, int *val, int n, hipStream_t s)
 {
     if (n <= 0) return;
     int bits = reorder_key_bits(g);
     hipLaunchKernelGGL(k_reorder_keys, dim3(nblk(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, slab_lo[0],
-                       slab_lo[1], slab_lo[2], slab_hi[0], slab_hi[1], slab_hi[2], bits - 1, (u64 *)key, val, n);
+                       slab_lo[1], slab_lo[2], slab_hi[0], slab_hi[1], slab_hi[2], bits - 1, reorder_sub_bits(g), key, val,
+                       n);
 }
 
 // first sorted position whose key carries the border bit == n_bulk
-__global__ void __launch_bounds__(256) k_count_border(const u64 *__restrict__ key, int n, int border_bit,
+__global__ void __launch_bounds__(256) k_count_border(const u32 *__restrict__ key, int n, int border_bit,
                                                       int *__restrict__ n_bulk)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
     if (i > n) return;
-    bool cur = (i == n) ? true : ((key[i] >> border_bit) & 1ULL) != 0;
-    bool prev = (i == 0) ? false : ((key[i - 1] >> border_bit) & 1ULL) != 0;
+    bool cur = (i == n) ? true : ((key[i] >> border_bit) & 1u) != 0;
+    bool prev = (i == 0) ? false : ((key[i - 1] >> border_bit) & 1u) != 0;
     if (cur && !prev) *n_bulk = i;
 }
-void launch_count_border(const uint64_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s)
+void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_count_border, dim3(nblk(n + 1, 256)), dim3(256), 0, s, (const u64 *)sorted_key, n, border_bit,
-                       n_bulk_out);
+    hipLaunchKernelGGL(k_count_border, dim3(nblk(n + 1, 256)), dim3(256), 0, s, sorted_key, n, border_bit, n_bulk_out);
 }
 
 // gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
@@ -759,13 +778,17 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
     const u32 t1 = __float_as_uint(c1.w), s1 = __float_as_uint(v1.w);
     const int n = a.count[i];
     const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
+    // row entry p: transposed 64-atom tiles, or chunked-8 words (cell-ordered builder)
+    auto entry = [&](int p) -> int {
+        return a.chunked ? a.table[row_word8(i, p >> 3, a.n_col) * 8 + (p & 7)] : col[(size_t)p * 64];
+    };
 
     if (FAST) {
         float fx = 0.f, fy = 0.f, fz = 0.f, energy = 0.f;
         float vr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float dtis = (float)a.dt_inv_sqrt;
         for (int p = 0; p < n; p++) {
-            int j = col[(size_t)p * 64];
+            int j = entry(p);
             float4 c2 = a.coord4[j];
             float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
             float rsq = dx * dx + dy * dy + dz * dz;
@@ -804,7 +827,7 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
         double fx = 0., fy = 0., fz = 0., energy = 0.;
         double vr[6] = {0., 0., 0., 0., 0., 0.};
         for (int p = 0; p < n; p++) {
-            int j = col[(size_t)p * 64];
+            int j = entry(p);
             float4 c2 = a.coord4[j];
             double dx = (double)c1.x - (double)c2.x;
             double dy = (double)c1.y - (double)c2.y;
@@ -865,59 +888,122 @@ __device__ inline u32 compact3b(u32 x)
     return x;
 }
 
-__global__ void __launch_bounds__(256) k_cell_build(const float4 *__restrict__ coord4, const u64 *__restrict__ key,
-                                                    const int *__restrict__ estart, const int *__restrict__ gstart,
-                                                    int M, int mbx, int mby, int mbz, float rc2, int nlocal, int n_col,
+// binrange[m] = {bulk start,end, border start,end | ghost start,end (absolute), 0, 0}: the three runs of bin m
+__global__ void __launch_bounds__(256) k_bin_ranges(const int *__restrict__ estart, const int *__restrict__ gstart, int M,
+                                                    int nlocal, int4 *__restrict__ binrange)
+{
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    binrange[2 * (size_t)m] = make_int4(estart[m], estart[m + 1], estart[(size_t)M + m], estart[(size_t)M + m + 1]);
+    binrange[2 * (size_t)m + 1] = make_int4(nlocal + gstart[m], nlocal + gstart[m + 1], 0, 0);
+}
+
+void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bin_ranges, dim3(nblk(M, 256)), dim3(256), 0, s, estart, gstart, M, nlocal, binrange);
+}
+
+// per-lane 8-entry staging in LDS: stage[q][lane]; a full chunk leaves as two 16-byte stores
+#define CELL_PUSH(kk)                                                                         \
+    {                                                                                         \
+        stage[(n & 7) * 256 + threadIdx.x] = (kk);                                            \
+        if ((n & 7) == 7 && n < n_col) {                                                      \
+            int4 lo_ = make_int4(stage[threadIdx.x], stage[256 + threadIdx.x], stage[512 + threadIdx.x], stage[768 + threadIdx.x]); \
+            int4 hi_ = make_int4(stage[1024 + threadIdx.x], stage[1280 + threadIdx.x], stage[1536 + threadIdx.x], (kk)); \
+            int4 *w_ = rows + 2 * row_word8(i, n >> 3, n_col);                                \
+            w_[0] = lo_; w_[1] = hi_;                                                         \
+        }                                                                                     \
+        n++;                                                                                  \
+    }
+#define CELL_TEST(kk, cc)                                                        \
+    {                                                                            \
+        float d_ = dist2(ci, cc);                                                \
+        if ((kk) != i && d_ <= rc2) CELL_PUSH(kk)                                \
+    }
+
+__device__ inline void cell_run(const float4 *__restrict__ coord4, int kb, int ke, const float4 ci, int i, float rc2,
+                                int n_col, int4 *__restrict__ rows, int *stage, int &n)
+{
+    int k = kb;
+    for (; k + 4 <= ke; k += 4) {     // four independent loads in flight per lane
+        float4 c0 = coord4[k], c1 = coord4[k + 1], c2 = coord4[k + 2], c3 = coord4[k + 3];
+        CELL_TEST(k, c0) CELL_TEST(k + 1, c1) CELL_TEST(k + 2, c2) CELL_TEST(k + 3, c3)
+    }
+    for (; k < ke; k++) {
+        float4 c0 = coord4[k];
+        CELL_TEST(k, c0)
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cell_build(const float4 *__restrict__ coord4, const u32 *__restrict__ key,
+                                                    int key_shift, const int4 *__restrict__ binrange, int M, int mbx,
+                                                    int mby, int mbz, float rc2, int nlocal, int n_col,
                                                     int *__restrict__ count, int *__restrict__ table,
                                                     int *__restrict__ overflow)
 {
+    __shared__ int stage[8 * 256];
     const int nbk = gridDim.x;
     const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
     const int i = blk * blockDim.x + threadIdx.x;
     if (i >= nlocal) return;
     const float4 ci = coord4[i];
-    const u32 m = (u32)(key[i] >> 12) & (u32)(M - 1);
+    const u32 m = (key[i] >> key_shift) & (u32)(M - 1);
     const int bx = (int)compact3b(m), by = (int)compact3b(m >> 1), bz = (int)compact3b(m >> 2);
-    int *col = table + ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
+    int4 *rows = (int4 *)table;
     int n = 0;
-#pragma unroll 1
-    for (int s = 0; s < 27; s++) {
-        const int x2 = bx + s % 3 - 1, y2 = by + (s / 3) % 3 - 1, z2 = bz + s / 9 - 1;
-        if (x2 < 0 || x2 >= mbx || y2 < 0 || y2 >= mby || z2 < 0 || z2 >= mbz) continue;
-        const u32 m2 = interleave3((u32)x2, (u32)y2, (u32)z2);
-#pragma unroll 1
-        for (int sec = 0; sec < 3; sec++) {
-            int kb, ke;
-            if (sec == 0) { kb = estart[m2]; ke = estart[m2 + 1]; }
-            else if (sec == 1) { kb = estart[(size_t)M + m2]; ke = estart[(size_t)M + m2 + 1]; }
-            else { kb = nlocal + gstart[m2]; ke = nlocal + gstart[m2 + 1]; }
-            int k = kb;
-            for (; k + 4 <= ke; k += 4) {     // four independent loads in flight per lane
-                float4 c0 = coord4[k], c1 = coord4[k + 1], c2 = coord4[k + 2], c3 = coord4[k + 3];
-                float d0 = dist2(ci, c0), d1 = dist2(ci, c1), d2 = dist2(ci, c2), d3 = dist2(ci, c3);
-                if (k != i && d0 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k; n++; }
-                if (k + 1 != i && d1 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k + 1; n++; }
-                if (k + 2 != i && d2 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k + 2; n++; }
-                if (k + 3 != i && d3 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k + 3; n++; }
-            }
-            for (; k < ke; k++) {
-                float d0 = dist2(ci, coord4[k]);
-                if (k != i && d0 <= rc2) { if (n < n_col) col[(size_t)n * 64] = k; n++; }
+    // one (dy,dz) row of three x-adjacent bins at a time; the six range words of the NEXT row are requested
+    // before the current row's candidates are walked, so the dependent bin->range->atoms chain overlaps
+    int4 ra[3], rb[3];
+    auto fetch = [&](int r, int4 *qa, int4 *qb) {
+        const int y2 = by + r % 3 - 1, z2 = bz + r / 3 - 1;
+        const bool rowok = r < 9 && y2 >= 0 && y2 < mby && z2 >= 0 && z2 < mbz;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int x2 = bx + t - 1;
+            qa[t] = make_int4(0, 0, 0, 0);
+            qb[t] = make_int4(0, 0, 0, 0);
+            if (rowok && x2 >= 0 && x2 < mbx) {
+                const size_t m2 = interleave3((u32)x2, (u32)y2, (u32)z2);
+                qa[t] = binrange[2 * m2];
+                qb[t] = binrange[2 * m2 + 1];
             }
         }
+    };
+    fetch(0, ra, rb);
+#pragma unroll 1
+    for (int r = 0; r < 9; r++) {
+        int4 na[3], nb[3];
+        fetch(r + 1, na, nb);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            cell_run(coord4, ra[t].x, ra[t].y, ci, i, rc2, n_col, rows, stage, n);
+            if (ra[t].w > ra[t].z) cell_run(coord4, ra[t].z, ra[t].w, ci, i, rc2, n_col, rows, stage, n);
+            if (rb[t].y > rb[t].x) cell_run(coord4, rb[t].x, rb[t].y, ci, i, rc2, n_col, rows, stage, n);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) { ra[t] = na[t]; rb[t] = nb[t]; }
+    }
+    // tail chunk (unused slots point at the atom itself: rsq = 0 is rejected by the force kernel)
+    if ((n & 7) && n < n_col) {
+        int v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = q < (n & 7) ? stage[q * 256 + threadIdx.x] : i;
+        int4 *w_ = rows + 2 * row_word8(i, n >> 3, n_col);
+        w_[0] = make_int4(v[0], v[1], v[2], v[3]);
+        w_[1] = make_int4(v[4], v[5], v[6], v[7]);
     }
     if (n > n_col) { atomicMax(overflow, n); n = n_col; }
     count[i] = n;
 }
 
-void launch_cell_build(const float4 *coord4, const uint64_t *sorted_key, const int *estart, const int *gstart, int M,
+void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key_shift, const int4 *binrange, int M,
                        const int *mbin, float rc2, int nlocal, int n_col, int *count, int *table, int *overflow,
                        hipStream_t s)
 {
     if (nlocal <= 0) return;
     int g = (nblk(nlocal, 256) + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_cell_build, dim3(g), dim3(256), 0, s, coord4, (const u64 *)sorted_key, estart, gstart, M, mbin[0],
-                       mbin[1], mbin[2], rc2, nlocal, n_col, count, table, overflow);
+    hipLaunchKernelGGL(k_cell_build, dim3(g), dim3(256), 0, s, coord4, sorted_key, key_shift, binrange, M, mbin[0], mbin[1],
+                       mbin[2], rc2, nlocal, n_col, count, table, overflow);
 }
 
 // pair force v3: lane per atom like v1, but the row is consumed 8 entries at a time -- 8 index loads, then 8
@@ -944,6 +1030,7 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
     const u32 t1 = __float_as_uint(c1.w), s1 = __float_as_uint(v1.w);
     const int n = a.count[i];
     const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
+    const int4 *rows = (const int4 *)a.table;
     const float dtis32 = (float)a.dt_inv_sqrt;
     float fx32 = 0.f, fy32 = 0.f, fz32 = 0.f;
     double fx = 0., fy = 0., fz = 0.;
@@ -952,8 +1039,24 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
         int j[PAIR3_CH];
         float4 c2[PAIR3_CH], v2[PAIR3_CH];
         bool hit[PAIR3_CH];
+        if (a.chunked) {
+            // chunked-8 rows: PAIR3_CH entries = PAIR3_CH/4 aligned 16-byte loads (tail slots hold i itself)
+            if constexpr (PAIR3_CH >= 4) {
 #pragma unroll
-        for (int q = 0; q < PAIR3_CH; q++) j[q] = (p0 + q < n) ? col[(size_t)(p0 + q) * 64] : i;   // self: rsq = 0, rejected
+                for (int q4 = 0; q4 < PAIR3_CH / 4; q4++) {
+                    int4 w = rows[2 * row_word8(i, p0 >> 3, a.n_col) + ((p0 & 7) >> 2) + q4];
+                    j[4 * q4] = w.x; j[4 * q4 + 1] = w.y; j[4 * q4 + 2] = w.z; j[4 * q4 + 3] = w.w;
+                }
+            } else {
+                int2 w = ((const int2 *)a.table)[4 * row_word8(i, p0 >> 3, a.n_col) + ((p0 & 7) >> 1)];
+                j[0] = w.x; j[1] = w.y;
+            }
+#pragma unroll
+            for (int q = 0; q < PAIR3_CH; q++) j[q] = (p0 + q < n) ? j[q] : i;
+        } else {
+#pragma unroll
+            for (int q = 0; q < PAIR3_CH; q++) j[q] = (p0 + q < n) ? col[(size_t)(p0 + q) * 64] : i;   // self: rsq = 0, rejected
+        }
 #pragma unroll
         for (int q = 0; q < PAIR3_CH; q++) c2[q] = a.coord4[j[q]];
 #pragma unroll
