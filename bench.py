@@ -40,14 +40,27 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Threads for the CPU baseline: the scheduler affinity, clipped by the cgroup CPU quota and by 64
+    (the OpenMP mode keeps one private force window per thread)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(L, x, v, lo, hi, every, steps):
     """Stock LAMMPS CPU pair_style dpd restatement (oracle/lmp_dpd_cpu.c, golden-pinned) timed on the host
     cores of this box: the same box, a bounded number of steps."""
     from oracle import bindings as ob
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     if steps <= 0:
         # ~1.4 M particle-steps/s/core measured for the reference binary (BASELINE.md); aim at ~15 s
-        steps = int(max(5, min(200, 15.0 * 1.4e6 * cores * 0.6 / len(x))))
+        steps = int(max(5, min(400, 15.0 * 1.4e6 * cores * 0.5 / len(x))))
         steps = max(every, steps // every * every)
     s = ob.LmpDpd(x, lo, hi, nthreads=cores)
     s.pair_style(1.0, 1.0, 419084618)
@@ -155,7 +168,7 @@ def main():
                    "avg_neighbors": info["avg_count"], "temperature_end": T},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_pair_dpd", "bytes_per_launch": b_pair, "us_per_launch": t_pair * 1e6},
+                     "kernel": "k_pair_dpd_mlp", "bytes_per_launch": b_pair, "us_per_launch": t_pair * 1e6},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
     }
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:

@@ -26,7 +26,7 @@ enum { MESO_PAIR_DPD = 0, MESO_PAIR_DPD_FAST = 1 };
 /* work ranges, AtomAttribute::LOCAL/BULK/BORDER util_meso.h:43-74, resolve_work_range atom_vec_meso.cu:194-218 */
 enum { MESO_RANGE_LOCAL = 0, MESO_RANGE_BULK = 1, MESO_RANGE_BORDER = 2 };
 /* ghost transports */
-enum { MESO_TRANSPORT_SELF = 0, MESO_TRANSPORT_RCCL = 1, MESO_TRANSPORT_HOST = 2 };
+enum { MESO_TRANSPORT_SELF = 0, MESO_TRANSPORT_RCCL = 1, MESO_TRANSPORT_HOST = 2, MESO_TRANSPORT_LOCAL = 3 };
 
 const char *meso_last_error(void);
 int meso_version(void);
@@ -40,10 +40,13 @@ int meso_set_option(meso_ctx *ctx, const char *key, double value);
 
 /* ---- domain + decomposition: Domain box, MesoComm procgrid (comm_meso.cu:41-186, src/comm.cpp Comm::setup) */
 int meso_set_box(meso_ctx *ctx, const double boxlo[3], const double boxhi[3], const int periodicity[3]);
-/* one rank per GPU on a brick procgrid; uid = 128-byte ncclUniqueId from rank 0 (RCCL transport only) */
+/* one rank per GPU on a brick procgrid; must precede meso_atoms_upload.  uid = 128-byte ncclUniqueId from rank 0
+ * (RCCL), or an 8-byte group id shared by the ranks of one process (LOCAL: several contexts, one host thread each) */
 int meso_comm_init(meso_ctx *ctx, int nranks, int rank, const int procgrid[3], int transport, const void *uid,
                    size_t uid_bytes);
 int meso_comm_get_unique_id(void *uid, size_t uid_bytes);
+/* brick processor grid of minimal surface for the box (Comm::set_procs, src/comm.cpp); host only, no GPU needed */
+int meso_decomp_procgrid(int nranks, const double prd[3], int procgrid[3]);
 /* host-staged transport (tests: several ranks sharing one GPU): exchange(user, npeer, peer[], sendbuf[],
  * sendbytes[], recvbuf[], recvbytes[]) must deliver every buffer; all pointers are host memory */
 typedef int (*meso_host_exchange_fn)(void *user, int npeer, const int *peer, const void *const *sendbuf,

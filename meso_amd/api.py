@@ -23,6 +23,26 @@ from . import _lib
 
 PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1}
 RANGES = {"local": 0, "bulk": 1, "border": 2}
+TRANSPORTS = {"self": 0, "rccl": 1, "host": 2, "local": 3}
+
+
+def procgrid(nranks, prd):
+    """Brick processor grid of minimal surface (host-only helper; no GPU needed)."""
+    lib = _lib.load()
+    p = np.ascontiguousarray(prd, np.float64)
+    out = np.zeros(3, np.int32)
+    if lib.meso_decomp_procgrid(int(nranks), _p(p), _p(out)):
+        raise MesoError(lib.meso_last_error().decode())
+    return tuple(int(v) for v in out)
+
+
+def nccl_unique_id():
+    """128-byte RCCL unique id (call on rank 0, broadcast to the other ranks)."""
+    lib = _lib.load()
+    buf = np.zeros(128, np.uint8)
+    if lib.meso_comm_get_unique_id(_p(buf), 128):
+        raise MesoError(lib.meso_last_error().decode())
+    return buf
 
 
 class MesoError(RuntimeError):
@@ -69,6 +89,13 @@ class Meso:
     def set_option(self, key, value):
         self._ck(self.lib.meso_set_option(self._h, key.encode(), float(value)))
 
+    # -- decomposition (one rank per GPU; call before read_atoms) ------------------------------
+    def comm_init(self, nranks, rank, grid, transport="rccl", uid=None):
+        g = np.ascontiguousarray(grid, np.int32)
+        u = None if uid is None else np.ascontiguousarray(uid, np.uint8)
+        self._ck(self.lib.meso_comm_init(self._h, nranks, rank, _p(g), TRANSPORTS[transport], _p(u),
+                                         0 if u is None else len(u)))
+
     # -- read_data / create atoms -----------------------------------------------------------
     def read_atoms(self, x, v, box_lo, box_hi, types=None, tags=None, masses=None, ntypes=None,
                    periodicity=(1, 1, 1)):
@@ -85,7 +112,7 @@ class Meso:
         self._ck(self.lib.meso_set_box(self._h, _p(lo), _p(hi), _p(per)))
         self._ck(self.lib.meso_set_mass(self._h, ntypes, _p(masses)))
         self._ck(self.lib.meso_atoms_upload(self._h, n, _p(x), _p(v), _p(tags), _p(types), None, None))
-        self.natoms = n
+        self.natoms = n   # atoms in the deck; with several ranks each keeps only its sub-box (see counts())
         self._setup_done = False
 
     # -- neighbor / neigh_modify ------------------------------------------------------------

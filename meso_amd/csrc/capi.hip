@@ -89,6 +89,13 @@ int meso_comm_get_unique_id(void *uid, size_t uid_bytes)
     return meso::comm_unique_id(uid, uid_bytes) ? set_err(MESO_ERR_COMM, "ncclGetUniqueId failed") : MESO_OK;
 }
 
+int meso_decomp_procgrid(int nranks, const double prd[3], int procgrid[3])
+{
+    if (nranks < 1 || !prd || !procgrid) return set_err(MESO_ERR_ARG, "invalid procgrid arguments");
+    meso::decomp_procgrid(nranks, prd, procgrid);
+    return MESO_OK;
+}
+
 int meso_comm_set_host_exchange(meso_ctx *ctx, meso_host_exchange_fn fn, void *user)
 {
     CTX(ctx);

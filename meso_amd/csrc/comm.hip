@@ -1,0 +1,690 @@
+// Spatial decomposition over several ranks (one rank per GPU): migration, ghost creation and the per-step
+// ghost refresh.  Replaces MesoComm::exchange / borders (/root/reference/src/USER-MESO/comm_meso.cu:256-550, 41-186)
+// and Comm::forward_comm (/root/reference/src/comm.cpp), which stage everything through pinned host arrays and
+// six serialized MPI_Sendrecv swaps.  Here each rank packs on the device straight from the SoA arrays and talks
+// to its (up to 26) brick neighbours directly: one message per peer per phase, all peers in one grouped RCCL
+// call over xGMI.  The per-step payload is the merged float4 pair already in the receiver's frame (32 B/ghost;
+// the reference sends 48 B of fp64 x,v and re-merges on the receiver).
+//
+// Transports: RCCL (ncclSend/ncclRecv grouped), LOCAL (several ranks inside one process, device-to-device
+// copies: how the multi-rank path is exercised on a single GPU), HOST (caller-supplied exchange on host buffers).
+#include "engine.h"
+#include "meso_device.h"
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace meso {
+
+#define HIPCHK(call)                                                      \
+    do {                                                                  \
+        int _rc = check((call), #call);                                   \
+        if (_rc) return _rc;                                              \
+    } while (0)
+#define TRY(call)                                                         \
+    do {                                                                  \
+        int _rc = (call);                                                 \
+        if (_rc) return _rc;                                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// in-process transport: ranks are Engine objects driven by different host threads
+// ------------------------------------------------------------------------------------------------
+struct LocalPost {
+    int npeer = 0;
+    const int *peer = nullptr;
+    void *const *sbuf = nullptr;
+    const size_t *sbytes = nullptr;
+    double value = 0.0;
+};
+
+struct LocalGroup {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 0, arrived = 0;
+    long gen = 0;
+    std::vector<LocalPost> post;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        long g = gen;
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+static std::mutex g_groups_mutex;
+static std::map<long, LocalGroup *> g_groups;
+
+static LocalGroup *local_group(long id, int n)
+{
+    std::lock_guard<std::mutex> lk(g_groups_mutex);
+    LocalGroup *&g = g_groups[id];
+    if (!g) { g = new LocalGroup; g->n = n; g->post.resize(n); }
+    return g;
+}
+
+int comm_unique_id(void *uid, size_t bytes)
+{
+    if (bytes < sizeof(ncclUniqueId)) return 1;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
+    memcpy(uid, &id, sizeof id);
+    return 0;
+}
+
+// brick procgrid with minimal surface for the given box (what Comm::set_procs / procmap.cpp picks)
+void decomp_procgrid(int nranks, const double *prd, int *pg)
+{
+    double best = 1e300;
+    pg[0] = nranks; pg[1] = 1; pg[2] = 1;
+    for (int a = 1; a <= nranks; a++) {
+        if (nranks % a) continue;
+        for (int b = 1; b <= nranks / a; b++) {
+            if ((nranks / a) % b) continue;
+            int c = nranks / a / b;
+            double surf = prd[0] * prd[1] / (a * b) + prd[0] * prd[2] / (a * c) + prd[1] * prd[2] / (b * c);
+            if (surf < best - 1e-12) { best = surf; pg[0] = a; pg[1] = b; pg[2] = c; }
+        }
+    }
+}
+
+int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *uid, size_t uid_bytes)
+{
+    if (nr < 1 || rk < 0 || rk >= nr) return fail(1, "Invalid rank layout");
+    if (pg[0] < 1 || pg[1] < 1 || pg[2] < 1 || pg[0] * pg[1] * pg[2] != nr) return fail(1, "Bad grid of processors");
+    if (nlocal > 0) return fail(3, "comm_init must precede atom creation");
+    nranks = nr; rank = rk; transport = nr == 1 ? 0 : tr;
+    for (int d = 0; d < 3; d++) procgrid[d] = pg[d];
+    myloc[0] = rk % pg[0]; myloc[1] = (rk / pg[0]) % pg[1]; myloc[2] = rk / (pg[0] * pg[1]);
+    params_ready = false;
+    if (nr == 1) return 0;
+    if (transport == 1) {
+        if (!uid || uid_bytes < sizeof(ncclUniqueId)) return fail(1, "RCCL transport needs the 128-byte unique id of rank 0");
+        ncclUniqueId id;
+        memcpy(&id, uid, sizeof id);
+        HIPCHK(hipSetDevice(device));
+        ncclComm_t c;
+        if (ncclCommInitRank(&c, nr, id, rk) != ncclSuccess) return fail(5, "ncclCommInitRank failed");
+        nccl = (ncclComm *)c;
+    } else if (transport == 3) {
+        long gid = 0;
+        if (uid && uid_bytes >= sizeof(long)) memcpy(&gid, uid, sizeof(long));
+        local = local_group(gid, nr);
+    } else if (transport == 2) {
+        if (!host_exchange) return fail(3, "HOST transport needs meso_comm_set_host_exchange first");
+    } else {
+        return fail(1, "Unknown transport");
+    }
+    return 0;
+}
+
+void Engine::comm_free()
+{
+    if (nccl) ncclCommDestroy((ncclComm_t)nccl);
+    nccl = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exchange primitive: device buffers, one message per peer each way
+// ------------------------------------------------------------------------------------------------
+int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf,
+                 const size_t *rbytes)
+{
+    if (transport == 1) {
+        ncclComm_t c = (ncclComm_t)nccl;
+        bool any = false;
+        for (int k = 0; k < np; k++) {
+            if (peer[k] == rank) {
+                if (rbytes[k]) HIPCHK(hipMemcpyAsync(rbuf[k], sbuf[k], rbytes[k], hipMemcpyDeviceToDevice, stream));
+            } else if (sbytes[k] || rbytes[k]) any = true;
+        }
+        if (any) {
+            if (ncclGroupStart() != ncclSuccess) return fail(5, "ncclGroupStart failed");
+            for (int k = 0; k < np; k++) {
+                if (peer[k] == rank) continue;
+                if (sbytes[k] && ncclSend(sbuf[k], sbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclSend failed");
+                if (rbytes[k] && ncclRecv(rbuf[k], rbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclRecv failed");
+            }
+            if (ncclGroupEnd() != ncclSuccess) return fail(5, "ncclGroupEnd failed");
+        }
+        return 0;
+    }
+    if (transport == 3) {
+        HIPCHK(hipStreamSynchronize(stream));
+        LocalPost &me = local->post[rank];
+        me.npeer = np; me.peer = peer; me.sbuf = sbuf; me.sbytes = sbytes;
+        local->barrier();
+        for (int k = 0; k < np; k++) {
+            if (!rbytes[k]) continue;
+            const LocalPost &src = local->post[peer[k]];
+            const void *from = nullptr;
+            for (int q = 0; q < src.npeer; q++)
+                if (src.peer[q] == rank) { from = src.sbuf[q]; if (src.sbytes[q] != rbytes[k]) return fail(5, "local transport: size mismatch"); }
+            if (!from) return fail(5, "local transport: peer did not post a message");
+            HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k], hipMemcpyDeviceToDevice, stream));
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        local->barrier();
+        return 0;
+    }
+    if (transport == 2) {
+        std::vector<std::vector<char>> hs(np), hr(np);
+        std::vector<const void *> sp(np);
+        std::vector<void *> rp(np);
+        for (int k = 0; k < np; k++) {
+            hs[k].resize(sbytes[k]); hr[k].resize(rbytes[k]);
+            if (sbytes[k]) HIPCHK(hipMemcpyAsync(hs[k].data(), sbuf[k], sbytes[k], hipMemcpyDeviceToHost, stream));
+            sp[k] = hs[k].data(); rp[k] = hr[k].data();
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        if (host_exchange(host_exchange_user, np, peer, sp.data(), sbytes, rp.data(), rbytes)) return fail(5, "host exchange failed");
+        for (int k = 0; k < np; k++)
+            if (rbytes[k]) HIPCHK(hipMemcpyAsync(rbuf[k], hr[k].data(), rbytes[k], hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    return fail(5, "exchange without a transport");
+}
+
+double Engine::reduce_global_sum(double v)
+{
+    if (nranks == 1) return v;
+    if (transport == 3) {
+        local->post[rank].value = v;
+        local->barrier();
+        double s = 0.0;
+        for (int r = 0; r < nranks; r++) s += local->post[r].value;
+        local->barrier();
+        return s;
+    }
+    // RCCL / HOST: all-gather through the pairwise exchange on a small device buffer (thermo steps only)
+    std::vector<int> pr;
+    for (int r = 0; r < nranks; r++) if (r != rank) pr.push_back(r);
+    int np = (int)pr.size();
+    double *d = d_scalar + 2;   // [2] mine, [3..] theirs
+    if (np + 3 > 16) {
+        // d_scalar holds 16 doubles: fall back to a ring of single exchanges for big groups
+        double s = v;
+        for (int r : pr) {
+            (void)hipMemcpyAsync(d, &v, sizeof(double), hipMemcpyHostToDevice, stream);
+            void *sb = d, *rb = d + 1;
+            size_t nb = sizeof(double);
+            int p = r;
+            if (xchg(1, &p, &sb, &nb, &rb, &nb)) return s;
+            double t = 0.0;
+            (void)hipMemcpyAsync(&t, d + 1, sizeof(double), hipMemcpyDeviceToHost, stream);
+            (void)hipStreamSynchronize(stream);
+            s += t;
+        }
+        return s;
+    }
+    (void)hipMemcpyAsync(d, &v, sizeof(double), hipMemcpyHostToDevice, stream);
+    std::vector<void *> sb(np, d), rb(np);
+    std::vector<size_t> nb(np, sizeof(double));
+    for (int k = 0; k < np; k++) rb[k] = d + 1 + k;
+    if (xchg(np, pr.data(), sb.data(), nb.data(), rb.data(), nb.data())) return v;
+    std::vector<double> h(np);
+    (void)hipMemcpyAsync(h.data(), d + 1, np * sizeof(double), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    double s = v;
+    for (double t : h) s += t;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct Decomp {
+    double boxlo[3], boxhi[3], prd[3];
+    int pg[3], myloc[3];
+};
+
+__host__ __device__ inline double sub_bound(const Decomp &D, int d, int l)
+{
+    return l >= D.pg[d] ? D.boxhi[d] : D.boxlo[d] + D.prd[d] * l / D.pg[d];
+}
+
+// owner location in dim d of a coordinate inside [boxlo, boxhi)
+__host__ __device__ inline int owner_loc(const Decomp &D, int d, double x)
+{
+    int o = (int)((x - D.boxlo[d]) / D.prd[d] * D.pg[d]);
+    o = o < 0 ? 0 : (o > D.pg[d] - 1 ? D.pg[d] - 1 : o);
+    while (o > 0 && x < sub_bound(D, d, o)) o--;
+    while (o < D.pg[d] - 1 && x >= sub_bound(D, d, o + 1)) o++;
+    return o;
+}
+
+// direction code (0..26, 13 = stays) of the rank that owns each atom after the PBC wrap
+__global__ void __launch_bounds__(256) k_migrate_code(const double *__restrict__ x, const double *__restrict__ y,
+                                                      const double *__restrict__ z, Decomp D, int n,
+                                                      int *__restrict__ code, int *__restrict__ lost)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double c[3] = {x[i], y[i], z[i]};
+    int s[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        int o = owner_loc(D, d, c[d]);
+        int t = o - D.myloc[d];
+        if (t > 1) t -= D.pg[d];
+        if (t < -1) t += D.pg[d];
+        if (t > 1 || t < -1) { atomicAdd(lost, 1); t = 0; }
+        s[d] = t;
+    }
+    code[i] = (s[0] + 1) + 3 * (s[1] + 1) + 9 * (s[2] + 1);
+}
+
+// 8 doubles per migrant: x,y,z,vx,vy,vz,(tag,type),(mask,image)
+__global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
+                                                      const int *__restrict__ dir_dst, int n0, int n, double *__restrict__ buf)
+{
+    // entries [n0, n0+n) of the direction-major list, skipping the stay segment handled by the caller
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    int k = n0 + q;
+    int d = 0;
+    for (int t = 1; t < 27; t++) d += (k >= dir_start[t]) ? 1 : 0;
+    int dst = dir_dst[d] + (k - dir_start[d]);
+    int j = list[k];
+    double *o = buf + 8 * (size_t)dst;
+    o[0] = a.x[0][j]; o[1] = a.x[1][j]; o[2] = a.x[2][j];
+    o[3] = a.v[0][j]; o[4] = a.v[1][j]; o[5] = a.v[2][j];
+    int2 p = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], a.image[j]);
+    o[6] = *reinterpret_cast<double *>(&p);
+    o[7] = *reinterpret_cast<double *>(&r);
+}
+
+__global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double *__restrict__ buf, const double *__restrict__ mass_type,
+                                                        int base, int n)
+{
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const double *o = buf + 8 * (size_t)q;
+    int i = base + q;
+    a.x[0][i] = o[0]; a.x[1][i] = o[1]; a.x[2][i] = o[2];
+    a.v[0][i] = o[3]; a.v[1][i] = o[4]; a.v[2][i] = o[5];
+    a.f[0][i] = 0.0; a.f[1][i] = 0.0; a.f[2][i] = 0.0;
+    double t6 = o[6], t7 = o[7];
+    int2 p = *reinterpret_cast<int2 *>(&t6), r = *reinterpret_cast<int2 *>(&t7);
+    a.tag[i] = p.x; a.type[i] = p.y; a.mask[i] = r.x; a.image[i] = r.y;
+    a.mass[i] = mass_type[p.y];
+}
+
+struct DirTab {
+    int start[28];   // segment of each direction in the direction-major send list
+    int dst[27];     // first slot of the direction's segment in the peer-major staging
+    int vofs[27];    // (forward) distance from the coordinate block to the velocity block of that peer
+    double shift[27][3];
+    double center[27][3];
+};
+
+__device__ inline int dir_of(const DirTab &T, int k)
+{
+    int d = 0;
+#pragma unroll
+    for (int t = 1; t < 27; t++) d += (k >= T.start[t]) ? 1 : 0;
+    return d;
+}
+
+// 5 doubles per new ghost: x,y,z (shift applied), (tag,type), (mask,0)  [pack_border_vel without the velocities:
+// they follow with the first forward refresh]
+__global__ void __launch_bounds__(256) k_pack_border_multi(AtomSoA a, const int *__restrict__ list, int n, DirTab T,
+                                                           double *__restrict__ buf)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int d = dir_of(T, k), j = list[k];
+    double *o = buf + 5 * (size_t)(T.dst[d] + (k - T.start[d]));
+    o[0] = a.x[0][j] + T.shift[d][0];
+    o[1] = a.x[1][j] + T.shift[d][1];
+    o[2] = a.x[2][j] + T.shift[d][2];
+    int2 p = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], 0);
+    o[3] = *reinterpret_cast<double *>(&p);
+    o[4] = *reinterpret_cast<double *>(&r);
+}
+
+__global__ void __launch_bounds__(256) k_unpack_border(AtomSoA a, const double *__restrict__ buf, int base, int n)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const double *o = buf + 5 * (size_t)g;
+    int i = base + g;
+    a.x[0][i] = o[0]; a.x[1][i] = o[1]; a.x[2][i] = o[2];
+    double t3 = o[3], t4 = o[4];
+    int2 p = *reinterpret_cast<int2 *>(&t3), r = *reinterpret_cast<int2 *>(&t4);
+    a.tag[i] = p.x; a.type[i] = p.y; a.mask[i] = r.x;
+}
+
+// per-step payload into the peer-major staging: [coords of peer p][velocities of peer p] ...
+__global__ void __launch_bounds__(256) k_pack_forward_multi(AtomSoA a, const int *__restrict__ list, int n, DirTab T,
+                                                            u32 seed, float4 *__restrict__ stage)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int d = dir_of(T, k), j = list[k];
+    int slot = T.dst[d] + (k - T.start[d]);
+    float4 c;
+    c.x = (float)((a.x[0][j] + T.shift[d][0]) - T.center[d][0]);
+    c.y = (float)((a.x[1][j] + T.shift[d][1]) - T.center[d][1]);
+    c.z = (float)((a.x[2][j] + T.shift[d][2]) - T.center[d][2]);
+    c.w = __uint_as_float((u32)(a.type[j] - 1));
+    stage[slot] = c;
+    float4 v;
+    v.x = (float)a.v[0][j]; v.y = (float)a.v[1][j]; v.z = (float)a.v[2][j];
+    v.w = __uint_as_float(signature(seed, a.tag[j], v.x, v.y, v.z));
+    stage[slot + T.vofs[d]] = v;
+}
+
+struct PeerTab {
+    int np;
+    int gbase[28];   // first ghost (arrival order) of each peer, gbase[np] = nghost
+};
+
+__global__ void __launch_bounds__(256) k_scatter_ghost(const float4 *__restrict__ stage, PeerTab P, const int *__restrict__ gslot,
+                                                       int nghost, float4 *__restrict__ coord4, float4 *__restrict__ veloc4)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nghost) return;
+    int p = 0;
+    for (int t = 1; t < P.np; t++) p += (g >= P.gbase[t]) ? 1 : 0;
+    int n_p = P.gbase[p + 1] - P.gbase[p];
+    int q = g - P.gbase[p];
+    int out = gslot ? gslot[g] : g;
+    coord4[out] = stage[2 * P.gbase[p] + q];
+    veloc4[out] = stage[2 * P.gbase[p] + n_p + q];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static Decomp make_decomp(const double *lo, const double *hi, const double *prd, const int *pg, const int *loc)
+{
+    Decomp D;
+    for (int d = 0; d < 3; d++) { D.boxlo[d] = lo[d]; D.boxhi[d] = hi[d]; D.prd[d] = prd[d]; D.pg[d] = pg[d]; D.myloc[d] = loc[d]; }
+    return D;
+}
+
+bool Engine::owns(const double *x) const
+{
+    Decomp D = make_decomp(boxlo, boxhi, prd, procgrid, myloc);
+    for (int d = 0; d < 3; d++) {
+        double c = x[d];
+        if (periodic[d]) {
+            if (c < boxlo[d]) c += prd[d];
+            if (c >= boxhi[d]) { c -= prd[d]; if (c < boxlo[d]) c = boxlo[d]; }
+        }
+        if (c < boxlo[d] || c >= boxhi[d]) {   // outside a non-periodic box: the edge rank keeps it
+            if ((c < boxlo[d] && myloc[d] != 0) || (c >= boxhi[d] && myloc[d] != procgrid[d] - 1)) return false;
+            continue;
+        }
+        if (owner_loc(D, d, c) != myloc[d]) return false;
+    }
+    return true;
+}
+
+// unique peers of the 26 directions (increasing rank), and each direction's peer index
+void Engine::build_peer_tables()
+{
+    peers.clear();
+    for (int d = 0; d < 27; d++)
+        if (d != 13 && send_active[d]) peers.push_back(peer27[d]);
+    std::sort(peers.begin(), peers.end());
+    peers.erase(std::unique(peers.begin(), peers.end()), peers.end());
+    for (int d = 0; d < 27; d++) {
+        peer_index[d] = -1;
+        if (d == 13 || !send_active[d]) continue;
+        peer_index[d] = (int)(std::lower_bound(peers.begin(), peers.end(), peer27[d]) - peers.begin());
+    }
+}
+
+// counts[d] (my direction-major segments) -> per-peer send counts, exchange, per-peer/per-direction recv counts
+int Engine::exchange_counts(const int *dir_count, std::vector<int> &send_n, std::vector<int> &recv_n,
+                            std::vector<int> &recv_dir /* np*27 */)
+{
+    int np = (int)peers.size();
+    std::vector<int> sendv((size_t)np * 27, 0);
+    send_n.assign(np, 0);
+    for (int d = 0; d < 27; d++) {
+        int p = peer_index[d];
+        if (p < 0) continue;
+        sendv[(size_t)p * 27 + d] = dir_count[d];
+        send_n[p] += dir_count[d];
+    }
+    int *dbuf = sendlist_aux;   // device scratch: 2 * np * 27 ints
+    HIPCHK(hipMemcpyAsync(dbuf, sendv.data(), sendv.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    std::vector<void *> sb(np), rb(np);
+    std::vector<size_t> nb(np, 27 * sizeof(int));
+    for (int p = 0; p < np; p++) { sb[p] = dbuf + (size_t)p * 27; rb[p] = dbuf + (size_t)(np + p) * 27; }
+    TRY(xchg(np, peers.data(), sb.data(), nb.data(), rb.data(), nb.data()));
+    recv_dir.assign((size_t)np * 27, 0);
+    HIPCHK(hipMemcpyAsync(recv_dir.data(), dbuf + (size_t)np * 27, recv_dir.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    recv_n.assign(np, 0);
+    for (int p = 0; p < np; p++)
+        for (int d = 0; d < 27; d++) recv_n[p] += recv_dir[(size_t)p * 27 + d];
+    return 0;
+}
+
+static void fill_dirtab(DirTab &T, const int *dir_start, const std::vector<int> &peers_send_base, const int *peer_index,
+                        const std::vector<int> &send_n, const double *shift27, const double *center27, bool forward)
+{
+    // peer-major staging: for each peer, its directions in increasing order
+    std::vector<int> fill(peers_send_base);
+    for (int d = 0; d < 27; d++) {
+        T.start[d] = dir_start[d];
+        T.dst[d] = 0; T.vofs[d] = 0;
+        for (int k = 0; k < 3; k++) { T.shift[d][k] = shift27[3 * d + k]; T.center[d][k] = center27[3 * d + k]; }
+        int p = peer_index[d];
+        if (p < 0) continue;
+        int cnt = dir_start[d + 1] - dir_start[d];
+        if (forward) {
+            // block of peer p starts at 2*base_p: coords then velocities
+            T.dst[d] = 2 * peers_send_base[p] + (fill[p] - peers_send_base[p]);
+            T.vofs[d] = send_n[p];
+        } else {
+            T.dst[d] = fill[p];
+        }
+        fill[p] += cnt;
+    }
+    T.start[27] = dir_start[27];
+}
+
+// MesoComm::exchange (comm_meso.cu:256-550): atoms that left my sub-box move to the neighbour that owns them
+int Engine::migrate()
+{
+    if (nranks == 1) return 0;
+    tbegin("migrate");
+    Decomp D = make_decomp(boxlo, boxhi, prd, procgrid, myloc);
+    int *code = gslot;   // scratch (rebuilt later in the rebuild)
+    HIPCHK(hipMemsetAsync(d_flags + 3, 0, sizeof(int), stream));
+    int nchunk = (nlocal + 255) / 256;
+    if (nlocal > 0) {
+        hipLaunchKernelGGL(k_migrate_code, dim3(nchunk), dim3(256), 0, stream, cur.x[0], cur.x[1], cur.x[2], D, nlocal, code,
+                           d_flags + 3);
+        launch_border_count_code(code, 0, nlocal, chunk_count, nchunk, stream);
+        HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+        for (int dir = 0; dir <= 27; dir++)
+            HIPCHK(hipMemcpyAsync(d_dir_start + dir, chunk_offset + (size_t)dir * nchunk, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        launch_border_fill_code(code, 0, nlocal, chunk_offset, nchunk, sendlist, stream);
+    } else {
+        HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
+    }
+    HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_flags + 3, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (h_flags[3]) return fail(5, "Atoms moved further than one sub-domain between rebuilds (lost atoms)");
+    int ds[28], cnt[27];
+    for (int k = 0; k < 28; k++) ds[k] = h_flags[16 + k];
+    for (int d = 0; d < 27; d++) cnt[d] = ds[d + 1] - ds[d];
+    int nstay = cnt[13];
+    int cnt_send[27];
+    for (int d = 0; d < 27; d++) cnt_send[d] = (d == 13) ? 0 : cnt[d];
+    for (int d = 0; d < 27; d++)
+        if (d != 13 && cnt[d] && peer_index[d] < 0) return fail(5, "Atom left the box through a non-periodic boundary");
+    std::vector<int> send_n, recv_n, recv_dir;
+    TRY(exchange_counts(cnt_send, send_n, recv_n, recv_dir));
+    int np = (int)peers.size(), nsend_tot = 0, nrecv_tot = 0;
+    std::vector<int> sbase(np, 0), rbase(np, 0);
+    for (int p = 0; p < np; p++) { sbase[p] = nsend_tot; nsend_tot += send_n[p]; rbase[p] = nrecv_tot; nrecv_tot += recv_n[p]; }
+    TRY(ensure_stage((size_t)std::max(nsend_tot, 1) * 8 * sizeof(double), (size_t)std::max(nrecv_tot, 1) * 8 * sizeof(double)));
+    if (nsend_tot > 0) {
+        // destination slot of each direction's segment in the peer-major buffer
+        std::vector<int> fill(sbase);
+        int h_dst[27];
+        for (int d = 0; d < 27; d++) {
+            h_dst[d] = 0;
+            int p = peer_index[d];
+            if (d == 13 || p < 0) continue;
+            h_dst[d] = fill[p];
+            fill[p] += cnt[d];
+        }
+        HIPCHK(hipMemcpyAsync(sendlist_aux, h_dst, 27 * sizeof(int), hipMemcpyHostToDevice, stream));
+        // segments before and after the stay segment
+        if (ds[13] > 0)
+            hipLaunchKernelGGL(k_pack_migrate, dim3((ds[13] + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start,
+                               sendlist_aux, 0, ds[13], (double *)stage_send);
+        int tail = ds[27] - ds[14];
+        if (tail > 0)
+            hipLaunchKernelGGL(k_pack_migrate, dim3((tail + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start,
+                               sendlist_aux, ds[14], tail, (double *)stage_send);
+    }
+    // compact the stayers (their order is preserved; the reorder sort follows anyway)
+    if (nstay != nlocal) {
+        launch_permute_atoms(cur, alt, sendlist + ds[13], nstay, stream);
+        std::swap(cur, alt);
+    }
+    TRY(ensure_capacity(nstay + nrecv_tot + 1));
+    std::vector<void *> sb(np), rb(np);
+    std::vector<size_t> sn(np), rn(np);
+    for (int p = 0; p < np; p++) {
+        sb[p] = (double *)stage_send + 8 * (size_t)sbase[p]; sn[p] = (size_t)send_n[p] * 8 * sizeof(double);
+        rb[p] = (double *)stage_recv + 8 * (size_t)rbase[p]; rn[p] = (size_t)recv_n[p] * 8 * sizeof(double);
+    }
+    TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
+    if (nrecv_tot > 0)
+        hipLaunchKernelGGL(k_unpack_migrate, dim3((nrecv_tot + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
+                           d_mass_type, nstay, nrecv_tot);
+    nlocal = nstay + nrecv_tot;
+    tend("migrate");
+    return 0;
+}
+
+// MesoComm::borders (comm_meso.cu:41-186) for nranks > 1
+int Engine::halo_borders_multi()
+{
+    tbegin("halo");
+    int beg = n_bulk, end = nlocal;
+    int nchunk = (end - beg + 255) / 256;
+    for (int k = 0; k < 28; k++) h_dir_start[k] = 0;
+    if (nchunk > 0) {
+        launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
+        HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+        for (int dir = 0; dir <= 27; dir++)
+            HIPCHK(hipMemcpyAsync(d_dir_start + dir, chunk_offset + (size_t)dir * nchunk, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];
+    } else {
+        HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
+    }
+    nsend = h_dir_start[27];
+    int cnt[27];
+    for (int d = 0; d < 27; d++) {
+        cnt[d] = h_dir_start[d + 1] - h_dir_start[d];
+        if (cnt[d] && peer_index[d] < 0) return fail(5, "border list for an inactive direction");
+    }
+    std::vector<int> recv_dir;
+    TRY(exchange_counts(cnt, peer_send_n, peer_recv_n, recv_dir));
+    int np = (int)peers.size();
+    peer_send_base.assign(np, 0); peer_recv_base.assign(np + 1, 0);
+    int stot = 0, rtot = 0;
+    for (int p = 0; p < np; p++) { peer_send_base[p] = stot; stot += peer_send_n[p]; peer_recv_base[p] = rtot; rtot += peer_recv_n[p]; }
+    peer_recv_base[np] = rtot;
+    nghost = rtot;
+    TRY(ensure_capacity(nlocal + nghost + 1));
+    if (nsend > send_cap) return fail(4, "send list capacity exceeded");
+    TRY(ensure_stage((size_t)std::max(std::max(stot, 1) * 5 * sizeof(double), (size_t)std::max(stot, 1) * 2 * sizeof(float4)),
+                     (size_t)std::max(std::max(rtot, 1) * 5 * sizeof(double), (size_t)std::max(rtot, 1) * 2 * sizeof(float4))));
+    if (nsend > 0) launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
+    DirTab T;
+    fill_dirtab(T, h_dir_start, peer_send_base, peer_index, peer_send_n, shift27, center27, false);
+    if (nsend > 0)
+        hipLaunchKernelGGL(k_pack_border_multi, dim3((nsend + 255) / 256), dim3(256), 0, stream, cur, sendlist, nsend, T,
+                           (double *)stage_send);
+    std::vector<void *> sb(np), rb(np);
+    std::vector<size_t> sn(np), rn(np);
+    for (int p = 0; p < np; p++) {
+        sb[p] = (double *)stage_send + 5 * (size_t)peer_send_base[p]; sn[p] = (size_t)peer_send_n[p] * 5 * sizeof(double);
+        rb[p] = (double *)stage_recv + 5 * (size_t)peer_recv_base[p]; rn[p] = (size_t)peer_recv_n[p] * 5 * sizeof(double);
+    }
+    TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
+    if (nghost > 0)
+        hipLaunchKernelGGL(k_unpack_border, dim3((nghost + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
+                           nlocal, nghost);
+    // tables of the per-step refresh
+    fill_dirtab(fwd_tab_host(), h_dir_start, peer_send_base, peer_index, peer_send_n, shift27, center27, true);
+    tend("halo");
+    return 0;
+}
+
+DirTab &Engine::fwd_tab_host()
+{
+    if (!fwd_tab) fwd_tab = new DirTab;
+    return *fwd_tab;
+}
+
+void Engine::free_fwd_tab()
+{
+    delete fwd_tab;
+    fwd_tab = nullptr;
+}
+
+// Comm::forward_comm for nranks > 1.  Split in two so the engine can run the bulk force kernel between them.
+int Engine::halo_forward_multi_begin(uint32_t sd)
+{
+    tbegin("halo");
+    int np = (int)peers.size();
+    if (nsend > 0)
+        hipLaunchKernelGGL(k_pack_forward_multi, dim3((nsend + 255) / 256), dim3(256), 0, stream, cur, sendlist, nsend,
+                           fwd_tab_host(), sd, (float4 *)stage_send);
+    std::vector<void *> sb(np), rb(np);
+    std::vector<size_t> sn(np), rn(np);
+    for (int p = 0; p < np; p++) {
+        sb[p] = (float4 *)stage_send + 2 * (size_t)peer_send_base[p]; sn[p] = (size_t)peer_send_n[p] * 2 * sizeof(float4);
+        rb[p] = (float4 *)stage_recv + 2 * (size_t)peer_recv_base[p]; rn[p] = (size_t)peer_recv_n[p] * 2 * sizeof(float4);
+    }
+    TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
+    if (nghost > 0) {
+        PeerTab P;
+        P.np = np;
+        for (int p = 0; p <= np; p++) P.gbase[p] = peer_recv_base[p];
+        hipLaunchKernelGGL(k_scatter_ghost, dim3((nghost + 255) / 256), dim3(256), 0, stream, (const float4 *)stage_recv, P,
+                           layout >= 1 ? gslot : nullptr, nghost, coord4 + nlocal, veloc4 + nlocal);
+    }
+    tend("halo");
+    return 0;
+}
+
+int Engine::ensure_stage(size_t sbytes, size_t rbytes)
+{
+    if (sbytes > stage_send_bytes) {
+        if (stage_send) (void)hipFree(stage_send);
+        stage_send = nullptr;
+        stage_send_bytes = sbytes + sbytes / 4 + 4096;
+        HIPCHK(hipMalloc(&stage_send, stage_send_bytes));
+    }
+    if (rbytes > stage_recv_bytes) {
+        if (stage_recv) (void)hipFree(stage_recv);
+        stage_recv = nullptr;
+        stage_recv_bytes = rbytes + rbytes / 4 + 4096;
+        HIPCHK(hipMalloc(&stage_recv, stage_recv_bytes));
+    }
+    if (!sendlist_aux) HIPCHK(hipMalloc((void **)&sendlist_aux, 2 * 27 * 27 * sizeof(int) + 64));
+    return 0;
+}
+
+} // namespace meso

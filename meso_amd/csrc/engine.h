@@ -14,6 +14,9 @@ struct ncclComm;
 
 namespace meso {
 
+struct DirTab;
+struct LocalGroup;
+
 struct PhaseTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0.0;
@@ -89,6 +92,17 @@ private:
     int migrate();
     int check_overflow();
     double reduce_global_sum(double v);
+    // multi-rank (comm.hip)
+    int xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf, const size_t *rbytes);
+    int exchange_counts(const int *dir_count, std::vector<int> &send_n, std::vector<int> &recv_n, std::vector<int> &recv_dir);
+    void build_peer_tables();
+    int halo_borders_multi();
+    int halo_forward_multi_begin(uint32_t seed);
+    int ensure_stage(size_t sbytes, size_t rbytes);
+    bool owns(const double *x) const;
+    void comm_free();
+    DirTab &fwd_tab_host();
+    void free_fwd_tab();
     void tbegin(const char *name);
     void tend(const char *name);
     void tflush();
@@ -106,6 +120,13 @@ private:
     int nranks = 1, rank = 0, procgrid[3] = {1, 1, 1}, myloc[3] = {0, 0, 0};
     int transport = 0;
     ncclComm *nccl = nullptr;
+    LocalGroup *local = nullptr;
+    std::vector<int> peers, peer_send_n, peer_recv_n, peer_send_base, peer_recv_base;
+    int peer_index[27];
+    void *stage_send = nullptr, *stage_recv = nullptr;
+    size_t stage_send_bytes = 0, stage_recv_bytes = 0;
+    int *sendlist_aux = nullptr;
+    DirTab *fwd_tab = nullptr;
     double sublo[3], subhi[3];
     double slab_lo[3], slab_hi[3];
     double shift27[81], center27[81];
@@ -185,6 +206,7 @@ private:
 };
 
 int comm_unique_id(void *uid, size_t uid_bytes);
+void decomp_procgrid(int nranks, const double *prd, int *pg);
 int script_run(Engine &E, const char *path, const char *var_name, const char *var_value, std::string &out);
 
 } // namespace meso

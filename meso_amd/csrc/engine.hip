@@ -79,7 +79,12 @@ void Engine::free_all()
     dfree(estart); dfree(gstart); dfree(gslot); dfree(table16);
     dfree(brick_flag); dfree(brick_pos); dfree(brick_active); dfree(binrange);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
-    dfree(d_partial); dfree(d_scalar); dfree(d_flags);
+    dfree(d_partial); dfree(d_scalar); dfree(d_flags); dfree(sendlist_aux);
+    if (stage_send) (void)hipFree(stage_send);
+    if (stage_recv) (void)hipFree(stage_recv);
+    stage_send = stage_recv = nullptr; stage_send_bytes = stage_recv_bytes = 0;
+    free_fwd_tab();
+    comm_free();
     if (h_flags) (void)hipHostFree(h_flags);
     if (h_scalar) (void)hipHostFree(h_scalar);
     h_flags = nullptr; h_scalar = nullptr;
@@ -232,18 +237,6 @@ int Engine::set_option(const std::string &key, double val)
     return fail(1, "Unknown option '" + key + "'");
 }
 
-int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *, size_t)
-{
-    if (nr < 1 || rk < 0 || rk >= nr) return fail(1, "Invalid rank layout");
-    if (pg[0] * pg[1] * pg[2] != nr) return fail(1, "Bad grid of processors");
-    if (nr > 1) return fail(5, "Multi-rank transport not initialised in this build step");
-    nranks = nr; rank = rk; transport = tr;
-    for (int d = 0; d < 3; d++) procgrid[d] = pg[d];
-    myloc[0] = rk % pg[0]; myloc[1] = (rk / pg[0]) % pg[1]; myloc[2] = rk / (pg[0] * pg[1]);
-    params_ready = false;
-    return 0;
-}
-
 // ------------------------------------------------------------------------------------------------
 // memory
 // ------------------------------------------------------------------------------------------------
@@ -275,6 +268,7 @@ int Engine::alloc_atoms(int cap)
         HIPCHK(dalloc(d_scalar, 16));
         HIPCHK(dalloc(d_flags, 16));
         HIPCHK(dalloc(d_dir_start, 32));
+        HIPCHK(dalloc(sendlist_aux, 2 * 27 * 27 + 64));
         HIPCHK(hipHostMalloc((void **)&h_flags, 64 * sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&h_scalar, 16 * sizeof(double)));
         HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), stream));
@@ -346,8 +340,25 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
     for (int d = 0; d < 3; d++) ext *= (prd[d] / procgrid[d] + 2.0 * cg) / (prd[d] / procgrid[d]);
     int cap = (int)(1.25 * n * std::min(ext, 27.0)) + 8192;
     nlocal = 0;
+    // several ranks: every rank is handed the whole deck and keeps the atoms of its own sub-box
+    std::vector<double> fx, fv;
+    std::vector<int> ftag, ftype, fmask, fimage;
+    if (nranks > 1) {
+        for (int i = 0; i < n; i++) {
+            if (!owns(x + 3 * (size_t)i)) continue;
+            for (int d = 0; d < 3; d++) { fx.push_back(x[3 * (size_t)i + d]); fv.push_back(v[3 * (size_t)i + d]); }
+            ftag.push_back(tag[i]); ftype.push_back(type[i]);
+            if (mask) fmask.push_back(mask[i]);
+            if (image) fimage.push_back(image[i]);
+        }
+        n = (int)ftag.size();
+        x = fx.data(); v = fv.data(); tag = ftag.data(); type = ftype.data();
+        if (mask) mask = fmask.data();
+        if (image) image = fimage.data();
+        cap = (int)(1.25 * n * std::min(ext, 27.0)) + 8192;
+    }
     if (cap > nmax) TRY(alloc_atoms(cap));
-    std::vector<double> tmp((size_t)n);
+    std::vector<double> tmp((size_t)std::max(n, 1));
     for (int d = 0; d < 3; d++) {
         for (int i = 0; i < n; i++) tmp[i] = x[3 * (size_t)i + d];
         HIPCHK(hipMemcpy(cur.x[d], tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
@@ -357,7 +368,7 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
     }
     HIPCHK(hipMemcpy(cur.tag, tag, n * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(cur.type, type, n * sizeof(int), hipMemcpyHostToDevice));
-    std::vector<int> itmp((size_t)n, 1);
+    std::vector<int> itmp((size_t)std::max(n, 1), 1);
     HIPCHK(hipMemcpy(cur.mask, mask ? mask : itmp.data(), n * sizeof(int), hipMemcpyHostToDevice));
     // image flags: 10 bits per dimension, 512 = no wrap (LAMMPS' smallint packing)
     std::fill(itmp.begin(), itmp.end(), 512 | (512 << 10) | (512 << 20));
@@ -437,6 +448,7 @@ int Engine::init_params()
         send_active[dir] = active;
         peer27[dir] = loc[0] + procgrid[0] * (loc[1] + procgrid[1] * loc[2]);
     }
+    build_peer_tables();
 
     // bins aligned with the sub-box, one ghost layer each side
     double subvol = 1.0;
@@ -508,9 +520,7 @@ int Engine::init_params()
     return 0;
 }
 
-double Engine::reduce_global_sum(double v) { return v; }   // single rank; RCCL all-reduce when nranks > 1
 
-int comm_unique_id(void *, size_t) { return 1; }
 
 void Engine::range(int r, int &beg, int &end) const
 {
@@ -522,7 +532,6 @@ void Engine::range(int r, int &beg, int &end) const
 // ------------------------------------------------------------------------------------------------
 // rebuild pieces
 // ------------------------------------------------------------------------------------------------
-int Engine::migrate() { return 0; }   // single rank: PBC wrap only
 
 // MesoAtom::sort_local (atom_meso.cu:343-384) + transfer_post_sort, all device resident
 int Engine::reorder_locals()
@@ -547,6 +556,7 @@ int Engine::reorder_locals()
 // MesoComm::borders (comm_meso.cu:41-186) as device list building + device pack
 int Engine::halo_borders()
 {
+    if (nranks > 1) return halo_borders_multi();
     tbegin("halo");
     int beg = n_bulk, end = nlocal;
     int nchunk = (end - beg + 255) / 256;
@@ -588,6 +598,7 @@ int Engine::halo_borders()
 // Comm::forward_comm + gpu_merge_xvt(ghost range): ghosts arrive as merged float4 pairs
 int Engine::halo_forward_seed(uint32_t sd)
 {
+    if (nranks > 1) return halo_forward_multi_begin(sd);
     if (nsend <= 0) return 0;
     tbegin("halo");
     launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,

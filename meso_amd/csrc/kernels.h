@@ -57,6 +57,9 @@ void launch_border_count(const AtomSoA &a, int beg, int end, const double *slab_
 void launch_border_fill(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi,
                         const int *dim_active, const int *chunk_offset /*[27][nchunk] exclusive, global*/,
                         int nchunk, int *sendlist, hipStream_t s);
+void launch_border_count_code(const int *code, int beg, int end, int *chunk_count, int nchunk, hipStream_t s);
+void launch_border_fill_code(const int *code, int beg, int end, const int *chunk_offset, int nchunk, int *list,
+                             hipStream_t s);
 // border payload: fp64 x (+shift), tag, type, mask -> destination arrays (tail of SoA or a send buffer)
 void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start /*dev [28]*/,
                         const double *shift27 /*host [27][3]*/, double *dx, double *dy, double *dz, int *dtag,

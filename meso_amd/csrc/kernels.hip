@@ -415,6 +415,48 @@ __global__ void __launch_bounds__(BORDER_CHUNK) k_border_count(const double *__r
     if (threadIdx.x == 0) chunk_count[13 * nchunk + blockIdx.x] = 0;
 }
 
+// same two-pass compaction keyed by a per-atom direction code (migration: code 13 = the atom stays)
+__global__ void __launch_bounds__(BORDER_CHUNK) k_code_count(const int *__restrict__ code, int beg, int end,
+                                                             int *__restrict__ chunk_count, int nchunk)
+{
+    int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
+    int c0 = i < end ? code[i] : -1;
+    for (int dir = 0; dir < 27; dir++) {
+        int c = __syncthreads_count(c0 == dir);
+        if (threadIdx.x == 0) chunk_count[dir * nchunk + blockIdx.x] = c;
+    }
+}
+
+__global__ void __launch_bounds__(BORDER_CHUNK) k_code_fill(const int *__restrict__ code, int beg, int end,
+                                                            const int *__restrict__ chunk_offset, int nchunk,
+                                                            int *__restrict__ list)
+{
+    __shared__ int wave_tot[BORDER_CHUNK / 64];
+    int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int c0 = i < end ? code[i] : -1;
+    for (int dir = 0; dir < 27; dir++) {
+        bool hit = c0 == dir;
+        u64 m = __ballot(hit);
+        int pre = __popcll(m & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int base = chunk_offset[dir * nchunk + blockIdx.x];
+        for (int k = 0; k < w; k++) base += wave_tot[k];
+        if (hit) list[base + pre] = i;
+        __syncthreads();
+    }
+}
+
+void launch_border_count_code(const int *code, int beg, int end, int *chunk_count, int nchunk, hipStream_t s)
+{
+    if (nchunk > 0) hipLaunchKernelGGL(k_code_count, dim3(nchunk), dim3(BORDER_CHUNK), 0, s, code, beg, end, chunk_count, nchunk);
+}
+void launch_border_fill_code(const int *code, int beg, int end, const int *chunk_offset, int nchunk, int *list, hipStream_t s)
+{
+    if (nchunk > 0) hipLaunchKernelGGL(k_code_fill, dim3(nchunk), dim3(BORDER_CHUNK), 0, s, code, beg, end, chunk_offset, nchunk, list);
+}
+
 void launch_border_count(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi, const int *,
                          int *chunk_count, int nchunk, hipStream_t s)
 {

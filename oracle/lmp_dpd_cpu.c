@@ -176,6 +176,7 @@ typedef struct {
     long ntimestep;
     int nthreads;
     double (*tf)[3]; /* per-thread force scratch, nthreads * nmax */
+    int *twin;       /* per-thread touched index windows [lo,hi) for owned and ghost partners: 4 ints */
     int nbuild;
     long nextsort;
     int sortfreq;
@@ -244,7 +245,7 @@ void lmp_destroy(LmpSys *s)
     free(s->x); free(s->v); free(s->f); free(s->type); free(s->tag); free(s->bins);
     free(s->mass); free(s->cut); free(s->a0); free(s->gamma); free(s->sigma); free(s->cutsq);
     free(s->cutneighsq); free(s->binhead); free(s->stencil); free(s->numneigh);
-    free(s->firstneigh); free(s->neighpool); free(s->tf); free(s->trandom);
+    free(s->firstneigh); free(s->neighpool); free(s->tf); free(s->trandom); free(s->twin);
     for (int i = 0; i < 6; i++) free(s->sendlist[i]);
     free(s);
 }
@@ -684,26 +685,48 @@ static void force_compute(LmpSys *s, int evflag)
     } else {
 #ifdef _OPENMP
         double eng = 0.0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+        if (!s->twin) s->twin = calloc(4 * (size_t)s->nthreads, sizeof(int));
 #pragma omp parallel num_threads(s->nthreads) reduction(+ : eng, v0, v1, v2, v3, v4, v5)
         {
             int tid = omp_get_thread_num(), nt = omp_get_num_threads();
             double(*tf)[3] = s->tf + (size_t)tid * s->nmax;
-            memset(tf, 0, sizeof(double[3]) * nall);
             int chunk = (s->nlocal + nt - 1) / nt;
             int ibeg = tid * chunk, iend = ibeg + chunk;
             if (iend > s->nlocal) iend = s->nlocal;
             if (ibeg > s->nlocal) ibeg = s->nlocal;
+            /* atoms are spatially sorted (Atom::sort), so the partners of my block live in a narrow index
+             * window plus a slice of the ghosts: only that window of the private array is cleared/reduced
+             * (USER-OMP clears and reduces whole per-thread arrays, which does not scale past a few threads) */
+            int lo = ibeg, hi = iend, glo = nall, ghi = s->nlocal;
+            for (int i = ibeg; i < iend; i++) {
+                const int *jl = s->neighpool + s->firstneigh[i];
+                for (int jj = 0; jj < s->numneigh[i]; jj++) {
+                    int j = jl[jj];
+                    if (j < s->nlocal) { if (j < lo) lo = j; if (j >= hi) hi = j + 1; }
+                    else { if (j < glo) glo = j; if (j >= ghi) ghi = j + 1; }
+                }
+            }
+            if (glo > ghi) glo = ghi;
+            int *w = s->twin + 4 * tid;
+            w[0] = lo; w[1] = hi; w[2] = glo; w[3] = ghi;
+            memset(tf + lo, 0, sizeof(double[3]) * (hi - lo));
+            memset(tf + glo, 0, sizeof(double[3]) * (ghi - glo));
             double e = 0.0, vv[6] = {0, 0, 0, 0, 0, 0};
             pair_compute_range(s, ibeg, iend, tf, &s->trandom[tid], evflag, &e, vv);
             eng += e; v0 += vv[0]; v1 += vv[1]; v2 += vv[2]; v3 += vv[3]; v4 += vv[4]; v5 += vv[5];
 #pragma omp barrier
-            /* reduce per-thread arrays (USER-OMP data_reduce_thr) */
+            /* reduce: each thread sums, for its slice of all atoms, the private windows that cover it */
             int c2 = (nall + nt - 1) / nt, b2 = tid * c2, e2 = b2 + c2;
             if (e2 > nall) e2 = nall;
             for (int t = 0; t < nt; t++) {
                 double(*sf)[3] = s->tf + (size_t)t * s->nmax;
-                for (int i = b2; i < e2; i++) {
-                    s->f[i][0] += sf[i][0]; s->f[i][1] += sf[i][1]; s->f[i][2] += sf[i][2];
+                const int *wt = s->twin + 4 * t;
+                for (int part = 0; part < 2; part++) {
+                    int a = wt[2 * part] > b2 ? wt[2 * part] : b2;
+                    int b = wt[2 * part + 1] < e2 ? wt[2 * part + 1] : e2;
+                    for (int i = a; i < b; i++) {
+                        s->f[i][0] += sf[i][0]; s->f[i][1] += sf[i][1]; s->f[i][2] += sf[i][2];
+                    }
                 }
             }
         }

@@ -1,0 +1,101 @@
+"""Spatial decomposition on ONE GPU: several ranks (one engine context + one host thread each) exchange
+migrants and ghosts through the in-process LOCAL transport, which runs the same device pack / unpack /
+scatter kernels and the same per-peer message schedule as the RCCL transport (only the copy primitive
+differs).  Decomposition invariance is the property the reference's TEA signatures are designed for
+(SURVEY.md 4 vi): forces and trajectories must not depend on the processor grid."""
+import threading
+
+import numpy as np
+import pytest
+
+from meso_amd.datagen import make_box
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(nranks, grid, L, style, sigma, steps, every=5):
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(L)
+    gid = np.frombuffer(np.random.default_rng(nranks * 1000 + L).bytes(8), np.uint8)
+    out, errs = [None] * nranks, []
+
+    def work(r):
+        try:
+            m = Meso()
+            if nranks > 1:
+                m.comm_init(nranks, r, grid, "local", gid)
+            m.read_atoms(x, v, lo, hi)
+            m.neighbor(0.3)
+            m.neigh_modify(delay=0, every=every, check=False)
+            m.pair_style(style, 1.0, 419084618)
+            m.pair_coeff(1, 1, 15.0, 4.5, sigma, 1.0, 1.0)
+            m.timestep(0.005)
+            m.setup()
+            f0 = m.gather(by_tag=False)
+            m.run(steps)
+            T = m.temperature()
+            out[r] = (f0, m.gather(by_tag=False), m.counts(), T)
+            m.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank did not finish"
+
+    def merge(idx):
+        cols = [np.concatenate([o[idx][k] for o in out]) for k in range(4)]
+        order = np.argsort(cols[3], kind="stable")
+        return [c[order] for c in cols]
+
+    return merge(0), merge(1), [o[2] for o in out], [o[3] for o in out], (x, v, lo, hi)
+
+
+@pytest.mark.parametrize("nranks,grid", [(2, (2, 1, 1)), (4, (2, 2, 1)), (8, (2, 2, 2)), (3, (1, 3, 1))])
+def test_decomposition_invariance(nranks, grid):
+    L = 12 if nranks != 3 else 13
+    ref0, ref1, _, Tref, (x, v, lo, hi) = _run_ranks(1, (1, 1, 1), L, "dpd/meso", 3.0, 1)
+    got0, got1, counts, T, _ = _run_ranks(nranks, grid, L, "dpd/meso", 3.0, 1)
+    n = len(x)
+    assert sum(c[0] for c in counts) == n                        # every atom owned exactly once
+    assert np.array_equal(got0[3], np.arange(1, n + 1)) and np.array_equal(got1[3], np.arange(1, n + 1))
+    # merged coordinates are recentred on each rank's own sub-box (atom_vec_meso.cu:154-156), so fp32 rounding
+    # differs between processor grids: forces agree to the fp32-coordinate tolerance, not bit for bit
+    scale = np.abs(ref0[2]).max()
+    assert np.abs(got0[2] - ref0[2]).max() < 5e-6 * scale        # setup forces (thermostat on: same TEA numbers)
+    prd = hi - lo
+    d = got1[0] - ref1[0]
+    d -= np.round(d / prd) * prd
+    assert np.abs(d).max() < 1e-7                                # positions after one step: step-0 forces only
+    # the step-1 random forces are keyed on the top 11 mantissa bits of each fp32 velocity (math_meso.h:436-442):
+    # a 1e-8 velocity difference re-keys a few particles (and their partners), everything else is bit-close
+    dv = np.abs(got1[1] - ref1[1]).max(axis=1)
+    assert (dv > 1e-5).mean() < 0.05 and np.median(dv) < 1e-7
+    assert all(abs(t - T[0]) < 1e-12 for t in T) and abs(T[0] - Tref[0]) < 1e-3   # one global value on every rank
+
+
+@pytest.mark.parametrize("style", ["dpd/meso", "dpd/fast/meso"])
+def test_migration_and_rebuilds_conserve_atoms(style):
+    """60 steps on a 2x2x2 grid: atoms cross sub-domain faces, edges and corners; none is lost or duplicated,
+    momentum stays zero and the thermostat holds the same temperature as the single-rank run."""
+    L = 12
+    _, ref1, _, Tref, (x, v, lo, hi) = _run_ranks(1, (1, 1, 1), L, style, 3.0, 60)
+    _, got1, counts, T, _ = _run_ranks(8, (2, 2, 2), L, style, 3.0, 60)
+    n = len(x)
+    assert sum(c[0] for c in counts) == n
+    assert np.array_equal(got1[3], np.arange(1, n + 1))
+    assert len({c[0] for c in counts}) > 1                       # populations drifted: migration really happened
+    assert np.abs(got1[1].sum(0)).max() < 1e-2
+    assert abs(T[0] - Tref[0]) < 0.08 and all(abs(t - T[0]) < 1e-9 for t in T)
+
+
+def test_sigma0_trajectory_is_grid_independent():
+    L = 12
+    _, ref1, _, _, (x, v, lo, hi) = _run_ranks(1, (1, 1, 1), L, "dpd/meso", 0.0, 20)
+    _, got1, _, _, _ = _run_ranks(8, (2, 2, 2), L, "dpd/meso", 0.0, 20)
+    prd = hi - lo
+    d = got1[0] - ref1[0]
+    d -= np.round(d / prd) * prd
+    assert np.abs(d).max() < 2e-6 and np.abs(got1[1] - ref1[1]).max() < 2e-5
