@@ -92,12 +92,6 @@ def main():
     from meso_amd.datagen import make_box
 
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        raise SystemExit("multi-GPU spatial decomposition is not wired into bench.py in this build")
-
     L = a.box
     x, v, lo, hi = make_box(L)
     n = len(x)
@@ -105,6 +99,21 @@ def main():
     for kv in a.opt:
         k, val = kv.split("=")
         m.set_option(k, float(val))
+    grid = (1, 1, 1)
+    if world > 1:
+        # one process per GPU; torch.distributed (RCCL) is used for the rendezvous of the ncclUniqueId, the
+        # barriers and the max-over-ranks timing; the ghost traffic itself is RCCL send/recv inside the engine
+        import torch.distributed as dist
+        from meso_amd.api import nccl_unique_id, procgrid
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        grid = procgrid(world, hi - lo)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.from_numpy(nccl_unique_id().copy())
+        uid = uid.cuda()
+        dist.broadcast(uid, 0)
+        m.comm_init(world, rank, grid, "rccl", uid.cpu().numpy())
     m.read_atoms(x, v, lo, hi)
     m.neighbor(0.3)
     m.neigh_modify(delay=0, every=a.every, check=False)
@@ -145,7 +154,8 @@ def main():
     m.set_option("profile", 0)
     t_pair = phases["pair"]["ms_per_call"] * 1e-3
     w = 8  # forces are stored as fp64 in both styles
-    b_pair = n * (16 + 16 + 4 + 4.0 * info["avg_count"] + 3 * w)
+    n_rank = m.counts()[0]                                          # atoms this rank's pair kernel covers
+    b_pair = n_rank * (16 + 16 + 4 + 4.0 * info["avg_count"] + 3 * w)
     achieved = b_pair / t_pair / 1e9
     T = m.temperature()
 
@@ -163,7 +173,7 @@ def main():
         "dtype": "f32" if a.style == "dpd/fast/meso" else "f64",
         "data": "synthetic",
         "config": {"workload": "%d^3 box rho=4 (N=%d), pair_style %s, neighbor 0.3 bin, rebuild every %d, dt 0.005, "
-                               "1 MI355X" % (L, n, a.style, a.every),
+                               "%d MI355X, procgrid %dx%dx%d" % ((L, n, a.style, a.every, a.gpus) + tuple(grid)),
                    "M_particle_steps_per_s": steps_per_s * n / 1e6,
                    "avg_neighbors": info["avg_count"], "temperature_end": T},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,195 @@
+/* Implementation of the LAMMPS-side binding declared in meso_hip_glue.h.  Pure host C++ against LAMMPS'
+   own headers; links with -lmeso_hip.  See INTEGRATION.md. */
+
+#include "string.h"
+#include "stdlib.h"
+#include "meso_hip_glue.h"
+#include "atom.h"
+#include "atom_vec.h"
+#include "comm.h"
+#include "domain.h"
+#include "error.h"
+#include "force.h"
+#include "memory.h"
+#include "neighbor.h"
+#include "output.h"
+#include "universe.h"
+#include "update.h"
+
+using namespace LAMMPS_NS;
+
+#define MESO(call) MesoHipContext::check(lmp, (call), FLERR)
+
+static meso_ctx *g_ctx = NULL;
+
+meso_ctx *MesoHipContext::get(LAMMPS *lmp)
+{
+  if (!g_ctx) {
+    /* one GPU per rank on the node, like the -device flag of the reference */
+    int rc = meso_init(-(lmp->universe->me), &g_ctx);
+    check(lmp, rc, FLERR);
+  }
+  return g_ctx;
+}
+
+void MesoHipContext::check(LAMMPS *lmp, int rc, const char *file, int line)
+{
+  if (rc) lmp->error->one(file, line, meso_last_error());
+}
+
+/* ---------------------------------------------------------------------- pair */
+
+MesoHipPairDPD::MesoHipPairDPD(LAMMPS *lmp) : Pair(lmp)
+{
+  split_flag = 1;
+  style_id = MESO_PAIR_DPD;
+  cut = NULL;
+}
+
+MesoHipPairDPDFast::MesoHipPairDPDFast(LAMMPS *lmp) : MesoHipPairDPD(lmp) { style_id = MESO_PAIR_DPD_FAST; }
+
+void MesoHipPairDPD::settings(int narg, char **arg)
+{
+  if (narg != 2) error->all(FLERR, "Illegal pair_style command");
+  cut_global = atof(arg[0]);
+  seed = atoi(arg[1]);
+  MESO(meso_pair_dpd_settings(MesoHipContext::get(lmp), style_id, cut_global, seed));
+}
+
+void MesoHipPairDPD::coeff(int narg, char **arg)
+{
+  if (narg < 6 || narg > 7) error->all(FLERR, "Incorrect args for pair coefficients");
+  int n = atom->ntypes;
+  if (!allocated) {
+    allocated = 1;
+    memory->create(setflag, n + 1, n + 1, "pair:setflag");
+    memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+    memory->create(cut, n + 1, n + 1, "pair:cut");
+    for (int i = 1; i <= n; i++)
+      for (int j = i; j <= n; j++) setflag[i][j] = 0;
+    MESO(meso_set_mass(MesoHipContext::get(lmp), n, atom->mass));
+  }
+  int ilo, ihi, jlo, jhi;
+  force->bounds(arg[0], n, ilo, ihi);
+  force->bounds(arg[1], n, jlo, jhi);
+  double cut_one = narg == 7 ? atof(arg[6]) : cut_global;
+  int count = 0;
+  for (int i = ilo; i <= ihi; i++)
+    for (int j = MAX(jlo, i); j <= jhi; j++) {
+      MESO(meso_pair_dpd_coeff(MesoHipContext::get(lmp), i, j, atof(arg[2]), atof(arg[3]), atof(arg[4]), atof(arg[5]), cut_one));
+      cut[i][j] = cut_one;
+      setflag[i][j] = 1;
+      count++;
+    }
+  if (count == 0) error->all(FLERR, "Incorrect args for pair coefficients");
+}
+
+void MesoHipPairDPD::init_style() {}   /* the neighbour table is built inside the library (meso_reneighbor) */
+
+double MesoHipPairDPD::init_one(int i, int j)
+{
+  if (setflag[i][j] == 0) error->all(FLERR, "All pair coeffs are not set");
+  cut[j][i] = cut[i][j];
+  return cut[i][j];
+}
+
+void MesoHipPairDPD::compute(int eflag, int vflag) { MESO(meso_pair_compute(MesoHipContext::get(lmp), MESO_RANGE_LOCAL, eflag, vflag)); }
+void MesoHipPairDPD::compute_bulk(int eflag, int vflag) { MESO(meso_pair_compute(MesoHipContext::get(lmp), MESO_RANGE_BULK, eflag, vflag)); }
+void MesoHipPairDPD::compute_border(int eflag, int vflag) { MESO(meso_pair_compute(MesoHipContext::get(lmp), MESO_RANGE_BORDER, eflag, vflag)); }
+
+/* ---------------------------------------------------------------------- fix nve/meso */
+
+MesoHipFixNVE::MesoHipFixNVE(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg)
+{
+  if (narg < 3) error->all(FLERR, "Illegal fix nve/meso command");
+  time_integrate = 1;
+}
+
+int MesoHipFixNVE::setmask() { return FixConst::INITIAL_INTEGRATE | FixConst::FINAL_INTEGRATE; }
+void MesoHipFixNVE::initial_integrate(int) { MESO(meso_nve_initial(MesoHipContext::get(lmp))); }
+void MesoHipFixNVE::final_integrate() { MESO(meso_nve_final(MesoHipContext::get(lmp))); }
+void MesoHipFixNVE::reset_dt() { MESO(meso_timestep(MesoHipContext::get(lmp), update->dt)); }
+
+/* ---------------------------------------------------------------------- compute temp/meso */
+
+MesoHipComputeTemp::MesoHipComputeTemp(LAMMPS *lmp, int narg, char **arg) : Compute(lmp, narg, arg)
+{
+  if (narg != 3) error->all(FLERR, "Illegal compute temp/meso command");
+  scalar_flag = 1;
+  extscalar = 0;
+  tempflag = 1;
+}
+
+double MesoHipComputeTemp::compute_scalar()
+{
+  invoked_scalar = update->ntimestep;
+  MESO(meso_compute_temp(MesoHipContext::get(lmp), &scalar));
+  return scalar;
+}
+
+/* ---------------------------------------------------------------------- run_style mvv/meso */
+
+MesoHipIntegrate::MesoHipIntegrate(LAMMPS *lmp, int narg, char **arg) : Integrate(lmp, narg, arg) {}
+
+void MesoHipIntegrate::init()
+{
+  Integrate::init();
+  force->newton = force->newton_pair = force->newton_bond = 0;   /* mvv_meso.cu:101-110 */
+  comm->ghost_velocity = 1;
+  if (domain->triclinic) error->one(FLERR, "<MESO> triclinic domain not supported in USER-MESO");
+  if (force->kspace) error->one(FLERR, "<MESO> kspace not supported in USER-MESO");
+}
+
+void MesoHipIntegrate::upload()
+{
+  meso_ctx *c = MesoHipContext::get(lmp);
+  MESO(meso_set_box(c, domain->boxlo, domain->boxhi, domain->periodicity));
+  MESO(meso_neighbor(c, neighbor->skin, neighbor->every, neighbor->delay, neighbor->dist_check));
+  MESO(meso_timestep(c, update->dt));
+  /* each rank hands over the atoms it owns; x[0]/v[0] are the contiguous double[n][3] blocks LAMMPS allocates */
+  MESO(meso_atoms_upload(c, atom->nlocal, atom->x[0], atom->v[0], atom->tag, atom->type, atom->mask, atom->image));
+}
+
+void MesoHipIntegrate::download()
+{
+  meso_ctx *c = MesoHipContext::get(lmp);
+  int n = 0;
+  MESO(meso_atoms_count(c, &n, NULL, NULL));
+  if (n > atom->nmax) atom->avec->grow(n);
+  atom->nlocal = n;
+  MESO(meso_atoms_download(c, atom->x[0], atom->v[0], atom->f[0], atom->tag, atom->type, atom->image));
+}
+
+void MesoHipIntegrate::setup()
+{
+  update->setupflag = 1;
+  upload();
+  MESO(meso_step_advance(MesoHipContext::get(lmp), update->ntimestep));
+  MESO(meso_setup(MesoHipContext::get(lmp)));
+  download();
+  output->setup();
+  update->setupflag = 0;
+}
+
+void MesoHipIntegrate::setup_minimal(int) { setup(); }
+
+void MesoHipIntegrate::run(int n)
+{
+  meso_ctx *c = MesoHipContext::get(lmp);
+  int done = 0;
+  while (done < n) {
+    bigint next = output->next;
+    int chunk = n - done;
+    if (next > update->ntimestep && next - update->ntimestep < chunk) chunk = (int) (next - update->ntimestep);
+    MESO(meso_run(c, chunk));
+    update->ntimestep += chunk;
+    done += chunk;
+    if (update->ntimestep == output->next) {
+      download();                                  /* transfer_pre_output, atom_meso.cu:258-266 */
+      output->write(update->ntimestep);
+    }
+  }
+  download();
+}
+
+void MesoHipIntegrate::cleanup() {}

@@ -1,0 +1,101 @@
+/* LAMMPS-side binding of libmeso_hip.so: the style classes a maintainer adds to a LAMMPS tree (next to, or
+   instead of, src/USER-MESO) so that the input decks of example/simple keep working unchanged:
+
+     atom_style dpd/atomic/meso  ->  stock AtomVecAtomic arrays (host mirror only)
+     run_style  mvv/meso         ->  MesoHipIntegrate   (IntegrateStyle, replaces ModifiedVerlet  mvv_meso.h:3-4)
+     pair_style dpd/meso         ->  MesoHipPairDPD     (PairStyle,      replaces MesoPairDPD     pair_dpd_meso.h:3)
+     pair_style dpd/fast/meso    ->  MesoHipPairDPDFast (PairStyle,      replaces MesoPairDPDFast pair_dpd_fast_meso.h:3)
+     fix        nve/meso         ->  MesoHipFixNVE      (FixStyle,       replaces FixNVEMeso      fix_nve_meso.h:3)
+     compute    temp/meso        ->  MesoHipComputeTemp (ComputeStyle,   replaces MesoComputeTemp compute_temp_meso.h)
+
+   The classes hold no HIP code: every virtual forwards to the C ABI of include/meso_hip.h.  The particle state lives
+   on the GPU between timesteps; LAMMPS' host arrays are refreshed (meso_atoms_download) only when the host needs
+   them (thermo / dump steps, end of run), which is what transfer_pre_output does in the reference
+   (atom_meso.cu:258-266).  Registration uses LAMMPS' own macro factory (src/force.cpp:81-86, src/update.cpp:298-318):
+   Make.sh style picks the *_CLASS blocks up from this header. */
+
+#ifdef PAIR_CLASS
+PairStyle(dpd/meso,MesoHipPairDPD)
+PairStyle(dpd/fast/meso,MesoHipPairDPDFast)
+#elif defined(FIX_CLASS)
+FixStyle(nve/meso,MesoHipFixNVE)
+#elif defined(COMPUTE_CLASS)
+ComputeStyle(temp/meso,MesoHipComputeTemp)
+#elif defined(INTEGRATE_CLASS)
+IntegrateStyle(mvv/meso,MesoHipIntegrate)
+IntegrateStyle(verlet/meso,MesoHipIntegrate)
+#else
+
+#ifndef LMP_MESO_HIP_GLUE_H
+#define LMP_MESO_HIP_GLUE_H
+
+#include "compute.h"
+#include "fix.h"
+#include "integrate.h"
+#include "pair.h"
+#include "meso_hip.h"
+
+namespace LAMMPS_NS {
+
+/* one context per LAMMPS instance (= per MPI rank = per GPU), shared by the styles below */
+struct MesoHipContext {
+  static meso_ctx *get(class LAMMPS *lmp);     /* meso_init on first use (device = local rank, src/lammps.cpp:432-452) */
+  static void check(class LAMMPS *lmp, int rc, const char *file, int line);   /* rc != 0 -> error->one(file,line,meso_last_error()) */
+};
+
+class MesoHipPairDPD : public Pair {
+ public:
+  MesoHipPairDPD(class LAMMPS *);
+  virtual ~MesoHipPairDPD() {}
+  void compute(int, int);              /* meso_pair_compute(ctx, MESO_RANGE_LOCAL, eflag, vflag) */
+  void compute_bulk(int, int);         /* ... MESO_RANGE_BULK   (pair_dpd_meso.cu:241-248) */
+  void compute_border(int, int);       /* ... MESO_RANGE_BORDER (pair_dpd_meso.cu:250-257) */
+  void settings(int, char **);         /* pair_style dpd/meso rc seed           -> meso_pair_dpd_settings */
+  void coeff(int, char **);            /* pair_coeff i j a0 gamma sigma s [rc]  -> meso_pair_dpd_coeff */
+  void init_style();
+  double init_one(int, int);
+ protected:
+  int style_id;                        /* MESO_PAIR_DPD or MESO_PAIR_DPD_FAST */
+  double cut_global;
+  int seed;
+  double **cut;
+};
+
+class MesoHipPairDPDFast : public MesoHipPairDPD {
+ public:
+  MesoHipPairDPDFast(class LAMMPS *);
+};
+
+class MesoHipFixNVE : public Fix {
+ public:
+  MesoHipFixNVE(class LAMMPS *, int, char **);
+  int setmask();
+  void initial_integrate(int);         /* meso_nve_initial */
+  void final_integrate();              /* meso_nve_final   */
+  void reset_dt();                     /* meso_timestep    */
+};
+
+class MesoHipComputeTemp : public Compute {
+ public:
+  MesoHipComputeTemp(class LAMMPS *, int, char **);
+  void init() {}
+  double compute_scalar();             /* meso_compute_temp (global sum done inside the library) */
+};
+
+class MesoHipIntegrate : public Integrate {
+ public:
+  MesoHipIntegrate(class LAMMPS *, int, char **);
+  void init();                         /* forces newton off / ghost velocities on like mvv_meso.cu:79-133 */
+  void setup();                        /* upload host arrays (meso_set_box/mass/atoms_upload), meso_setup */
+  void setup_minimal(int);
+  void run(int);                       /* meso_run in chunks that end on output->next, then download */
+  void cleanup();
+ private:
+  void upload();
+  void download();
+};
+
+}
+
+#endif
+#endif
