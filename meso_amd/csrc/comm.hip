@@ -507,8 +507,7 @@ int Engine::migrate()
                            d_flags + 3);
         launch_border_count_code(code, 0, nlocal, chunk_count, nchunk, stream);
         HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
-        for (int dir = 0; dir <= 27; dir++)
-            HIPCHK(hipMemcpyAsync(d_dir_start + dir, chunk_offset + (size_t)dir * nchunk, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        launch_dir_starts(chunk_offset, nchunk, d_dir_start, stream);
         launch_border_fill_code(code, 0, nlocal, chunk_offset, nchunk, sendlist, stream);
     } else {
         HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
@@ -583,8 +582,7 @@ int Engine::halo_borders_multi()
     if (nchunk > 0) {
         launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
         HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
-        for (int dir = 0; dir <= 27; dir++)
-            HIPCHK(hipMemcpyAsync(d_dir_start + dir, chunk_offset + (size_t)dir * nchunk, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        launch_dir_starts(chunk_offset, nchunk, d_dir_start, stream);
         HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];

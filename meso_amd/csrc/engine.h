@@ -144,7 +144,8 @@ private:
     std::vector<int> coeff_set;
     std::vector<double> mass_type;  // ntypes+1
     int neigh_kernel = 1;           // 0 simple, 1 wave/LDS
-    int pair_kernel = 2;            // 0 lane-per-atom, 1 ballot-compacted (tile / brick), 2 lane-per-atom, 8-deep MLP
+    int pair_kernel = 2;            // 0 lane-per-atom, 1 tile/brick, 2 auto (fp32: 8-deep MLP, fp64: MLP + compaction),
+                                    // 3 MLP + ballot compaction, 4 MLP only
     int pair_debug = 0;             // timing ablations (bench only)
     int fuse_clear = 1;             // pair kernel writes f instead of clear + accumulate
     long natoms_total = 0;

@@ -566,11 +566,7 @@ int Engine::halo_borders()
         launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
         HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
         // direction starts = offsets of chunk 0 of each direction (+ total)
-        for (int dir = 0; dir < 27; dir++)
-            HIPCHK(hipMemcpyAsync(d_dir_start + dir, chunk_offset + (size_t)dir * nchunk, sizeof(int),
-                                  hipMemcpyDeviceToDevice, stream));
-        HIPCHK(hipMemcpyAsync(d_dir_start + 27, chunk_offset + (size_t)27 * nchunk, sizeof(int),
-                              hipMemcpyDeviceToDevice, stream));
+        launch_dir_starts(chunk_offset, nchunk, d_dir_start, stream);
         HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];
@@ -799,6 +795,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     TRY(ensure_table32());
     tbegin("pair");
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
+    else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
     else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
     else launch_pair_dpd_tile(p, pair_style, stream);
     tend("pair");
@@ -853,6 +850,7 @@ int Engine::run(int nsteps)
             TRY(ensure_table32());
             tbegin("pair");
             if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
+            else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
             else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
             else launch_pair_dpd_tile(p, pair_style, stream);
             tend("pair");

@@ -57,6 +57,7 @@ void launch_border_count(const AtomSoA &a, int beg, int end, const double *slab_
 void launch_border_fill(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi,
                         const int *dim_active, const int *chunk_offset /*[27][nchunk] exclusive, global*/,
                         int nchunk, int *sendlist, hipStream_t s);
+void launch_dir_starts(const int *chunk_offset, int nchunk, int *dir_start, hipStream_t s);
 void launch_border_count_code(const int *code, int beg, int end, int *chunk_count, int nchunk, hipStream_t s);
 void launch_border_fill_code(const int *code, int beg, int end, const int *chunk_offset, int nchunk, int *list,
                              hipStream_t s);
@@ -105,6 +106,8 @@ struct PairArgs {
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // lane-per-atom with 8-deep memory-level parallelism (forces only)
 void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
+// the same with a ballot-compacted heavy phase (per-wave LDS ring)
+void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s);
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
 void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
 void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key_shift, const int4 *binrange, int M,

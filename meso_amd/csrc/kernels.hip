@@ -502,6 +502,17 @@ void launch_border_fill(const AtomSoA &a, int beg, int end, const double *slab_l
                        chunk_offset, nchunk, sendlist);
 }
 
+// dir_start[d] = chunk_offset[d*nchunk] (d = 0..27): one launch instead of 28 tiny device-to-device copies
+__global__ void k_dir_starts(const int *__restrict__ chunk_offset, int nchunk, int *__restrict__ dir_start)
+{
+    int d = threadIdx.x;
+    if (d < 28) dir_start[d] = chunk_offset[(size_t)d * nchunk];
+}
+void launch_dir_starts(const int *chunk_offset, int nchunk, int *dir_start, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dir_starts, dim3(1), dim3(64), 0, s, chunk_offset, nchunk, dir_start);
+}
+
 struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0 when not crossing a PBC)
 struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction
 
@@ -1162,15 +1173,195 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
     else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
 }
 
+// pair force v4 = v3's memory-level parallelism + a ballot-compacted heavy phase.  Phase A (per lane, 8 row entries
+// at a time): row words, coordinate gathers, cutoff tests, velocity gathers of the hits.  Hits are appended to a
+// per-wave LDS ring with ballot + popcount; whenever 64 are queued the wave evaluates them with every lane busy
+// (TEA, Gaussian, weights cost ~100 VALU instructions per pair; only ~47 % of list entries are inside r_c, so
+// the lane-per-atom form runs that code at < 50 % lane efficiency).  Per-atom sums are wave-scope LDS adds in a
+// fixed order: results are reproducible run to run, and there are no global atomics.
+#define P4_WAVES 4
+#define P4_RING 128
+template <bool FAST, int CH, bool ACC64>
+__global__ void __launch_bounds__(64 * P4_WAVES, 4) k_pair_dpd_mlpc(PairArgs a)
+{
+    typedef typename std::conditional<ACC64, double, float>::type acc_t;
+    extern __shared__ double smem[];
+    const int ncf = a.ntypes * a.ntypes * N_COEFF;
+    double *cf64 = smem;
+    float *cf32 = (float *)smem;
+    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
+        if (FAST) cf32[p] = a.coeff32[p];
+        else cf64[p] = a.coeff64[p];
+    }
+    const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t per_wave = 64 * 16 * 2 + P4_RING * 16 * 2 + P4_RING * 4 + 64 * 3 * sizeof(acc_t);
+    char *wb = (char *)smem + off + (size_t)w * per_wave;
+    float4 *own_c = (float4 *)wb;
+    float4 *own_v = own_c + 64;
+    float4 *ring_c = own_v + 64;
+    float4 *ring_v = ring_c + P4_RING;
+    int *ring_id = (int *)(ring_v + P4_RING);
+    acc_t *facc = (acc_t *)(ring_id + P4_RING);
+    __syncthreads();
+
+    const int nbk = gridDim.x;
+    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
+    const int i = a.beg + blk * blockDim.x + threadIdx.x;
+    const bool mine = i < a.end;
+    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
+    int n = 0;
+    if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
+    own_c[lane] = c1;
+    own_v[lane] = v1;
+    facc[lane] = 0; facc[64 + lane] = 0; facc[128 + lane] = 0;
+    const u32 t1 = __float_as_uint(c1.w);
+    const int4 *rows = (const int4 *)a.table;
+    const u64 lt = (1ULL << lane) - 1ULL;
+    const float dtis32 = (float)a.dt_inv_sqrt;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    int qhead = 0, qtail = 0;
+
+    auto drain = [&](int nb) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nb) {
+            const int slot = (qhead + lane) & (P4_RING - 1);
+            const float4 cj = ring_c[slot], vj = ring_v[slot];
+            const int ai = ring_id[slot];
+            const float4 ci = own_c[ai], vi = own_v[ai];
+            const u32 si = __float_as_uint(vi.w), sj = __float_as_uint(vj.w);
+            const int cidx = __float_as_uint(ci.w) * a.ntypes + __float_as_uint(cj.w);
+            if (FAST) {
+                const float *cf = cf32 + cidx * N_COEFF;
+                float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
+                float rsq = dx * dx + dy * dy + dz * dz;
+                float rn = gaussian_tea_fast(si, sj);
+                float rinv = __builtin_amdgcn_rsqf(rsq);
+                float r = rsq * rinv;
+                float dvx = vi.x - vj.x, dvy = vi.y - vj.y, dvz = vi.z - vj.z;
+                float dot = dx * dvx + dy * dvy + dz * dvz;
+                float wc = 1.0f - r * cf[P_CUTINV];
+                float ew = cf[P_EXPW];
+                float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
+                float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
+                fpair *= rinv;
+                __hip_atomic_fetch_add(&facc[ai], (acc_t)(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&facc[64 + ai], (acc_t)(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&facc[128 + ai], (acc_t)(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {
+                const double *cf = cf64 + cidx * N_COEFF;
+                double dx = (double)ci.x - (double)cj.x, dy = (double)ci.y - (double)cj.y, dz = (double)ci.z - (double)cj.z;
+                double rsq = dx * dx + dy * dy + dz * dz;
+                double rn = gaussian_tea(si, sj);
+                double rinv = rsqrt(rsq);
+                double r = rsq * rinv;
+                double dvx = (double)vi.x - (double)vj.x, dvy = (double)vi.y - (double)vj.y, dvz = (double)vi.z - (double)vj.z;
+                double dot = dx * dvx + dy * dvy + dz * dvz;
+                double wc = 1.0 - r * cf[P_CUTINV];
+                double ew = cf[P_EXPW];
+                double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
+                double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
+                fpair *= rinv;
+                __hip_atomic_fetch_add(&facc[ai], (acc_t)(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&facc[64 + ai], (acc_t)(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&facc[128 + ai], (acc_t)(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        qhead += nb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    for (int p0 = 0; p0 < nmax; p0 += CH) {
+        int j[CH];
+        float4 c2[CH], v2[CH];
+        bool hit[CH];
+        if (a.chunked) {
+#pragma unroll
+            for (int q4 = 0; q4 < CH / 4; q4++) {
+                int4 wv = make_int4(i, i, i, i);
+                if (p0 + 4 * q4 < n) wv = rows[2 * row_word8(i, p0 >> 3, a.n_col) + ((p0 & 7) >> 2) + q4];
+                j[4 * q4] = wv.x; j[4 * q4 + 1] = wv.y; j[4 * q4 + 2] = wv.z; j[4 * q4 + 3] = wv.w;
+            }
+#pragma unroll
+            for (int q = 0; q < CH; q++) j[q] = (p0 + q < n) ? j[q] : i;
+        } else {
+            const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
+#pragma unroll
+            for (int q = 0; q < CH; q++) j[q] = (p0 + q < n) ? col[(size_t)(p0 + q) * 64] : i;
+        }
+        if (!mine) {
+#pragma unroll
+            for (int q = 0; q < CH; q++) j[q] = a.beg;   // a valid index; never a hit (n == 0)
+        }
+#pragma unroll
+        for (int q = 0; q < CH; q++) c2[q] = a.coord4[j[q]];
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const int cidx = t1 * a.ntypes + __float_as_uint(c2[q].w);
+            if (FAST) {
+                float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
+                float rsq = dx * dx + dy * dy + dz * dz;
+                hit[q] = p0 + q < n && rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
+            } else {
+                double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
+                double rsq = dx * dx + dy * dy + dz * dz;
+                hit[q] = p0 + q < n && rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
+            }
+            v2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hit[q]) v2[q] = a.veloc4[j[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const u64 m = __ballot(hit[q]);
+            if (m) {
+                if (hit[q]) {
+                    const int slot = (qtail + __popcll(m & lt)) & (P4_RING - 1);
+                    ring_c[slot] = c2[q];
+                    ring_v[slot] = v2[q];
+                    ring_id[slot] = lane;
+                }
+                qtail += __popcll(m);
+                if (qtail - qhead >= 64) drain(64);
+            }
+        }
+    }
+    if (qtail > qhead) drain(qtail - qhead);
+
+    if (mine) {
+        double fx = (double)facc[lane], fy = (double)facc[64 + lane], fz = (double)facc[128 + lane];
+        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
+        else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
+    }
+}
+
+void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s)
+{
+    int n = p.end - p.beg;
+    if (n <= 0) return;
+    size_t ncf = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? 4 : 8);
+    // accumulators are fp64 in both styles: ds_add_f32 is ~2x slower than ds_add_f64 on gfx950 (332 vs 156 us)
+    size_t per_wave = 64 * 16 * 2 + P4_RING * 16 * 2 + P4_RING * 4 + 64 * 3 * 8;
+    size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * P4_WAVES;
+    dim3 grid((nblk(n, 64 * P4_WAVES) + 7) / 8 * 8), block(64 * P4_WAVES);
+    if (fast) hipLaunchKernelGGL((k_pair_dpd_mlpc<true, 8, true>), grid, block, sm, s, p);
+    else hipLaunchKernelGGL((k_pair_dpd_mlpc<false, 4, true>), grid, block, sm, s, p);
+}
+
 void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s)
 {
     int n = p.end - p.beg;
     if (n <= 0) return;
     size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? sizeof(float) : sizeof(double));
     dim3 grid((nblk(n, 256) + 7) / 8 * 8), block(256);
-    // fp64 math needs twice the registers per pair in flight: 4-deep keeps 4+ waves per SIMD
-    // depth x occupancy measured on 64^3 (profiles/r01_notes.md): fp32 8-deep at 4 waves/SIMD (112 VGPRs);
-    // fp64 keeps ~45 polynomial constants live, so 2-deep under a 128-VGPR budget wins there
+    // depth x occupancy measured on 64^3 (profiles/r01_notes.md): fp32 8-deep at 4 waves/SIMD (112 VGPRs).  A branch-free
+    // heavy phase (select instead of exec mask, 2-8 slots interleaved) was slower at every depth (162-230 us): it
+    // costs registers/occupancy and the velocity gathers of the misses.
     if (fast) hipLaunchKernelGGL((k_pair_dpd_mlp<true, 8, 4>), grid, block, sm, s, p);
     else hipLaunchKernelGGL((k_pair_dpd_mlp<false, 2, 4>), grid, block, sm, s, p);
 }

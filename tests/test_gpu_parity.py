@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 # with LDS-staged halos and 16-bit rows; pair_kernel 0 = lane per atom, 1 = ballot-compacted (tile / brick).
 PATHS = {"lane": (("layout", 0), ("pair_kernel", 0)), "tile": (("layout", 0), ("pair_kernel", 1)),
          "brick": (("layout", 1), ("pair_kernel", 1)), "brick-rows+lane": (("layout", 1), ("pair_kernel", 0)),
-         "cell+mlp": (("layout", 2), ("pair_kernel", 2))}
+         "cell+mlp": (("layout", 2), ("pair_kernel", 2)), "cell+mlpc": (("layout", 2), ("pair_kernel", 3)),
+         "bins+mlpc": (("layout", 0), ("pair_kernel", 3))}
 
 
 @pytest.fixture(scope="module")
@@ -159,7 +160,7 @@ def test_sigma0_vs_stock_lammps_cpu(Meso, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("path", ["lane", "tile", "brick", "cell+mlp"])
+@pytest.mark.parametrize("path", ["lane", "tile", "brick", "cell+mlp", "cell+mlpc"])
 @pytest.mark.parametrize("style,every,sigma,steps", [("dpd/meso", 5, 3.0, 12), ("dpd/meso", 1, 3.0, 12),
                                                      ("dpd/fast/meso", 5, 0.0, 12), ("dpd/fast/meso", 5, 3.0, 1)])
 def test_trajectory_vs_meso_oracle(Meso, oracle, style, every, sigma, steps, path):
