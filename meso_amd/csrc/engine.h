@@ -147,6 +147,7 @@ private:
     int pair_kernel = 2;            // 0 lane-per-atom, 1 tile/brick, 2 auto (fp32: 8-deep MLP, fp64: MLP + compaction),
                                     // 3 MLP + ballot compaction, 4 MLP only
     int pair_debug = 0;             // timing ablations (bench only)
+    int fuse_step = 1;              // final(s)+initial(s+1)(+merge) in one kernel between steps of one run()
     int fuse_clear = 1;             // pair kernel writes f instead of clear + accumulate
     long natoms_total = 0;
 

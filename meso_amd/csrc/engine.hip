@@ -230,6 +230,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
     if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
+    if (key == "fuse_step") { fuse_step = (int)val; return 0; }
     if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
@@ -821,14 +822,15 @@ int Engine::run(int nsteps)
 {
     if (!is_setup) return fail(3, "run before setup");
     tbegin("total_steps");
+    bool initial_done = false, merged = false;
     for (int it = 0; it < nsteps; it++) {
         ntimestep++;
-        TRY(nve_initial());
+        if (!initial_done) TRY(nve_initial());
         int rebuild = 0;
         TRY(decide(&rebuild));
-        if (rebuild) TRY(reneighbor());
+        if (rebuild) { TRY(reneighbor()); merged = false; }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
-        TRY(merge_locals(sd));
+        if (!merged) TRY(merge_locals(sd));
         TRY(halo_forward_seed(sd));
         PairArgs p;
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
@@ -855,7 +857,22 @@ int Engine::run(int nsteps)
             else launch_pair_dpd_tile(p, pair_style, stream);
             tend("pair");
         }
-        TRY(nve_final());
+        if (fuse_step && it + 1 < nsteps) {
+            // one pass for final(s) + initial(s+1); the merge for s+1 rides along when s+1 provably keeps the table
+            const int a1 = ago + 1;
+            const bool next_rebuild = dist_check || (a1 >= delay && a1 % every == 0);
+            tbegin("nve");
+            launch_nve_boundary(cur, 0.5 * dt, dt, groupbit, nlocal, next_rebuild ? 0 : 1, coord4, veloc4,
+                                0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
+                                premix_tea<64>((u32)seed, (u32)(ntimestep + 1)), stream);
+            tend("nve");
+            initial_done = true;
+            merged = !next_rebuild;
+        } else {
+            TRY(nve_final());
+            initial_done = false;
+            merged = false;
+        }
         ev_valid = false;
     }
     tend("total_steps");

@@ -29,6 +29,9 @@ void launch_merge_xvt(const AtomSoA &a, float4 *coord4, float4 *veloc4, double c
                       uint32_t seed, int beg, int end, hipStream_t s);
 void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s);
 void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s);
+// final(step s) + initial(step s+1) [+ merge for step s+1] in one pass
+void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, int merge, float4 *coord4,
+                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s);
 void launch_sum_mv2(const AtomSoA &a, int groupbit, int n, double *partial, double *result, hipStream_t s);
 void launch_pbc(const AtomSoA &a, const double *boxlo, const double *boxhi, const int *periodic, int n,
                 hipStream_t s);

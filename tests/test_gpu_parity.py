@@ -185,6 +185,18 @@ def test_trajectory_vs_meso_oracle(Meso, oracle, style, every, sigma, steps, pat
     m.close()
 
 
+def test_fused_step_boundary_is_bit_identical(Meso):
+    """final(s)+initial(s+1)+merge fused into one kernel gives the same bits as the three separate kernels."""
+    res = []
+    for fuse in (0, 1):
+        m, _ = _engine(Meso, 7, opts=(("fuse_step", fuse),))
+        m.run(17)
+        res.append(m.gather())
+        m.close()
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(a, b)
+
+
 def test_momentum_and_thermostat(Meso):
     m, _ = _engine(Meso, 8)
     f = m.gather()[2]
