@@ -782,6 +782,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.e_pair = ev ? e_pair : nullptr;
     for (int k = 0; k < 6; k++) p.virial[k] = ev ? virial[k] : nullptr;
     p.coeff64 = d_coeff64; p.coeff32 = d_coeff32; p.ntypes = ntypes;
+    for (int k = 0; k < 7; k++) p.cf1[k] = coeff[k];
     p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
     p.beg = beg; p.end = end;
     p.accumulate = 1;
@@ -838,6 +839,7 @@ int Engine::run(int nsteps)
         p.e_pair = nullptr;
         for (int k = 0; k < 6; k++) p.virial[k] = nullptr;
         p.coeff64 = d_coeff64; p.coeff32 = d_coeff32; p.ntypes = ntypes;
+        for (int k = 0; k < 7; k++) p.cf1[k] = coeff[k];
         p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
         p.beg = 0; p.end = nlocal;
         p.accumulate = fuse_clear ? 0 : 1;

@@ -100,6 +100,7 @@ struct PairArgs {
     const double *coeff64;
     const float *coeff32;
     int ntypes;
+    double cf1[7];        // the single coefficient row when ntypes == 1 (kernel-argument constants, no LDS lookups)
     double dt_inv_sqrt;
     int beg, end;
     int accumulate;       // 1: f += (reference semantics), 0: f = (force_clear fused)

@@ -1108,7 +1108,7 @@ void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key
 // pair force v3: lane per atom like v1, but the row is consumed 8 entries at a time -- 8 index loads, then 8
 // coordinate gathers, then the velocity gathers of the hits are all in flight together, so a wave keeps ~8
 // L2 requests per lane outstanding instead of one (v1 measured 86 % of wave cycles waiting on memory).
-template <bool FAST, int PAIR3_CH, int OCC>
+template <bool FAST, int PAIR3_CH, int OCC, bool NT1>
 __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
 {
     extern __shared__ double smem[];
@@ -1164,11 +1164,11 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
             if (FAST) {
                 float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
                 float rsq = dx * dx + dy * dy + dz * dz;
-                hit[q] = rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
+                hit[q] = rsq < (NT1 ? (float)a.cf1[P_CUTSQ] : cf32[cidx * N_COEFF + P_CUTSQ]) && rsq >= (float)MESO_EPSILON_SQ;
             } else {
                 double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
                 double rsq = dx * dx + dy * dy + dz * dz;
-                hit[q] = rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
+                hit[q] = rsq < (NT1 ? a.cf1[P_CUTSQ] : cf64[cidx * N_COEFF + P_CUTSQ]) && rsq >= MESO_EPSILON_SQ;
             }
             v2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (hit[q]) v2[q] = a.veloc4[j[q]];
@@ -1179,7 +1179,10 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
             const int cidx = t1 * a.ntypes + __float_as_uint(c2[q].w);
             const u32 s2 = __float_as_uint(v2[q].w);
             if (FAST) {
-                const float *cf = cf32 + cidx * N_COEFF;
+                const float *cfp = cf32 + cidx * N_COEFF;
+                const float c_cutinv = NT1 ? (float)a.cf1[P_CUTINV] : cfp[P_CUTINV], c_ew = NT1 ? (float)a.cf1[P_EXPW] : cfp[P_EXPW];
+                const float c_a0 = NT1 ? (float)a.cf1[P_A0] : cfp[P_A0], c_gamma = NT1 ? (float)a.cf1[P_GAMMA] : cfp[P_GAMMA];
+                const float c_sigma = NT1 ? (float)a.cf1[P_SIGMA] : cfp[P_SIGMA];
                 float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
                 float rsq = dx * dx + dy * dy + dz * dz;
                 float rn = gaussian_tea_fast(s1, s2);
@@ -1187,14 +1190,17 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
                 float r = rsq * rinv;
                 float dvx = v1.x - v2[q].x, dvy = v1.y - v2[q].y, dvz = v1.z - v2[q].z;
                 float dot = dx * dvx + dy * dvy + dz * dvz;
-                float wc = 1.0f - r * cf[P_CUTINV];
-                float ew = cf[P_EXPW];
-                float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
-                float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
+                float wc = 1.0f - r * c_cutinv;
+                float wr = wc;
+                if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
+                float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis32);
                 fpair *= rinv;
                 fx32 += dx * fpair; fy32 += dy * fpair; fz32 += dz * fpair;
             } else {
-                const double *cf = cf64 + cidx * N_COEFF;
+                const double *cfp = cf64 + cidx * N_COEFF;
+                const double c_cutinv = NT1 ? a.cf1[P_CUTINV] : cfp[P_CUTINV], c_ew = NT1 ? a.cf1[P_EXPW] : cfp[P_EXPW];
+                const double c_a0 = NT1 ? a.cf1[P_A0] : cfp[P_A0], c_gamma = NT1 ? a.cf1[P_GAMMA] : cfp[P_GAMMA];
+                const double c_sigma = NT1 ? a.cf1[P_SIGMA] : cfp[P_SIGMA];
                 double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
                 double rsq = dx * dx + dy * dy + dz * dz;
                 double rn = gaussian_tea(s1, s2);
@@ -1202,10 +1208,10 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
                 double r = rsq * rinv;
                 double dvx = (double)v1.x - (double)v2[q].x, dvy = (double)v1.y - (double)v2[q].y, dvz = (double)v1.z - (double)v2[q].z;
                 double dot = dx * dvx + dy * dvy + dz * dvz;
-                double wc = 1.0 - r * cf[P_CUTINV];
-                double ew = cf[P_EXPW];
-                double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
-                double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
+                double wc = 1.0 - r * c_cutinv;
+                double wr = wc;
+                if (c_ew != 1.0) wr = powd_poly(wc, c_ew);
+                double fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * a.dt_inv_sqrt);
                 fpair *= rinv;
                 fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
             }
@@ -1228,7 +1234,7 @@ __global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
 #define P4_WAVES 4
 #define P4_RING 128
 template <bool FAST, int CH, bool ACC64>
-__global__ void __launch_bounds__(64 * P4_WAVES, 4) k_pair_dpd_mlpc(PairArgs a)
+__global__ void __launch_bounds__(64 * P4_WAVES, FAST ? 4 : 2) k_pair_dpd_mlpc(PairArgs a)
 {
     typedef typename std::conditional<ACC64, double, float>::type acc_t;
     extern __shared__ double smem[];
@@ -1283,6 +1289,7 @@ __global__ void __launch_bounds__(64 * P4_WAVES, 4) k_pair_dpd_mlpc(PairArgs a)
             const int cidx = __float_as_uint(ci.w) * a.ntypes + __float_as_uint(cj.w);
             if (FAST) {
                 const float *cf = cf32 + cidx * N_COEFF;
+                const float c_cutinv = cf[P_CUTINV], c_ew = cf[P_EXPW], c_a0 = cf[P_A0], c_gamma = cf[P_GAMMA], c_sigma = cf[P_SIGMA];
                 float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
                 float rsq = dx * dx + dy * dy + dz * dz;
                 float rn = gaussian_tea_fast(si, sj);
@@ -1290,16 +1297,17 @@ __global__ void __launch_bounds__(64 * P4_WAVES, 4) k_pair_dpd_mlpc(PairArgs a)
                 float r = rsq * rinv;
                 float dvx = vi.x - vj.x, dvy = vi.y - vj.y, dvz = vi.z - vj.z;
                 float dot = dx * dvx + dy * dvy + dz * dvz;
-                float wc = 1.0f - r * cf[P_CUTINV];
-                float ew = cf[P_EXPW];
-                float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
-                float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
+                float wc = 1.0f - r * c_cutinv;
+                float wr = wc;
+                if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
+                float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis32);
                 fpair *= rinv;
                 __hip_atomic_fetch_add(&facc[ai], (acc_t)(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_add(&facc[64 + ai], (acc_t)(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_add(&facc[128 + ai], (acc_t)(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             } else {
                 const double *cf = cf64 + cidx * N_COEFF;
+                const double c_cutinv = cf[P_CUTINV], c_ew = cf[P_EXPW], c_a0 = cf[P_A0], c_gamma = cf[P_GAMMA], c_sigma = cf[P_SIGMA];
                 double dx = (double)ci.x - (double)cj.x, dy = (double)ci.y - (double)cj.y, dz = (double)ci.z - (double)cj.z;
                 double rsq = dx * dx + dy * dy + dz * dz;
                 double rn = gaussian_tea(si, sj);
@@ -1307,10 +1315,10 @@ __global__ void __launch_bounds__(64 * P4_WAVES, 4) k_pair_dpd_mlpc(PairArgs a)
                 double r = rsq * rinv;
                 double dvx = (double)vi.x - (double)vj.x, dvy = (double)vi.y - (double)vj.y, dvz = (double)vi.z - (double)vj.z;
                 double dot = dx * dvx + dy * dvy + dz * dvz;
-                double wc = 1.0 - r * cf[P_CUTINV];
-                double ew = cf[P_EXPW];
-                double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
-                double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
+                double wc = 1.0 - r * c_cutinv;
+                double wr = wc;
+                if (c_ew != 1.0) wr = powd_poly(wc, c_ew);
+                double fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * a.dt_inv_sqrt);
                 fpair *= rinv;
                 __hip_atomic_fetch_add(&facc[ai], (acc_t)(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_add(&facc[64 + ai], (acc_t)(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1408,8 +1416,11 @@ void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s)
     // depth x occupancy measured on 64^3 (profiles/r01_notes.md): fp32 8-deep at 4 waves/SIMD (112 VGPRs).  A branch-free
     // heavy phase (select instead of exec mask, 2-8 slots interleaved) was slower at every depth (162-230 us): it
     // costs registers/occupancy and the velocity gathers of the misses.
-    if (fast) hipLaunchKernelGGL((k_pair_dpd_mlp<true, 8, 4>), grid, block, sm, s, p);
-    else hipLaunchKernelGGL((k_pair_dpd_mlp<false, 2, 4>), grid, block, sm, s, p);
+    const bool nt1 = p.ntypes == 1;
+    if (fast && nt1) hipLaunchKernelGGL((k_pair_dpd_mlp<true, 8, 4, true>), grid, block, sm, s, p);
+    else if (fast) hipLaunchKernelGGL((k_pair_dpd_mlp<true, 8, 4, false>), grid, block, sm, s, p);
+    else if (nt1) hipLaunchKernelGGL((k_pair_dpd_mlp<false, 2, 4, true>), grid, block, sm, s, p);
+    else hipLaunchKernelGGL((k_pair_dpd_mlp<false, 2, 4, false>), grid, block, sm, s, p);
 }
 
 // =========================================================================================

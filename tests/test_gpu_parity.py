@@ -185,6 +185,25 @@ def test_trajectory_vs_meso_oracle(Meso, oracle, style, every, sigma, steps, pat
     m.close()
 
 
+@pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-10), ("dpd/fast/meso", 1e-4)])
+def test_kernels_agree_on_a_large_box(Meso, style, tol):
+    """32^3 (131 k atoms, 512+ workgroups, XCD remap active): every force kernel against the lane-per-atom one.
+    (A register-spilling build of the compacted fp64 kernel was correct at 25^3 and wrong here.)"""
+    ref = None
+    for path in ("cell-lane", "cell+mlp", "cell+mlpc", "brick", "tile"):
+        opts = {"cell-lane": (("layout", 2), ("pair_kernel", 0)), "cell+mlp": (("layout", 2), ("pair_kernel", 4))}.get(path, PATHS.get(path))
+        m, _ = _engine(Meso, 32, style=style, opts=opts)
+        m.force_clear("local")
+        m.compute()
+        f = m.gather()[2]
+        m.close()
+        assert np.isfinite(f).all(), path
+        if ref is None:
+            ref = f
+        else:
+            assert np.abs(f - ref).max() <= tol * np.abs(ref).max(), path
+
+
 def test_fused_step_boundary_is_bit_identical(Meso):
     """final(s)+initial(s+1)+merge fused into one kernel gives the same bits as the three separate kernels."""
     res = []
