@@ -158,6 +158,17 @@ def main():
     b_pair = n_rank * (16 + 16 + 4 + 4.0 * info["avg_count"] + 3 * w)
     achieved = b_pair / t_pair / 1e9
     T = m.temperature()
+    if not (abs(T - 1.0) < 0.25):
+        raise SystemExit("bench: temperature %r after the run - the trajectory is not physical" % T)
+    # HBM traffic of the dominant kernel from the PMC passes of the same workload (profiles/, collected separately:
+    # counters cannot be read inside this process); null for workloads that were not profiled
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if L == 64 and a.style == "dpd/fast/meso" and a.gpus == 1:
+            traffic = tj["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     line = {
         "metric": "DPD timesteps/s, %d^3 rho=4 box" % L,
@@ -177,7 +188,7 @@ def main():
                    "M_particle_steps_per_s": steps_per_s * n / 1e6,
                    "avg_neighbors": info["avg_count"], "temperature_end": T},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_pair_dpd_mlp", "bytes_per_launch": b_pair, "us_per_launch": t_pair * 1e6},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
     }

@@ -133,6 +133,7 @@ void Engine::comm_free()
 int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf,
                  const size_t *rbytes)
 {
+    hipStream_t stream = xs ? xs : this->stream;   // exchange stream (the side stream during overlapped refreshes)
     if (transport == 1) {
         ncclComm_t c = (ncclComm_t)nccl;
         bool any = false;
@@ -642,7 +643,7 @@ void Engine::free_fwd_tab()
 }
 
 // Comm::forward_comm for nranks > 1.  Split in two so the engine can run the bulk force kernel between them.
-int Engine::halo_forward_multi_begin(uint32_t sd)
+int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
 {
     tbegin("halo");
     int np = (int)peers.size();
@@ -655,15 +656,31 @@ int Engine::halo_forward_multi_begin(uint32_t sd)
         sb[p] = (float4 *)stage_send + 2 * (size_t)peer_send_base[p]; sn[p] = (size_t)peer_send_n[p] * 2 * sizeof(float4);
         rb[p] = (float4 *)stage_recv + 2 * (size_t)peer_recv_base[p]; rn[p] = (size_t)peer_recv_n[p] * 2 * sizeof(float4);
     }
-    TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
+    // exchange + scatter run on the side stream so the bulk force kernel (main stream) overlaps them, the role the
+    // reference gives its bulk/border split (mvv_meso.cu:338-362) to hide the PCIe + MPI round trip
+    if (!ev_pack) { HIPCHK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming)); }
+    HIPCHK(hipEventRecord(ev_pack, stream));
+    HIPCHK(hipStreamWaitEvent(side, ev_pack, 0));
+    xs = side;
+    int rc = xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data());
+    xs = nullptr;
+    if (rc) return rc;
     if (nghost > 0) {
         PeerTab P;
         P.np = np;
         for (int p = 0; p <= np; p++) P.gbase[p] = peer_recv_base[p];
-        hipLaunchKernelGGL(k_scatter_ghost, dim3((nghost + 255) / 256), dim3(256), 0, stream, (const float4 *)stage_recv, P,
+        hipLaunchKernelGGL(k_scatter_ghost, dim3((nghost + 255) / 256), dim3(256), 0, side, (const float4 *)stage_recv, P,
                            layout >= 1 ? gslot : nullptr, nghost, coord4 + nlocal, veloc4 + nlocal);
     }
+    HIPCHK(hipEventRecord(ev_halo, side));
+    if (!async) HIPCHK(hipStreamWaitEvent(stream, ev_halo, 0));
     tend("halo");
+    return 0;
+}
+
+int Engine::halo_wait()
+{
+    if (nranks > 1 && ev_halo) HIPCHK(hipStreamWaitEvent(stream, ev_halo, 0));
     return 0;
 }
 

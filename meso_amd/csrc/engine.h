@@ -86,7 +86,7 @@ private:
     void range(int r, int &beg, int &end) const;
     int merge_locals(uint32_t seed);
     int halo_borders();
-    int halo_forward_seed(uint32_t seed);
+    int halo_forward_seed(uint32_t seed, bool async = false);
     int build_cells_and_table();
     int reorder_locals();
     int migrate();
@@ -97,7 +97,8 @@ private:
     int exchange_counts(const int *dir_count, std::vector<int> &send_n, std::vector<int> &recv_n, std::vector<int> &recv_dir);
     void build_peer_tables();
     int halo_borders_multi();
-    int halo_forward_multi_begin(uint32_t seed);
+    int halo_forward_multi_begin(uint32_t seed, bool async);
+    int halo_wait();
     int ensure_stage(size_t sbytes, size_t rbytes);
     bool owns(const double *x) const;
     void comm_free();
@@ -127,6 +128,9 @@ private:
     size_t stage_send_bytes = 0, stage_recv_bytes = 0;
     int *sendlist_aux = nullptr;
     DirTab *fwd_tab = nullptr;
+    hipStream_t xs = nullptr;       // stream used by xchg (nullptr: the main stream)
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+    int overlap = 1;                // bulk force kernel overlaps the ghost refresh (nranks > 1)
     double sublo[3], subhi[3];
     double slab_lo[3], slab_hi[3];
     double shift27[81], center27[81];

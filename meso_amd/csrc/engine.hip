@@ -85,6 +85,9 @@ void Engine::free_all()
     stage_send = stage_recv = nullptr; stage_send_bytes = stage_recv_bytes = 0;
     free_fwd_tab();
     comm_free();
+    if (ev_pack) (void)hipEventDestroy(ev_pack);
+    if (ev_halo) (void)hipEventDestroy(ev_halo);
+    ev_pack = ev_halo = nullptr;
     if (h_flags) (void)hipHostFree(h_flags);
     if (h_scalar) (void)hipHostFree(h_scalar);
     h_flags = nullptr; h_scalar = nullptr;
@@ -231,6 +234,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
     if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
     if (key == "fuse_step") { fuse_step = (int)val; return 0; }
+    if (key == "overlap") { overlap = (int)val; return 0; }
     if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
@@ -593,9 +597,9 @@ int Engine::halo_borders()
 }
 
 // Comm::forward_comm + gpu_merge_xvt(ghost range): ghosts arrive as merged float4 pairs
-int Engine::halo_forward_seed(uint32_t sd)
+int Engine::halo_forward_seed(uint32_t sd, bool async)
 {
-    if (nranks > 1) return halo_forward_multi_begin(sd);
+    if (nranks > 1) return halo_forward_multi_begin(sd, async);
     if (nsend <= 0) return 0;
     tbegin("halo");
     launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,
@@ -832,7 +836,8 @@ int Engine::run(int nsteps)
         if (rebuild) { TRY(reneighbor()); merged = false; }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
-        TRY(halo_forward_seed(sd));
+        const bool split = nranks > 1 && overlap && n_bulk > 0 && n_bulk < nlocal;
+        TRY(halo_forward_seed(sd, split));
         PairArgs p;
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
         for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
@@ -841,23 +846,28 @@ int Engine::run(int nsteps)
         p.coeff64 = d_coeff64; p.coeff32 = d_coeff32; p.ntypes = ntypes;
         for (int k = 0; k < 7; k++) p.cf1[k] = coeff[k];
         p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
-        p.beg = 0; p.end = nlocal;
         p.accumulate = fuse_clear ? 0 : 1;
         p.debug = pair_debug;
         p.chunked = layout == 2 ? 1 : 0;
         if (!fuse_clear) TRY(force_clear(0));
-        if (layout == 1 && pair_kernel == 1) {
-            tbegin("pair");
-            launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
-            tend("pair");
-        } else {
-            TRY(ensure_table32());
-            tbegin("pair");
-            if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
-            else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
-            else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
-            else launch_pair_dpd_tile(p, pair_style, stream);
-            tend("pair");
+        // bulk atoms have no ghost partners: their forces are computed while the ghosts are in flight
+        for (int part = 0; part < (split ? 2 : 1); part++) {
+            p.beg = split ? (part == 0 ? 0 : n_bulk) : 0;
+            p.end = split ? (part == 0 ? n_bulk : nlocal) : nlocal;
+            if (split && part == 1) TRY(halo_wait());
+            if (layout == 1 && pair_kernel == 1) {
+                tbegin("pair");
+                launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
+                tend("pair");
+            } else {
+                TRY(ensure_table32());
+                tbegin("pair");
+                if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
+                else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
+                else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
+                else launch_pair_dpd_tile(p, pair_style, stream);
+                tend("pair");
+            }
         }
         if (fuse_step && it + 1 < nsteps) {
             // one pass for final(s) + initial(s+1); the merge for s+1 rides along when s+1 provably keeps the table

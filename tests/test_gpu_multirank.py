@@ -13,7 +13,7 @@ from meso_amd.datagen import make_box
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(nranks, grid, L, style, sigma, steps, every=5):
+def _run_ranks(nranks, grid, L, style, sigma, steps, every=5, overlap=1):
     from meso_amd.api import Meso
     x, v, lo, hi = make_box(L)
     gid = np.frombuffer(np.random.default_rng(nranks * 1000 + L).bytes(8), np.uint8)
@@ -22,6 +22,7 @@ def _run_ranks(nranks, grid, L, style, sigma, steps, every=5):
     def work(r):
         try:
             m = Meso()
+            m.set_option("overlap", overlap)
             if nranks > 1:
                 m.comm_init(nranks, r, grid, "local", gid)
             m.read_atoms(x, v, lo, hi)
@@ -89,6 +90,14 @@ def test_migration_and_rebuilds_conserve_atoms(style):
     assert len({c[0] for c in counts}) > 1                       # populations drifted: migration really happened
     assert np.abs(got1[1].sum(0)).max() < 1e-2
     assert abs(T[0] - Tref[0]) < 0.08 and all(abs(t - T[0]) < 1e-9 for t in T)
+
+
+def test_overlapped_refresh_is_bit_identical():
+    """bulk kernel || ghost exchange on the side stream, then border kernel == one kernel after the exchange."""
+    a = _run_ranks(4, (2, 2, 1), 12, "dpd/meso", 3.0, 12, overlap=0)[1]
+    b = _run_ranks(4, (2, 2, 1), 12, "dpd/meso", 3.0, 12, overlap=1)[1]
+    for u, w in zip(a[:3], b[:3]):
+        assert np.array_equal(u, w)
 
 
 def test_sigma0_trajectory_is_grid_independent():
