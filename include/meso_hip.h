@@ -70,6 +70,16 @@ int meso_pair_dpd_settings(meso_ctx *ctx, int style, double cut_global, int seed
 int meso_pair_dpd_coeff(meso_ctx *ctx, int itype, int jtype, double a0, double gamma, double sigma, double expw,
                         double cut /* <=0: cut_global */);
 
+/* ---- bonded topology (configs[4]): AtomStyle(dpd/bond/meso) atom_vec_dpd_bond_meso.cu:20-45, BondStyle(harmonic/meso)
+ *      bond_harmonic_meso.cu:46-117, exclusions neigh_build_meso.cu:497-569.  Call after meso_atoms_upload, with the
+ *      whole Bonds section on every rank; special_bonds first (weights 0 or 1, default 0 0 0 like src/force.cpp:47-48) */
+int meso_special_bonds(meso_ctx *ctx, double w12, double w13, double w14);
+int meso_bonds_upload(meso_ctx *ctx, int nbonds, const int *tag_i, const int *tag_j, const int *bond_type);
+int meso_bond_style_harmonic(meso_ctx *ctx, int nbondtypes);
+int meso_bond_coeff(meso_ctx *ctx, int type, double k, double r0);
+int meso_bond_compute(meso_ctx *ctx, int eflag);          /* Bond::compute, adds to f */
+int meso_compute_ebond(meso_ctx *ctx, double *e_total);
+
 /* ---- timestep, fix nve/meso group */
 int meso_timestep(meso_ctx *ctx, double dt);
 

@@ -97,6 +97,27 @@ void MesoHipPairDPD::compute(int eflag, int vflag) { MESO(meso_pair_compute(Meso
 void MesoHipPairDPD::compute_bulk(int eflag, int vflag) { MESO(meso_pair_compute(MesoHipContext::get(lmp), MESO_RANGE_BULK, eflag, vflag)); }
 void MesoHipPairDPD::compute_border(int eflag, int vflag) { MESO(meso_pair_compute(MesoHipContext::get(lmp), MESO_RANGE_BORDER, eflag, vflag)); }
 
+/* ---------------------------------------------------------------------- bond harmonic/meso */
+
+void MesoHipBondHarmonic::compute(int eflag, int) { MESO(meso_bond_compute(MesoHipContext::get(lmp), eflag)); }
+
+void MesoHipBondHarmonic::coeff(int narg, char **arg)
+{
+  if (narg != 3) error->all(FLERR, "Incorrect args for bond coefficients");
+  if (!allocated) {
+    allocated = 1;
+    memory->create(setflag, atom->nbondtypes + 1, "bond:setflag");
+    for (int i = 1; i <= atom->nbondtypes; i++) setflag[i] = 0;
+    MESO(meso_bond_style_harmonic(MesoHipContext::get(lmp), atom->nbondtypes));
+  }
+  int ilo, ihi;
+  force->bounds(arg[0], atom->nbondtypes, ilo, ihi);
+  for (int i = ilo; i <= ihi; i++) {
+    MESO(meso_bond_coeff(MesoHipContext::get(lmp), i, atof(arg[1]), atof(arg[2])));
+    setflag[i] = 1;
+  }
+}
+
 /* ---------------------------------------------------------------------- fix nve/meso */
 
 MesoHipFixNVE::MesoHipFixNVE(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg)
@@ -148,6 +169,22 @@ void MesoHipIntegrate::upload()
   MESO(meso_timestep(c, update->dt));
   /* each rank hands over the atoms it owns; x[0]/v[0] are the contiguous double[n][3] blocks LAMMPS allocates */
   MESO(meso_atoms_upload(c, atom->nlocal, atom->x[0], atom->v[0], atom->tag, atom->type, atom->mask, atom->image));
+  if (atom->molecular && atom->bond_per_atom > 0) {
+    /* flatten the per-atom bond lists (each bond once: tag < partner when newton_bond is off both atoms store it) */
+    int nb = 0;
+    for (int i = 0; i < atom->nlocal; i++) nb += atom->num_bond[i];
+    int *ti = new int[nb + 1], *tj = new int[nb + 1], *bt = new int[nb + 1];
+    int m = 0;
+    for (int i = 0; i < atom->nlocal; i++)
+      for (int b = 0; b < atom->num_bond[i]; b++)
+        if (atom->tag[i] < atom->bond_atom[i][b] || force->newton_bond) {
+          ti[m] = atom->tag[i]; tj[m] = atom->bond_atom[i][b]; bt[m] = atom->bond_type[i][b]; m++;
+        }
+    /* one rank: the list is complete; several ranks: MPI_Allgatherv the three arrays before this call */
+    MESO(meso_special_bonds(c, force->special_lj[1], force->special_lj[2], force->special_lj[3]));
+    MESO(meso_bonds_upload(c, m, ti, tj, bt));
+    delete [] ti; delete [] tj; delete [] bt;
+  }
 }
 
 void MesoHipIntegrate::download()

@@ -17,6 +17,8 @@
 #ifdef PAIR_CLASS
 PairStyle(dpd/meso,MesoHipPairDPD)
 PairStyle(dpd/fast/meso,MesoHipPairDPDFast)
+#elif defined(BOND_CLASS)
+BondStyle(harmonic/meso,MesoHipBondHarmonic)
 #elif defined(FIX_CLASS)
 FixStyle(nve/meso,MesoHipFixNVE)
 #elif defined(COMPUTE_CLASS)
@@ -29,6 +31,7 @@ IntegrateStyle(verlet/meso,MesoHipIntegrate)
 #ifndef LMP_MESO_HIP_GLUE_H
 #define LMP_MESO_HIP_GLUE_H
 
+#include "bond.h"
 #include "compute.h"
 #include "fix.h"
 #include "integrate.h"
@@ -64,6 +67,19 @@ class MesoHipPairDPD : public Pair {
 class MesoHipPairDPDFast : public MesoHipPairDPD {
  public:
   MesoHipPairDPDFast(class LAMMPS *);
+};
+
+/* bond_style harmonic/meso (replaces MesoBondHarmonic, bond_harmonic_meso.h:3); the Bonds section is handed over once by
+   MesoHipIntegrate::upload through meso_bonds_upload (after meso_special_bonds with force->special_lj[1..3]) */
+class MesoHipBondHarmonic : public Bond {
+ public:
+  MesoHipBondHarmonic(class LAMMPS *lmp) : Bond(lmp) {}
+  void compute(int, int);              /* meso_bond_compute */
+  void coeff(int, char **);            /* bond_coeff type K r0 -> meso_bond_coeff */
+  double equilibrium_distance(int) { return 0.0; }
+  void write_restart(FILE *) {}
+  void read_restart(FILE *) {}
+  double single(int, double, int, int, double &) { return 0.0; }
 };
 
 class MesoHipFixNVE : public Fix {

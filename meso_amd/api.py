@@ -143,6 +143,33 @@ class Meso:
     def pair_coeff(self, i, j, a0, gamma, sigma, expw, cut=0.0):
         self._ck(self.lib.meso_pair_dpd_coeff(self._h, i, j, a0, gamma, sigma, expw, cut))
 
+    # -- bonded topology: atom_style dpd/bond/meso, bond_style harmonic/meso ---------------------
+    def special_bonds(self, w12=0.0, w13=0.0, w14=0.0):
+        self._ck(self.lib.meso_special_bonds(self._h, w12, w13, w14))
+
+    def read_bonds(self, bonds):
+        """bonds: (nb,3) int array of (tag_i, tag_j, type) - the Bonds section of the data file."""
+        b = np.ascontiguousarray(bonds, np.int32).reshape(-1, 3)
+        ti, tj, bt = (np.ascontiguousarray(b[:, k]) for k in range(3))
+        self._ck(self.lib.meso_bonds_upload(self._h, len(b), _p(ti), _p(tj), _p(bt)))
+        self._setup_done = False
+
+    def bond_style(self, style, nbondtypes):
+        if style != "harmonic/meso":
+            raise MesoError("Unknown bond style " + style)
+        self._ck(self.lib.meso_bond_style_harmonic(self._h, nbondtypes))
+
+    def bond_coeff(self, btype, k, r0):
+        self._ck(self.lib.meso_bond_coeff(self._h, btype, k, r0))
+
+    def bond_compute(self, eflag=0):
+        self._ck(self.lib.meso_bond_compute(self._h, eflag))
+
+    def ebond(self):
+        t = C.c_double()
+        self._ck(self.lib.meso_compute_ebond(self._h, C.byref(t)))
+        return t.value
+
     def fix_nve(self):
         pass  # fix nve/meso is the only integrator fix on this path; always active
 

@@ -279,9 +279,10 @@ __global__ void __launch_bounds__(256) k_migrate_code(const double *__restrict__
     code[i] = (s[0] + 1) + 3 * (s[1] + 1) + 9 * (s[2] + 1);
 }
 
-// 8 doubles per migrant: x,y,z,vx,vy,vz,(tag,type),(mask,image)
+// ms doubles per migrant: x,y,z,vx,vy,vz,(tag,type),(mask,image) [+ nbond, nspecial, bond tags/types, special tags]
 __global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
-                                                      const int *__restrict__ dir_dst, int n0, int n, double *__restrict__ buf)
+                                                      const int *__restrict__ dir_dst, int n0, int n, int ms,
+                                                      double *__restrict__ buf)
 {
     // entries [n0, n0+n) of the direction-major list, skipping the stay segment handled by the caller
     int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,20 +292,26 @@ __global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__re
     for (int t = 1; t < 27; t++) d += (k >= dir_start[t]) ? 1 : 0;
     int dst = dir_dst[d] + (k - dir_start[d]);
     int j = list[k];
-    double *o = buf + 8 * (size_t)dst;
+    double *o = buf + (size_t)ms * dst;
     o[0] = a.x[0][j]; o[1] = a.x[1][j]; o[2] = a.x[2][j];
     o[3] = a.v[0][j]; o[4] = a.v[1][j]; o[5] = a.v[2][j];
     int2 p = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], a.image[j]);
     o[6] = *reinterpret_cast<double *>(&p);
     o[7] = *reinterpret_cast<double *>(&r);
+    if (a.bpa > 0 || a.msp > 0) {
+        int *t = reinterpret_cast<int *>(o + 8);
+        t[0] = a.nbond[j]; t[1] = a.nspecial[j];
+        for (int b = 0; b < a.bpa; b++) { t[2 + 2 * b] = a.bond_tag[(size_t)j * a.bpa + b]; t[3 + 2 * b] = a.bond_type[(size_t)j * a.bpa + b]; }
+        for (int s = 0; s < a.msp; s++) t[2 + 2 * a.bpa + s] = a.special[(size_t)j * a.msp + s];
+    }
 }
 
 __global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double *__restrict__ buf, const double *__restrict__ mass_type,
-                                                        int base, int n)
+                                                        int base, int n, int ms)
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    const double *o = buf + 8 * (size_t)q;
+    const double *o = buf + (size_t)ms * q;
     int i = base + q;
     a.x[0][i] = o[0]; a.x[1][i] = o[1]; a.x[2][i] = o[2];
     a.v[0][i] = o[3]; a.v[1][i] = o[4]; a.v[2][i] = o[5];
@@ -313,6 +320,12 @@ __global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double 
     int2 p = *reinterpret_cast<int2 *>(&t6), r = *reinterpret_cast<int2 *>(&t7);
     a.tag[i] = p.x; a.type[i] = p.y; a.mask[i] = r.x; a.image[i] = r.y;
     a.mass[i] = mass_type[p.y];
+    if (a.bpa > 0 || a.msp > 0) {
+        const int *t = reinterpret_cast<const int *>(o + 8);
+        a.nbond[i] = t[0]; a.nspecial[i] = t[1];
+        for (int b = 0; b < a.bpa; b++) { a.bond_tag[(size_t)i * a.bpa + b] = t[2 + 2 * b]; a.bond_type[(size_t)i * a.bpa + b] = t[3 + 2 * b]; }
+        for (int s = 0; s < a.msp; s++) a.special[(size_t)i * a.msp + s] = t[2 + 2 * a.bpa + s];
+    }
 }
 
 struct DirTab {
@@ -530,7 +543,8 @@ int Engine::migrate()
     int np = (int)peers.size(), nsend_tot = 0, nrecv_tot = 0;
     std::vector<int> sbase(np, 0), rbase(np, 0);
     for (int p = 0; p < np; p++) { sbase[p] = nsend_tot; nsend_tot += send_n[p]; rbase[p] = nrecv_tot; nrecv_tot += recv_n[p]; }
-    TRY(ensure_stage((size_t)std::max(nsend_tot, 1) * 8 * sizeof(double), (size_t)std::max(nrecv_tot, 1) * 8 * sizeof(double)));
+    const int ms = mig_stride();
+    TRY(ensure_stage((size_t)std::max(nsend_tot, 1) * ms * sizeof(double), (size_t)std::max(nrecv_tot, 1) * ms * sizeof(double)));
     if (nsend_tot > 0) {
         // destination slot of each direction's segment in the peer-major buffer
         std::vector<int> fill(sbase);
@@ -546,11 +560,11 @@ int Engine::migrate()
         // segments before and after the stay segment
         if (ds[13] > 0)
             hipLaunchKernelGGL(k_pack_migrate, dim3((ds[13] + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start,
-                               sendlist_aux, 0, ds[13], (double *)stage_send);
+                               sendlist_aux, 0, ds[13], ms, (double *)stage_send);
         int tail = ds[27] - ds[14];
         if (tail > 0)
             hipLaunchKernelGGL(k_pack_migrate, dim3((tail + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start,
-                               sendlist_aux, ds[14], tail, (double *)stage_send);
+                               sendlist_aux, ds[14], tail, ms, (double *)stage_send);
     }
     // compact the stayers (their order is preserved; the reorder sort follows anyway)
     if (nstay != nlocal) {
@@ -561,13 +575,13 @@ int Engine::migrate()
     std::vector<void *> sb(np), rb(np);
     std::vector<size_t> sn(np), rn(np);
     for (int p = 0; p < np; p++) {
-        sb[p] = (double *)stage_send + 8 * (size_t)sbase[p]; sn[p] = (size_t)send_n[p] * 8 * sizeof(double);
-        rb[p] = (double *)stage_recv + 8 * (size_t)rbase[p]; rn[p] = (size_t)recv_n[p] * 8 * sizeof(double);
+        sb[p] = (double *)stage_send + (size_t)ms * sbase[p]; sn[p] = (size_t)send_n[p] * ms * sizeof(double);
+        rb[p] = (double *)stage_recv + (size_t)ms * rbase[p]; rn[p] = (size_t)recv_n[p] * ms * sizeof(double);
     }
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
     if (nrecv_tot > 0)
         hipLaunchKernelGGL(k_unpack_migrate, dim3((nrecv_tot + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
-                           d_mass_type, nstay, nrecv_tot);
+                           d_mass_type, nstay, nrecv_tot, ms);
     nlocal = nstay + nrecv_tot;
     tend("migrate");
     return 0;

@@ -39,6 +39,12 @@ public:
                      const int *image);
     int atoms_download(double *x, double *v, double *f, int *tag, int *type, int *image);
     int neighbor(double skin, int every, int delay, int check);
+    int bonds_upload(int nbonds, const int *tag_i, const int *tag_j, const int *btype);
+    int special_bonds(double w12, double w13, double w14);
+    int bond_style(int nbondtypes);
+    int bond_coeff(int type, double k, double r0);
+    int bond_compute(int eflag);
+    int compute_ebond(double *e);
     int pair_settings(int style, double cut, int seed);
     int pair_coeff(int i, int j, double a0, double gamma, double sigma, double expw, double cut);
     int set_option(const std::string &key, double val);
@@ -202,6 +208,18 @@ private:
     int *d_dir_start = nullptr;
     int h_dir_start[28];
     int nsend = 0;
+
+    // bonded topology
+    int bpa = 0, msp = 0, nbondtypes = 0, maxtag = 0;
+    double special_w[3] = {0.0, 0.0, 0.0};
+    std::vector<double> bond_kr0;            // [k(0..nbt)][r0(0..nbt)]
+    std::vector<int> h_tags;                 // tags of the atoms kept at upload (topology is attached by tag)
+    double *d_bond_kr0 = nullptr, *e_bond = nullptr;
+    int *bond_idx = nullptr, *tagmap = nullptr, *tagc = nullptr;
+    bool have_bonds = false;
+    int alloc_topology(AtomSoA &a, int cap, int keep);
+    int rebuild_topology();
+    int mig_stride() const { return 8 + (2 + 2 * bpa + msp + 1) / 2; }
 
     // scalars
     double *d_partial = nullptr, *d_scalar = nullptr;

@@ -62,6 +62,7 @@ static void free_soa(AtomSoA &a)
 {
     for (int d = 0; d < 3; d++) { dfree(a.x[d]); dfree(a.v[d]); dfree(a.f[d]); }
     dfree(a.tag); dfree(a.type); dfree(a.mask); dfree(a.image); dfree(a.mass);
+    dfree(a.nbond); dfree(a.bond_tag); dfree(a.bond_type); dfree(a.nspecial); dfree(a.special);
 }
 
 void Engine::free_all()
@@ -70,6 +71,7 @@ void Engine::free_all()
     free_soa(cur); free_soa(alt);
     dfree(coord4); dfree(veloc4);
     for (int k = 0; k < 6; k++) dfree(virial[k]);
+    dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32);
     dfree(pair_count); dfree(pair_table);
     dfree(bin_id); dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(bin_start);
@@ -291,6 +293,13 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(cur.mask, keep, c, stream)); HIPCHK(regrow(alt.mask, 0, c, stream));
     HIPCHK(regrow(cur.image, keep, c, stream)); HIPCHK(regrow(alt.image, 0, c, stream));
     HIPCHK(regrow(cur.mass, keep, c, stream)); HIPCHK(regrow(alt.mass, 0, c, stream));
+    if (bpa > 0 || msp > 0) {
+        TRY(alloc_topology(cur, cap, nlocal));
+        TRY(alloc_topology(alt, cap, 0));
+        HIPCHK(regrow(bond_idx, 0, c * (size_t)std::max(bpa, 1), stream));
+        HIPCHK(regrow(tagc, 0, c, stream));
+        HIPCHK(regrow(e_bond, 0, c, stream));
+    }
     HIPCHK(regrow(coord4, 0, c, stream)); HIPCHK(regrow(veloc4, 0, c, stream));
     for (int k = 0; k < 6; k++) HIPCHK(regrow(virial[k], 0, c, stream));
     HIPCHK(regrow(e_pair, 0, c, stream));
@@ -322,6 +331,153 @@ int Engine::alloc_atoms(int cap)
         HIPCHK(dalloc(table16, table_tiles * 64 * (size_t)n_col));
     }
     nmax = cap;
+    return 0;
+}
+
+int Engine::alloc_topology(AtomSoA &a, int cap, int keep)
+{
+    size_t c = (size_t)cap, k = (size_t)keep;
+    a.bpa = bpa; a.msp = msp;
+    HIPCHK(regrow(a.nbond, k, c, stream));
+    HIPCHK(regrow(a.bond_tag, k * std::max(bpa, 1), c * std::max(bpa, 1), stream));
+    HIPCHK(regrow(a.bond_type, k * std::max(bpa, 1), c * std::max(bpa, 1), stream));
+    HIPCHK(regrow(a.nspecial, k, c, stream));
+    HIPCHK(regrow(a.special, k * std::max(msp, 1), c * std::max(msp, 1), stream));
+    return 0;
+}
+
+// special_bonds lj w12 w13 w14: like filter_exclusion_meso (neigh_build_meso.cu:546-569) a level is either kept or
+// removed from the pair rows; fractional weights are not supported on this path
+int Engine::special_bonds(double w12, double w13, double w14)
+{
+    if (have_bonds) return fail(3, "special_bonds must precede the bond list");
+    special_w[0] = w12; special_w[1] = w13; special_w[2] = w14;
+    for (int k = 0; k < 3; k++)
+        if (special_w[k] != 0.0 && special_w[k] != 1.0) return fail(1, "special_bonds weights must be 0 or 1 on the meso path");
+    return 0;
+}
+
+int Engine::bond_style(int nbt)
+{
+    if (nbt < 1) return fail(1, "Illegal bond_style command");
+    nbondtypes = nbt;
+    bond_kr0.assign(2 * (size_t)(nbt + 1), 0.0);
+    return 0;
+}
+
+// BondHarmonic::coeff (src/MOLECULE/bond_harmonic.cpp): bond_coeff type K r0
+int Engine::bond_coeff(int type, double k, double r0)
+{
+    if (nbondtypes == 0) return fail(3, "bond_coeff before bond_style");
+    if (type < 1 || type > nbondtypes) return fail(1, "Incorrect args for bond coefficients");
+    bond_kr0[type] = k;
+    bond_kr0[nbondtypes + 1 + type] = r0;
+    dfree(d_bond_kr0);
+    return 0;
+}
+
+// Bonds section of the data file: (tag_i, tag_j, type).  Every rank is handed the whole list and keeps, for the
+// atoms it owns, the bond on BOTH atoms (newton off, atom_vec_dpd_bond_meso.cu) plus the 1-2/1-3/1-4 partner tags
+// of the levels that special_bonds removes (Special::build, src/special.cpp).
+int Engine::bonds_upload(int nb, const int *ti, const int *tj, const int *bt)
+{
+    if (nb < 0 || (nb && (!ti || !tj || !bt))) return fail(1, "Invalid bond arrays");
+    if (nlocal > 0 && h_tags.empty()) return fail(3, "Bonds must follow the atoms");
+    maxtag = 0;
+    for (int b = 0; b < nb; b++) maxtag = std::max(maxtag, std::max(ti[b], tj[b]));
+    for (int t : h_tags) maxtag = std::max(maxtag, t);
+    std::vector<std::vector<std::pair<int, int>>> adj((size_t)maxtag + 1);
+    for (int b = 0; b < nb; b++) {
+        if (ti[b] < 1 || tj[b] < 1 || ti[b] == tj[b]) return fail(1, "Invalid atom ID in Bonds section of data file");
+        if (nbondtypes && (bt[b] < 1 || bt[b] > nbondtypes)) return fail(1, "Invalid bond type in Bonds section of data file");
+        adj[ti[b]].push_back(std::make_pair(tj[b], bt[b]));
+        adj[tj[b]].push_back(std::make_pair(ti[b], bt[b]));
+    }
+    int excl_levels = 0;   // consecutive levels with weight 0, starting at 1-2
+    while (excl_levels < 3 && special_w[excl_levels] == 0.0) excl_levels++;
+    // special partners by breadth-first search to depth excl_levels
+    auto specials = [&](int t) {
+        std::vector<int> out, frontier(1, t), seen(1, t);
+        for (int lev = 0; lev < excl_levels; lev++) {
+            std::vector<int> next;
+            for (int u : frontier)
+                for (auto &pr : adj[u])
+                    if (std::find(seen.begin(), seen.end(), pr.first) == seen.end()) { seen.push_back(pr.first); next.push_back(pr.first); out.push_back(pr.first); }
+            frontier.swap(next);
+        }
+        return out;
+    };
+    // array widths come from the WHOLE list (every rank holds it), so all ranks agree on the message layout
+    int new_bpa = 0, new_msp = 0;
+    for (int t = 1; t <= maxtag; t++) {
+        if (adj[t].empty()) continue;
+        new_bpa = std::max(new_bpa, (int)adj[t].size());
+        new_msp = std::max(new_msp, (int)specials(t).size());
+    }
+    int n = nlocal;
+    std::vector<std::vector<int>> spec((size_t)n);
+    for (int i = 0; i < n; i++) spec[i] = specials(h_tags[i]);
+    bpa = std::max(new_bpa, 1); msp = std::max(new_msp, 1);
+    TRY(alloc_atoms(std::max(nmax, 1024)));   // (re)allocates with the topology arrays
+    std::vector<int> hn((size_t)n, 0), hbt((size_t)n * bpa, 0), hty((size_t)n * bpa, 0), hs((size_t)n, 0), hsp((size_t)n * msp, 0);
+    for (int i = 0; i < n; i++) {
+        auto &a = adj[h_tags[i]];
+        hn[i] = (int)a.size();
+        for (size_t b = 0; b < a.size(); b++) { hbt[(size_t)i * bpa + b] = a[b].first; hty[(size_t)i * bpa + b] = a[b].second; }
+        hs[i] = (int)spec[i].size();
+        for (size_t s = 0; s < spec[i].size(); s++) hsp[(size_t)i * msp + s] = spec[i][s];
+    }
+    if (n) {
+        HIPCHK(hipMemcpy(cur.nbond, hn.data(), hn.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(cur.bond_tag, hbt.data(), hbt.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(cur.bond_type, hty.data(), hty.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(cur.nspecial, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(cur.special, hsp.data(), hsp.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    dfree(tagmap);
+    HIPCHK(dalloc(tagmap, (size_t)maxtag + 2));
+    have_bonds = true;
+    is_setup = false;
+    return 0;
+}
+
+// map_set_device + bond_all (atom_meso.cu:108-126, neighbor_meso.cu:130-): after every rebuild
+int Engine::rebuild_topology()
+{
+    if (!have_bonds) return 0;
+    int nall = nlocal + nghost;
+    launch_tag_cell(cur.tag, layout >= 1 ? gslot : nullptr, nlocal, nghost, tagc, stream);
+    HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
+    launch_set_map(tagc, nall, maxtag, tagmap, stream);
+    HIPCHK(hipMemsetAsync(d_flags + 4, 0, sizeof(int), stream));
+    launch_map_bonds(cur.nbond, cur.bond_tag, bpa, tagmap, maxtag, nlocal, bond_idx, d_flags + 4, stream);
+    return 0;
+}
+
+// BondHarmonic::compute / gpu_bond_harmonic (bond_harmonic_meso.cu:46-117)
+int Engine::bond_compute(int eflag)
+{
+    if (!have_bonds || nbondtypes == 0) return 0;
+    if (!d_bond_kr0) {
+        HIPCHK(dalloc(d_bond_kr0, bond_kr0.size()));
+        HIPCHK(hipMemcpy(d_bond_kr0, bond_kr0.data(), bond_kr0.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    tbegin("bond");
+    launch_bond_harmonic(coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, cur.f[0],
+                         cur.f[1], cur.f[2], eflag ? e_bond : nullptr, stream);
+    tend("bond");
+    return 0;
+}
+
+int Engine::compute_ebond(double *e)
+{
+    if (!have_bonds) { *e = 0.0; return 0; }
+    std::vector<double> h((size_t)nlocal);
+    HIPCHK(hipMemcpyAsync(h.data(), e_bond, nlocal * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    double s = 0.0;
+    for (double v : h) s += v;
+    *e = reduce_global_sum(s);
     return 0;
 }
 
@@ -380,6 +536,8 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
     HIPCHK(hipMemcpy(cur.image, image ? image : itmp.data(), n * sizeof(int), hipMemcpyHostToDevice));
     for (int i = 0; i < n; i++)
         if (type[i] < 1 || (ntypes && type[i] > ntypes)) return fail(1, "Invalid atom type in atom arrays");
+    h_tags.assign(tag, tag + n);
+    have_bonds = false;
     nlocal = n;
     nghost = 0;
     n_bulk = 0;
@@ -642,6 +800,7 @@ int Engine::build_cells_and_table()
         tend("bin");
         TRY(merge_locals(0));
         TRY(halo_forward_seed(0));
+        TRY(rebuild_topology());
         if (layout == 1) {
             HIPCHK(hipStreamSynchronize(stream));
             bargs.active = brick_active;
@@ -653,8 +812,10 @@ int Engine::build_cells_and_table()
         } else {
             tbegin("neigh");
             launch_bin_ranges(estart, gstart, bargs.M, nlocal, binrange, stream);
+            ExclArgs ex = {nullptr, nullptr, nullptr, 0};
+            if (have_bonds && msp > 0) { ex.tagc = tagc; ex.nspecial = cur.nspecial; ex.special = cur.special; ex.msp = msp; }
             launch_cell_build(coord4, rkey, reorder_sub_bits(geom), binrange, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count, pair_table,
-                              d_flags, stream);
+                              d_flags, have_bonds ? &ex : nullptr, stream);
             tend("neigh");
             table32_valid = true;
         }
@@ -696,8 +857,9 @@ int Engine::ensure_table32()
 
 int Engine::check_overflow()
 {
-    HIPCHK(hipMemcpyAsync(h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 5 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    if (have_bonds && h_flags[4]) return fail(4, "Bond atoms missing: a bonded partner is outside the ghost cutoff");
     if (h_flags[0]) {
         char buf[200];
         if (h_flags[0] >= 100000)
@@ -812,12 +974,14 @@ int Engine::pair_compute(int r, int eflag, int vflag)
 int Engine::setup()
 {
     if (nlocal <= 0 && nranks == 1) return fail(3, "No atoms have been uploaded");
+    if (have_bonds && layout != 2) return fail(3, "bonded topology needs the cell-ordered layout (layout=2)");
     TRY(init_params());
     TRY(reneighbor());
     nbuild = 0;
     TRY(force_clear(0));
     for (int k = 0; k < 6; k++) launch_fill_f64(virial[k], 0.0, nlocal, stream);
     TRY(pair_compute(0, 1, 1));
+    TRY(bond_compute(1));
     TRY(check_overflow());
     is_setup = true;
     return 0;
@@ -869,6 +1033,7 @@ int Engine::run(int nsteps)
                 tend("pair");
             }
         }
+        TRY(bond_compute(0));
         if (fuse_step && it + 1 < nsteps) {
             // one pass for final(s) + initial(s+1); the merge for s+1 rides along when s+1 provably keeps the table
             const int a1 = ago + 1;

@@ -19,6 +19,9 @@ struct AtomSoA {
     double *x[3], *v[3], *f[3];
     int *tag, *type, *mask, *image;
     double *mass;
+    // bonded topology, per atom (null / 0 for atom_style dpd/atomic/meso): bond_tag[i*bpa+b], special[i*msp+s]
+    int *nbond, *bond_tag, *bond_type, *nspecial, *special;
+    int bpa, msp;
 };
 
 struct HaloShift { double prd[3]; };
@@ -114,9 +117,10 @@ void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
 void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s);
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
 void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
+struct ExclArgs;
 void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key_shift, const int4 *binrange, int M,
                        const int *mbin, float rc2, int nlocal, int n_col, int *count, int *table, int *overflow,
-                       hipStream_t s);
+                       const ExclArgs *excl, hipStream_t s);
 // wave-per-tile, ballot-compacted variant (forces only)
 void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s);
 
@@ -143,6 +147,19 @@ void launch_brick_convert(const BrickArgs &g, int n_col, const int *count, const
                           int *table32, int *overflow, hipStream_t s);
 void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, int fast,
                        int *overflow, hipStream_t s);
+
+// ---- bonded topology (bond.hip) -----------------------------------------------------------------------
+void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, int *tagc, hipStream_t s);
+void launch_set_map(const int *tagc, int nall, int maxtag, int *map, hipStream_t s);
+void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int *map, int maxtag, int nlocal,
+                      int *bond_idx, int *missing, hipStream_t s);
+void launch_bond_harmonic(const float4 *coord4, const int *nbond, const int *bond_idx, const int *bond_type, int bpa,
+                          const double *kr0, int nbt, const double *prd, int nlocal, double *fx, double *fy,
+                          double *fz, double *e_bond, hipStream_t s);
+struct ExclArgs {            // special-partner filter of the list builder (null tagc: no exclusions)
+    const int *tagc, *nspecial, *special;
+    int msp;
+};
 
 // ---- unit kernels for known-answer tests --------------------------------------------------------------
 void launch_test_tea(const uint32_t *u, const uint32_t *v, int n, int rounds, uint32_t *out0, uint32_t *out1,

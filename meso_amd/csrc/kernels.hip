@@ -399,6 +399,17 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
     dst.mask[i] = src.mask[j];
     dst.image[i] = src.image[j];
     dst.mass[i] = src.mass[j];
+    if (src.bpa > 0) {
+        dst.nbond[i] = src.nbond[j];
+        for (int b = 0; b < src.bpa; b++) {
+            dst.bond_tag[(size_t)i * src.bpa + b] = src.bond_tag[(size_t)j * src.bpa + b];
+            dst.bond_type[(size_t)i * src.bpa + b] = src.bond_type[(size_t)j * src.bpa + b];
+        }
+    }
+    if (src.msp > 0) {
+        dst.nspecial[i] = src.nspecial[j];
+        for (int s = 0; s < src.msp; s++) dst.special[(size_t)i * src.msp + s] = src.special[(size_t)j * src.msp + s];
+    }
 }
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, hipStream_t s)
 {
@@ -1017,11 +1028,20 @@ void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, 
 #define CELL_TEST(kk, cc)                                                        \
     {                                                                            \
         float d_ = dist2(ci, cc);                                                \
-        if ((kk) != i && d_ <= rc2) CELL_PUSH(kk)                                \
+        if ((kk) != i && d_ <= rc2 && !(nsp && cell_excluded(ex, i, nsp, (kk)))) CELL_PUSH(kk) \
     }
 
+// gpu_filter_exclusion (neigh_build_meso.cu:497-544): drop special partners by tag
+__device__ inline bool cell_excluded(const ExclArgs &ex, int i, int nsp, int k)
+{
+    const int t = ex.tagc[k];
+    bool hit = false;
+    for (int s = 0; s < nsp; s++) hit |= ex.special[(size_t)i * ex.msp + s] == t;
+    return hit;
+}
+
 __device__ inline void cell_run(const float4 *__restrict__ coord4, int kb, int ke, const float4 ci, int i, float rc2,
-                                int n_col, int4 *__restrict__ rows, int *stage, int &n)
+                                int n_col, int4 *__restrict__ rows, int *stage, int &n, const ExclArgs &ex, int nsp)
 {
     int k = kb;
     for (; k + 4 <= ke; k += 4) {     // four independent loads in flight per lane
@@ -1038,7 +1058,7 @@ __global__ void __launch_bounds__(256) k_cell_build(const float4 *__restrict__ c
                                                     int key_shift, const int4 *__restrict__ binrange, int M, int mbx,
                                                     int mby, int mbz, float rc2, int nlocal, int n_col,
                                                     int *__restrict__ count, int *__restrict__ table,
-                                                    int *__restrict__ overflow)
+                                                    int *__restrict__ overflow, ExclArgs ex)
 {
     __shared__ int stage[8 * 256];
     const int nbk = gridDim.x;
@@ -1050,6 +1070,7 @@ __global__ void __launch_bounds__(256) k_cell_build(const float4 *__restrict__ c
     const int bx = (int)compact3b(m), by = (int)compact3b(m >> 1), bz = (int)compact3b(m >> 2);
     int4 *rows = (int4 *)table;
     int n = 0;
+    const int nsp = ex.tagc ? ex.nspecial[i] : 0;
     // one (dy,dz) row of three x-adjacent bins at a time; the six range words of the NEXT row are requested
     // before the current row's candidates are walked, so the dependent bin->range->atoms chain overlaps
     int4 ra[3], rb[3];
@@ -1075,9 +1096,9 @@ __global__ void __launch_bounds__(256) k_cell_build(const float4 *__restrict__ c
         fetch(r + 1, na, nb);
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            cell_run(coord4, ra[t].x, ra[t].y, ci, i, rc2, n_col, rows, stage, n);
-            if (ra[t].w > ra[t].z) cell_run(coord4, ra[t].z, ra[t].w, ci, i, rc2, n_col, rows, stage, n);
-            if (rb[t].y > rb[t].x) cell_run(coord4, rb[t].x, rb[t].y, ci, i, rc2, n_col, rows, stage, n);
+            cell_run(coord4, ra[t].x, ra[t].y, ci, i, rc2, n_col, rows, stage, n, ex, nsp);
+            if (ra[t].w > ra[t].z) cell_run(coord4, ra[t].z, ra[t].w, ci, i, rc2, n_col, rows, stage, n, ex, nsp);
+            if (rb[t].y > rb[t].x) cell_run(coord4, rb[t].x, rb[t].y, ci, i, rc2, n_col, rows, stage, n, ex, nsp);
         }
 #pragma unroll
         for (int t = 0; t < 3; t++) { ra[t] = na[t]; rb[t] = nb[t]; }
@@ -1097,12 +1118,14 @@ __global__ void __launch_bounds__(256) k_cell_build(const float4 *__restrict__ c
 
 void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key_shift, const int4 *binrange, int M,
                        const int *mbin, float rc2, int nlocal, int n_col, int *count, int *table, int *overflow,
-                       hipStream_t s)
+                       const ExclArgs *excl, hipStream_t s)
 {
     if (nlocal <= 0) return;
     int g = (nblk(nlocal, 256) + 7) / 8 * 8;
+    ExclArgs ex = {nullptr, nullptr, nullptr, 0};
+    if (excl) ex = *excl;
     hipLaunchKernelGGL(k_cell_build, dim3(g), dim3(256), 0, s, coord4, sorted_key, key_shift, binrange, M, mbin[0], mbin[1],
-                       mbin[2], rc2, nlocal, n_col, count, table, overflow);
+                       mbin[2], rc2, nlocal, n_col, count, table, overflow, ex);
 }
 
 // pair force v3: lane per atom like v1, but the row is consumed 8 entries at a time -- 8 index loads, then 8

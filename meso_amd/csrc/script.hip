@@ -65,6 +65,9 @@ struct Deck {
     int periodic[3] = {1, 1, 1};
     std::vector<double> x, v, mass;
     std::vector<int> tag, type;
+    int nbonds = 0, nbondtypes = 0;
+    std::vector<int> bond_i, bond_j, bond_t;
+    bool bonds_sent = false;
     bool have_atoms = false, uploaded = false, is_setup = false;
     int thermo_every = 0;
     std::string atom_style, run_style;
@@ -105,8 +108,19 @@ int read_data(Engine &E, Deck &D, const std::string &path)
             D.hi[d] = atof(w[1].c_str());
             continue;
         }
-        if (w.size() >= 2 && (w[1] == "bonds" || w[1] == "angles" || w[1] == "dihedrals" || w[1] == "impropers")) continue;
+        if (w.size() == 2 && w[1] == "bonds") { D.nbonds = atoi(w[0].c_str()); continue; }
+        if (w.size() == 3 && w[1] == "bond" && w[2] == "types") { D.nbondtypes = atoi(w[0].c_str()); continue; }
+        if (w.size() >= 2 && (w[1] == "angles" || w[1] == "dihedrals" || w[1] == "impropers")) continue;
         if (w.size() == 3 && w[2] == "types") continue;
+        if (w[0] == "Bonds") {
+            D.bond_i.resize(D.nbonds); D.bond_j.resize(D.nbonds); D.bond_t.resize(D.nbonds);
+            for (int b = 0; b < D.nbonds; b++) {
+                long id; int t, a1, a2;
+                if (!(f >> id >> t >> a1 >> a2)) { E.err = "Unexpected end of data file"; return 1; }
+                D.bond_t[b] = t; D.bond_i[b] = a1; D.bond_j[b] = a2;
+            }
+            continue;
+        }
         if (w[0] == "Masses" || w[0] == "Atoms" || w[0] == "Velocities") {
             section = w[0];
             if (section == "Atoms") {
@@ -115,9 +129,11 @@ int read_data(Engine &E, Deck &D, const std::string &path)
                 D.v.assign((size_t)3 * D.natoms, 0.0);
                 D.tag.resize(D.natoms);
                 D.type.resize(D.natoms);
+                const bool molecular = D.atom_style == "dpd/bond/meso" || D.atom_style == "bond";
                 for (int i = 0; i < D.natoms; i++) {
-                    long id; int t; double a, b, c;
-                    if (!(f >> id >> t >> a >> b >> c)) { E.err = "Unexpected end of data file"; return 1; }
+                    long id, mol = 0; int t; double a, b, c;
+                    if (molecular) { if (!(f >> id >> mol >> t >> a >> b >> c)) { E.err = "Unexpected end of data file"; return 1; } }
+                    else if (!(f >> id >> t >> a >> b >> c)) { E.err = "Unexpected end of data file"; return 1; }
                     std::getline(f, line);   // rest of line (image flags ignored)
                     if (t < 1 || t > D.ntypes) { E.err = "Invalid atom type in Atoms section of data file"; return 1; }
                     D.tag[i] = (int)id; D.type[i] = t;
@@ -202,6 +218,7 @@ int upload(Engine &E, Deck &D)
     if (D.mass.empty()) { E.err = "All masses are not set"; return 1; }
     if ((rc = E.set_mass(D.ntypes, D.mass.data()))) return rc;
     if ((rc = E.atoms_upload(D.natoms, D.x.data(), D.v.data(), D.tag.data(), D.type.data(), nullptr, nullptr))) return rc;
+    if (D.nbonds > 0 && (rc = E.bonds_upload(D.nbonds, D.bond_i.data(), D.bond_j.data(), D.bond_t.data()))) return rc;
     D.uploaded = true;
     return 0;
 }
@@ -261,7 +278,7 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
                 else { E.err = "Illegal boundary command"; return 1; }
             }
         } else if (c == "atom_style") {
-            if (w.size() < 2 || (w[1] != "dpd/atomic/meso" && w[1] != "atomic")) { E.err = "Invalid atom style " + (w.size() > 1 ? w[1] : ""); return 1; }
+            if (w.size() < 2 || (w[1] != "dpd/atomic/meso" && w[1] != "atomic" && w[1] != "dpd/bond/meso" && w[1] != "bond")) { E.err = "Invalid atom style " + (w.size() > 1 ? w[1] : ""); return 1; }
             D.atom_style = w[1];
         } else if (c == "variable") {
             if (w.size() >= 4 && (w[2] == "index" || w[2] == "equal" || w[2] == "string")) { if (!D.vars.count(w[1])) D.vars[w[1]] = w[3]; }
@@ -316,6 +333,15 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
                     count++;
                 }
             if (!count) { E.err = "Incorrect args for pair coefficients"; return 1; }
+        } else if (c == "special_bonds") {
+            if (w.size() != 5 || w[1] != "lj") { E.err = "Illegal special_bonds command"; return 1; }
+            if ((rc = E.special_bonds(atof(w[2].c_str()), atof(w[3].c_str()), atof(w[4].c_str())))) return rc;
+        } else if (c == "bond_style") {
+            if (w.size() != 2 || w[1] != "harmonic/meso") { E.err = "Invalid bond style"; return 1; }
+            if ((rc = E.bond_style(std::max(D.nbondtypes, 1)))) return rc;
+        } else if (c == "bond_coeff") {
+            if (w.size() != 4) { E.err = "Incorrect args for bond coefficients"; return 1; }
+            if ((rc = E.bond_coeff(atoi(w[1].c_str()), atof(w[2].c_str()), atof(w[3].c_str())))) return rc;
         } else if (c == "compute") {
             if (w.size() < 4 || w[2] != "all") { E.err = "Illegal compute command"; return 1; }
             if (w[3] != "temp/meso" && w[3] != "pe/meso" && w[3] != "pressure/meso") { E.err = "Invalid compute style " + w[3]; return 1; }

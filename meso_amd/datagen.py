@@ -40,13 +40,20 @@ def make_box(L: int, seed: int | None = None):
 
 
 def write_data(path: str, x: np.ndarray, lo, hi, v: np.ndarray | None = None,
-               types: np.ndarray | None = None, ntypes: int = 1) -> None:
-    """LAMMPS ``read_data`` file (atom_style atomic / dpd/atomic/meso), optional Velocities."""
+               types: np.ndarray | None = None, ntypes: int = 1, bonds: np.ndarray | None = None) -> None:
+    """LAMMPS ``read_data`` file (atom_style atomic / dpd/atomic/meso), optional Velocities.  With ``bonds``
+    (nb,3: tag_i, tag_j, type) the file is in atom_style bond / dpd/bond/meso form (molecule-id column, Bonds)."""
     n = len(x)
     if types is None:
         types = np.ones(n, dtype=np.int64)
     with open(path, "w") as f:
-        f.write("LAMMPS\n\n%d atoms\n\n%d atom types\n\n" % (n, ntypes))
+        f.write("LAMMPS\n\n%d atoms\n" % n)
+        if bonds is not None:
+            f.write("%d bonds\n" % len(bonds))
+        f.write("\n%d atom types\n" % ntypes)
+        if bonds is not None:
+            f.write("%d bond types\n" % int(bonds[:, 2].max()))
+        f.write("\n")
         for d, a in enumerate("xyz"):
             f.write("%.17g %.17g %slo %shi\n" % (lo[d], hi[d], a, a))
         f.write("\nMasses\n\n")
@@ -54,11 +61,18 @@ def write_data(path: str, x: np.ndarray, lo, hi, v: np.ndarray | None = None,
             f.write("%d 1.000000\n" % t)
         f.write("\nAtoms\n\n")
         for i in range(n):
-            f.write("%d %d %.17g %.17g %.17g\n" % (i + 1, types[i], x[i, 0], x[i, 1], x[i, 2]))
+            if bonds is not None:
+                f.write("%d 0 %d %.17g %.17g %.17g\n" % (i + 1, types[i], x[i, 0], x[i, 1], x[i, 2]))
+            else:
+                f.write("%d %d %.17g %.17g %.17g\n" % (i + 1, types[i], x[i, 0], x[i, 1], x[i, 2]))
         if v is not None:
             f.write("\nVelocities\n\n")
             for i in range(n):
                 f.write("%d %.17g %.17g %.17g\n" % (i + 1, v[i, 0], v[i, 1], v[i, 2]))
+        if bonds is not None:
+            f.write("\nBonds\n\n")
+            for b, (i, j, t) in enumerate(bonds):
+                f.write("%d %d %d %d\n" % (b + 1, t, i, j))
 
 
 def read_data(path: str):
@@ -91,3 +105,28 @@ def read_data(path: str):
         va = va[np.argsort(va[:, 0].astype(np.int64), kind="stable")]
         v = np.ascontiguousarray(va[:, 1:4])
     return x, v, types, ntypes, lo, hi
+
+
+def make_polymer_box(L: int, frac: float = 0.1, seed: int | None = None, chain=(1, 1, 2, 2, 2, 2), r0: float = 0.5):
+    """configs[4] deck (build-defined, SURVEY.md 8d: the reference ships no polymer input): a rho=4 cube in which
+    ``frac`` of the beads form linear A2B4 amphiphiles (types 1,1,2,2,2,2, consecutive ids, random-walk chains of
+    step r0), the rest is type-1 solvent.  Returns x, v, types, bonds(nb,3: tag_i, tag_j, type), lo, hi."""
+    rng = np.random.default_rng((L if seed is None else seed) + 5000)
+    n = RHO * L ** 3
+    m = len(chain)
+    nchain = int(frac * n / m)
+    x = rng.random((n, 3)) * L
+    types = np.ones(n, dtype=np.int32)
+    bonds = []
+    for c in range(nchain):
+        base = c * m
+        for k in range(1, m):
+            step = rng.normal(size=3)
+            step *= r0 / np.linalg.norm(step)
+            x[base + k] = x[base + k - 1] + step
+            bonds.append((base + k, base + k + 1, 1))
+        types[base:base + m] = chain
+    x %= L
+    x = np.minimum(x, np.nextafter(float(L), 0.0))
+    v = make_velocities(n, (L if seed is None else seed) + 6000)
+    return x, v, types, np.array(bonds, dtype=np.int32).reshape(-1, 3), np.zeros(3), np.full(3, float(L))

@@ -61,6 +61,65 @@ class MesoRefSim:
     def pair_coeff(self, i, j, a0, gamma, sigma, expw=1.0, cut=1.0):
         self.coeffs[(min(i, j), max(i, j))] = (a0, gamma, sigma, expw, cut)
 
+    def set_bonds(self, bonds, coeffs, special=(0.0, 0.0, 0.0)):
+        """bonds (nb,3: tag_i, tag_j, type); coeffs {type: (k, r0)}; special_bonds weights (0 = level excluded
+        from the pair rows, gpu_filter_exclusion neigh_build_meso.cu:497-569).  Bond force: gpu_bond_harmonic
+        bond_harmonic_meso.cu:84-101 == BondHarmonic::compute src/MOLECULE/bond_harmonic.cpp:44-96."""
+        self.bonds = np.asarray(bonds, np.int64).reshape(-1, 3)
+        self.bond_coeffs = coeffs
+        adj = {}
+        for a, b, _ in self.bonds:
+            adj.setdefault(int(a), []).append(int(b))
+            adj.setdefault(int(b), []).append(int(a))
+        levels = 0
+        while levels < 3 and special[levels] == 0.0:
+            levels += 1
+        self.special = {}
+        for t in adj:
+            seen, frontier, out = {t}, [t], []
+            for _ in range(levels):
+                nxt = []
+                for u in frontier:
+                    for w in adj[u]:
+                        if w not in seen:
+                            seen.add(w); nxt.append(w); out.append(w)
+                frontier = nxt
+            self.special[t] = out
+
+    def _apply_exclusions(self):
+        if not getattr(self, "special", None):
+            return
+        xa, va, ta, ga = self._all()
+        for t, spec in self.special.items():
+            i = t - 1
+            if not spec:
+                continue
+            row = self.table[i, :self.count[i]]
+            keep = ~np.isin(ga[row], spec)
+            k = int(keep.sum())
+            self.table[i, :k] = row[keep]
+            self.count[i] = k
+
+    def _bond_forces(self):
+        self.e_bond = 0.0
+        if getattr(self, "bonds", None) is None or len(self.bonds) == 0:
+            return
+        c = self.c4[:self.n, :3].astype(np.float64)
+        prd = self.hi - self.lo
+        i = np.concatenate([self.bonds[:, 0], self.bonds[:, 1]]) - 1
+        j = np.concatenate([self.bonds[:, 1], self.bonds[:, 0]]) - 1
+        bt = np.concatenate([self.bonds[:, 2], self.bonds[:, 2]])
+        k = np.array([self.bond_coeffs[int(t)][0] for t in bt])
+        r0 = np.array([self.bond_coeffs[int(t)][1] for t in bt])
+        d = c[j] - c[i]
+        d = d + np.where(d > -0.5 * prd, np.where(d < 0.5 * prd, 0.0, -prd), prd)     # minimum_image math_meso.h:148-152
+        rsq = (d * d).sum(1)
+        rinv = 1.0 / np.sqrt(rsq)
+        r = rinv * rsq
+        fb = 2.0 * k * (r - r0) * rinv
+        np.add.at(self.f, i, d * fb[:, None])
+        self.e_bond = float(0.5 * (k * (r - r0) ** 2).sum())
+
     # -- pieces -------------------------------------------------------------
     def _pbc(self):
         prd = self.hi - self.lo
@@ -91,6 +150,7 @@ class MesoRefSim:
         self.count, self.table, self.maxlen = ob.neigh_full(self.n, c4, self.cutmax + self.skin, self.stride)
         if self.maxlen > self.stride:
             raise RuntimeError("pair table overflow")
+        self._apply_exclusions()
         self.ago = 0
 
     def _force(self):
@@ -98,6 +158,7 @@ class MesoRefSim:
         self.c4, self.v4 = self._merge(seed)
         self.f = ob.pair_dpd(self.n, self.c4, self.v4, self.count, self.table, self.coeff, self.ntypes,
                              self.dt, fast=self.fast)
+        self._bond_forces()
 
     def setup(self):
         self.cutmax = max(c[4] for c in self.coeffs.values())

@@ -1,0 +1,164 @@
+"""configs[4]: bonded chains (atom_style dpd/bond/meso, bond_style harmonic/meso, special-bond exclusions) against
+the CPU oracle, on one rank and decomposed over 8 ranks of one GPU."""
+import threading
+
+import numpy as np
+import pytest
+
+from meso_amd.datagen import make_polymer_box
+
+pytestmark = pytest.mark.gpu
+
+A = {(1, 1): 15.0, (2, 2): 15.0, (1, 2): 40.0}
+
+
+def _setup(m, x, v, types, bonds, lo, hi, style="dpd/meso", sigma=3.0, special=(0.0, 0.0, 0.0)):
+    m.read_atoms(x, v, lo, hi, types=types, ntypes=2)
+    m.special_bonds(*special)
+    m.read_bonds(bonds)
+    m.bond_style("harmonic/meso", 1)
+    m.bond_coeff(1, 50.0, 0.5)
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=5, check=False)
+    m.pair_style(style, 1.0, 419084618)
+    for (i, j), a in A.items():
+        m.pair_coeff(i, j, a, 4.5, sigma, 1.0, 1.0)
+    m.timestep(0.005)
+    m.setup()
+
+
+def _oracle(x, v, types, bonds, lo, hi, sigma=3.0, special=(0.0, 0.0, 0.0), fast=False):
+    from oracle.meso_sim import MesoRefSim
+    s = MesoRefSim(x, v, lo, hi, types=types, ntypes=2, fast=fast)
+    for (i, j), a in A.items():
+        s.pair_coeff(i, j, a, 4.5, sigma, 1.0, 1.0)
+    s.set_bonds(bonds, {1: (50.0, 0.5)}, special)
+    s.setup()
+    return s
+
+
+@pytest.mark.parametrize("special", [(0.0, 0.0, 0.0), (0.0, 1.0, 1.0), (1.0, 1.0, 1.0)])
+def test_forces_rows_and_bond_energy(oracle, special):
+    from meso_amd.api import Meso
+    x, v, types, bonds, lo, hi = make_polymer_box(8, frac=0.3)
+    s = _oracle(x, v, types, bonds, lo, hi, special=special)
+    with Meso() as m:
+        _setup(m, x, v, types, bonds, lo, hi, special=special)
+        xg, vg, fg, tag, typ = m.gather()
+        count, _ = m.neigh_table()
+        _, _, _, tag_dev, _ = m.gather(by_tag=False)
+        assert np.array_equal(typ, types)
+        assert np.array_equal(count[np.argsort(tag_dev)], s.count)          # special partners are not in the rows
+        assert np.abs(fg - s.f).max() < 1e-9 * np.abs(s.f).max()
+        assert m.ebond() == pytest.approx(s.e_bond, rel=1e-10)
+    if special == (1.0, 1.0, 1.0):
+        assert s.count.sum() > _oracle(x, v, types, bonds, lo, hi).count.sum()
+
+
+@pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-9), ("dpd/fast/meso", 5e-5)])
+def test_polymer_trajectory(oracle, style, tol):
+    from meso_amd.api import Meso
+    x, v, types, bonds, lo, hi = make_polymer_box(7, frac=0.3)
+    sigma = 3.0 if style == "dpd/meso" else 0.0
+    s = _oracle(x, v, types, bonds, lo, hi, sigma=sigma, fast=style != "dpd/meso")
+    with Meso() as m:
+        _setup(m, x, v, types, bonds, lo, hi, style=style, sigma=sigma)
+        m.run(12)
+        s.run(12)
+        xg, vg = m.gather()[:2]
+    prd = hi - lo
+    d = xg - s.x
+    d -= np.round(d / prd) * prd
+    assert np.abs(d).max() < tol and np.abs(vg - s.v).max() < 100 * tol
+
+
+def test_chains_survive_decomposition():
+    """8 ranks: chains straddle sub-domain faces and beads migrate with their bond / special lists."""
+    from meso_amd.api import Meso
+    L = 12
+    x, v, types, bonds, lo, hi = make_polymer_box(L, frac=0.2)
+    gid = np.frombuffer(np.random.default_rng(77).bytes(8), np.uint8)
+
+    def run(nranks, grid):
+        out, errs = [None] * nranks, []
+
+        def work(r):
+            try:
+                m = Meso()
+                if nranks > 1:
+                    m.comm_init(nranks, r, grid, "local", gid)
+                _setup(m, x, v, types, bonds, lo, hi)
+                e0 = m.ebond()
+                f0 = m.gather(by_tag=False)
+                m.run(40)
+                m.force_clear("local"); m.compute(); m.bond_compute(1)
+                out[r] = (e0, f0, m.gather(by_tag=False), m.temperature(), m.counts(), m.ebond())
+                m.close()
+            except Exception as e:   # noqa: BLE001
+                errs.append((r, repr(e)))
+        th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        [t.start() for t in th]
+        [t.join(timeout=300) for t in th]
+        assert not errs, errs
+        return out
+
+    one = run(1, (1, 1, 1))
+    many = run(8, (2, 2, 2))
+    n = len(x)
+    assert sum(o[4][0] for o in many) == n
+    # chains start at r = r0 exactly, so the initial bond energy is fp32 rounding noise; after 40 steps it is O(N)
+    assert all(abs(o[0] - one[0][0]) < 1e-6 for o in many)
+    assert all(abs(o[5] - many[0][5]) < 1e-9 * abs(many[0][5]) for o in many)          # one global value on all ranks
+    assert abs(many[0][5] - one[0][5]) < 0.15 * abs(one[0][5]) and one[0][5] > 1.0
+    f1 = one[0][1][2][np.argsort(one[0][1][3])]
+    tags = np.concatenate([o[1][3] for o in many])
+    f8 = np.concatenate([o[1][2] for o in many])[np.argsort(tags)]
+    assert np.array_equal(np.sort(tags), np.arange(1, n + 1))
+    assert np.abs(f8 - f1).max() < 5e-6 * np.abs(f1).max()
+    tags40 = np.concatenate([o[2][3] for o in many])
+    assert np.array_equal(np.sort(tags40), np.arange(1, n + 1))                          # nobody lost after 40 steps
+    assert abs(many[0][3] - one[0][3]) < 0.1
+
+
+DECK = """dimension 3
+units lj
+boundary p p p
+atom_style dpd/bond/meso
+neighbor 0.3 bin
+neigh_modify delay 0 every 5 check no
+special_bonds lj 0.0 1.0 1.0
+read_data {data}
+run_style mvv/meso
+bond_style harmonic/meso
+bond_coeff 1 50.0 0.5
+pair_style dpd/meso 1.0 419084618
+pair_coeff 1 1 15.0 4.5 3.0 1.0 1.0
+pair_coeff 2 2 15.0 4.5 3.0 1.0 1.0
+pair_coeff 1 2 40.0 4.5 3.0 1.0 1.0
+compute mobile all temp/meso
+fix 1 all nve/meso
+thermo_style custom step c_mobile
+thermo 10
+timestep 0.005
+run 10
+"""
+
+
+def test_script_driver_runs_a_polymer_deck(oracle, tmp_path):
+    """The mini driver reads atom_style dpd/bond/meso files (molecule column, Bonds section) and the bond commands;
+    the trajectory equals the API-driven one (same engine calls) and the oracle's."""
+    from meso_amd.api import Meso
+    from meso_amd.datagen import write_data
+    x, v, types, bonds, lo, hi = make_polymer_box(6, frac=0.3)
+    write_data(str(tmp_path / "poly.data"), x, lo, hi, v=v, types=types, ntypes=2, bonds=bonds)
+    (tmp_path / "poly.run").write_text(DECK.format(data=tmp_path / "poly.data"))
+    special = (0.0, 1.0, 1.0)
+    s = _oracle(x, v, types, bonds, lo, hi, special=special)
+    s.run(10)
+    with Meso() as m:
+        log = m.script(str(tmp_path / "poly.run"))
+        xg, vg, fg, tag, typ = m.gather()
+        assert np.abs(xg - s.x).max() < 1e-9
+        assert m.ebond() == pytest.approx(s.e_bond, rel=1e-8)
+        rows = [ln.split() for ln in log.splitlines() if ln.split() and ln.split()[0] in ("0", "10")]
+        assert float(rows[-1][1]) == pytest.approx(s.temperature, rel=1e-9)
