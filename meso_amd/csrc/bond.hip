@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) k_bond_harmonic(const float4 *__restrict_
             fx += dx * fbond; fy += dy * fbond; fz += dz * fbond;
             if (EV) e += k[type] * (r - r0[type]) * (r - r0[type]);
         }
-        fx_[i] += fx; fy_[i] += fy; fz_[i] += fz;
+        if (fx_) { fx_[i] += fx; fy_[i] += fy; fz_[i] += fz; }   // null: energy-only pass (compute_ebond)
         if (EV) e_bond[i] = e * 0.5;
     }
 }

@@ -471,7 +471,10 @@ int Engine::bond_compute(int eflag)
 
 int Engine::compute_ebond(double *e)
 {
-    if (!have_bonds) { *e = 0.0; return 0; }
+    if (!have_bonds || nbondtypes == 0 || !is_setup || !d_bond_kr0) { *e = 0.0; return 0; }
+    // energy at the coordinates of the last force evaluation (what thermo prints on an eflag step, src/thermo.cpp ebond)
+    launch_bond_harmonic(coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, nullptr, nullptr,
+                         nullptr, e_bond, stream);
     std::vector<double> h((size_t)nlocal);
     HIPCHK(hipMemcpyAsync(h.data(), e_bond, nlocal * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));

@@ -158,7 +158,9 @@ def test_script_driver_runs_a_polymer_deck(oracle, tmp_path):
     with Meso() as m:
         log = m.script(str(tmp_path / "poly.run"))
         xg, vg, fg, tag, typ = m.gather()
-        assert np.abs(xg - s.x).max() < 1e-9
+        d = xg - s.x
+        d -= np.round(d / (hi - lo)) * (hi - lo)
+        assert np.abs(d).max() < 1e-9
         assert m.ebond() == pytest.approx(s.e_bond, rel=1e-8)
         rows = [ln.split() for ln in log.splitlines() if ln.split() and ln.split()[0] in ("0", "10")]
-        assert float(rows[-1][1]) == pytest.approx(s.temperature, rel=1e-9)
+        assert float(rows[-1][1]) == pytest.approx(s.temperature, rel=1e-7)      # thermo prints 8 digits
