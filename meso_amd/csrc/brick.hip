@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
                                                            const unsigned short *__restrict__ table16,
                                                            int *__restrict__ overflow)
 {
-    typedef typename std::conditional<FAST, float, double>::type acc_t;
+    // fp32 style: 64-bit fixed-point sums (ds_add_u64; float LDS atomics serialise on gfx950, see pair_ring.hip)
+    typedef typename std::conditional<FAST, u64, double>::type acc_t;
     __shared__ BrickHdr H;
     __shared__ float4 hc[BRK_MAXH];
     __shared__ float4 hv[BRK_MAXH];
@@ -299,9 +300,9 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
                     float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
                     float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
                     fpair *= rinv;
-                    __hip_atomic_fetch_add((float *)&facc[0][oo], dx * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add((float *)&facc[1][oo], dy * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add((float *)&facc[2][oo], dz * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add((u64 *)&facc[0][oo], to_fixed(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add((u64 *)&facc[1][oo], to_fixed(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add((u64 *)&facc[2][oo], to_fixed(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 } else {
                     const double *cf = cf64 + cidx * N_COEFF;
                     double dx = (double)ci.x - (double)cj.x, dy = (double)ci.y - (double)cj.y, dz = (double)ci.z - (double)cj.z;
@@ -369,7 +370,9 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArg
         if (qtail > qhead) drain(qtail - qhead);
 
         if (mine && i >= a.beg && i < a.end) {
-            double fx = (double)facc[0][o], fy = (double)facc[1][o], fz = (double)facc[2][o];
+            double fx, fy, fz;
+            if (FAST) { fx = from_fixed((u64)facc[0][o]); fy = from_fixed((u64)facc[1][o]); fz = from_fixed((u64)facc[2][o]); }
+            else { fx = (double)facc[0][o]; fy = (double)facc[1][o]; fz = (double)facc[2][o]; }
             if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
             else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
         }

@@ -59,6 +59,7 @@ public:
     int halo_forward();
     int force_clear(int range);
     int pair_compute(int range, int eflag, int vflag);
+    void launch_pair(PairArgs &p, int ev);
 
     // computes
     int compute_temp(double *t);
@@ -154,7 +155,7 @@ private:
     std::vector<int> coeff_set;
     std::vector<double> mass_type;  // ntypes+1
     int neigh_kernel = 1;           // 0 simple, 1 wave/LDS
-    int pair_kernel = 2;            // 0 lane-per-atom, 1 tile/brick, 2 auto (fp32: 8-deep MLP, fp64: MLP + compaction),
+    int pair_kernel = 2;            // 0 lane-per-atom, 1 tile/brick, 2 auto (fp32 on cell rows: ring, fp64: MLP + compaction),
                                     // 3 MLP + ballot compaction, 4 MLP only
     int pair_debug = 0;             // timing ablations (bench only)
     int fuse_step = 1;              // final(s)+initial(s+1)(+merge) in one kernel between steps of one run()

@@ -489,7 +489,7 @@ int Engine::ensure_capacity(int need)
     if (need <= nmax) return 0;
     int cap = (int)(need * 1.15) + 4096;
     TRY(alloc_atoms(cap));
-    is_setup = is_setup;   // neighbour table contents are rebuilt by the caller
+    // neighbour table contents are rebuilt by the caller
     return 0;
 }
 
@@ -936,6 +936,18 @@ int Engine::force_clear(int r)
 // MesoPairDPD::compute / compute_bulk / compute_border (pair_dpd_meso.cu:241-266).  The merged arrays of the
 // local range are refreshed for LOCAL and BULK calls, the ghost range for LOCAL and BORDER calls, exactly the
 // split the reference uses to hide its host round trip.
+// kernel choice (option pair_kernel): 0 lane per atom, 1 tile, 2 auto, 3 mlpc, 4 mlp, 5 ring
+void Engine::launch_pair(PairArgs &p, int ev)
+{
+    p.nall = nlocal + nghost;
+    const bool cell = layout == 2;
+    if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
+    else if ((pair_kernel == 5 || pair_kernel == 2) && cell && pair_style == 1) launch_pair_dpd_ring(p, stream);
+    else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
+    else if (pair_kernel == 2 || pair_kernel == 4 || pair_kernel == 5 || cell) launch_pair_dpd_mlp(p, pair_style, stream);
+    else launch_pair_dpd_tile(p, pair_style, stream);
+}
+
 int Engine::pair_compute(int r, int eflag, int vflag)
 {
     if (!is_setup && !params_ready) return fail(3, "pair_compute before setup");
@@ -965,10 +977,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     }
     TRY(ensure_table32());
     tbegin("pair");
-    if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
-    else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
-    else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
-    else launch_pair_dpd_tile(p, pair_style, stream);
+    launch_pair(p, ev);
     tend("pair");
     if (ev) ev_valid = true;
     return 0;
@@ -1029,10 +1038,7 @@ int Engine::run(int nsteps)
             } else {
                 TRY(ensure_table32());
                 tbegin("pair");
-                if (pair_kernel == 0) launch_pair_dpd(p, pair_style, 0, stream);
-                else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
-                else if (pair_kernel == 2 || layout == 2) launch_pair_dpd_mlp(p, pair_style, stream);
-                else launch_pair_dpd_tile(p, pair_style, stream);
+                launch_pair(p, 0);
                 tend("pair");
             }
         }

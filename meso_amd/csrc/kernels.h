@@ -109,12 +109,16 @@ struct PairArgs {
     int accumulate;       // 1: f += (reference semantics), 0: f = (force_clear fused)
     int chunked;          // 1: chunked-8 rows (cell-ordered builder), 0: transposed 64-atom tiles
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
+    int nall;             // atoms in coord4/veloc4 (locals + ghosts): bound of the buffer-addressed gathers
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // lane-per-atom with 8-deep memory-level parallelism (forces only)
 void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
 // the same with a ballot-compacted heavy phase (per-wave LDS ring)
 void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s);
+// fp32 style on chunked-8 rows: light cutoff scan per lane, hits compacted into a per-wave LDS ring of 4-byte
+// records, heavy phase on full waves with the partner data re-gathered through buffer loads (pair_ring.hip)
+void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s);
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
 void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
 struct ExclArgs;

@@ -9,12 +9,6 @@ namespace meso {
 static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 static inline int capgrid(long n, int b, int cap = 256 * 8) { int g = nblk(n, b); return g < 1 ? 1 : (g > cap ? cap : g); }
 
-// Row layout of the cell-ordered table ("chunked-8"): 8 consecutive entries of one atom form one 32-byte word,
-// word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63).  A lane writes/reads whole 32-B sectors (no partial-sector
-// writes: the 4-byte scattered stores of the transposed layout cost 8x the bytes at HBM, profiles/r01_pmc_*),
-// and a wave's access to chunk c of its 64 atoms is one contiguous 2 KiB.
-__device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
-
 // =========================================================================================
 // atom kernels
 // =========================================================================================

@@ -212,4 +212,20 @@ __host__ __device__ inline int clampi(int i, int nmin, int nmax)
     return a > nmin ? a : nmin;
 }
 
+// Row layout of the cell-ordered table ("chunked-8"): 8 consecutive entries of one atom form one 32-byte word,
+// word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63).  A lane writes/reads whole 32-B sectors (no partial-sector
+// writes: the 4-byte scattered stores of the transposed layout cost 8x the bytes at HBM, profiles/r01_pmc_*),
+// and a wave's access to chunk c of its 64 atoms is one contiguous 2 KiB.
+__device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
+
+// x -> two's-complement 64-bit fixed point with 32 fractional bits: floor(x) in the high word, fract(x) * 2^32 in the low
+// word (exact for every fp32 x with |x| < 2^31 down to 2^-32 resolution)
+__device__ inline u64 to_fixed(float x)
+{
+    const int hi = (int)__builtin_floorf(x);
+    const u32 lo = (u32)(__builtin_amdgcn_fractf(x) * 4294967296.0f);
+    return ((u64)(u32)hi << 32) | lo;
+}
+__device__ inline double from_fixed(u64 a) { return (double)(long long)a * (1.0 / 4294967296.0); }
+
 } // namespace meso

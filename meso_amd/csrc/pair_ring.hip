@@ -1,0 +1,186 @@
+// pair_style dpd/fast/meso force kernel, "ring" form (gfx950, wave64).
+//
+// Computes what gpu_dpd_fast<0> computes (/root/reference/src/USER-MESO/pair_dpd_fast_meso.cu:91-205): full list,
+// newton off, fp32 arithmetic, TEA-keyed pair noise.  The lane-per-atom kernels are bound by VALU issue, not by HBM
+// (profiles/r01_pmc_64_fast.txt: 77 M wave-instructions per launch = 87 % of the VALU issue slots of 1024 SIMDs):
+// only ~45 % of the row entries are inside r_c and a wave executes the ~110-instruction TEA/Gaussian/weight
+// sequence for a slot as soon as ONE of its lanes has a hit, for as many slots as its longest row has.  Here
+//
+//   light phase (lane = atom): the row is read 8 entries at a time (two 16-byte words of the chunked-8 table, the
+//     next chunk's words already in flight), the 8 partner coordinates are gathered with buffer loads (a 32-bit
+//     byte offset per lane, no 64-bit address arithmetic), the cutoff is tested, and each hit appends ONE 4-byte
+//     record (owner lane << 26 | partner index) to a per-wave LDS ring with ballot + mbcnt;
+//   heavy phase (lane = hit): whenever 64 records are queued their partner coordinate/velocity words are
+//     requested (64 independent gathers), and the batch requested at the PREVIOUS drain point - whose data has
+//     arrived meanwhile - is evaluated with every lane busy.  The owner's own coordinate/velocity come from LDS;
+//     the three force components are added to per-wave LDS accumulators as 64-bit fixed point (2^-32 units,
+//     ds_add_u64).  Measured on gfx950 (tools/micro/lds_atomic_bench.hip), CU cycles per 64-lane x 3-component
+//     group: ds_add_f32 579, ds_add_f64 56, ds_add_u64 30, ds_add_u32 21, plain 12-byte stores 21 - the float
+//     LDS atomics serialise, the integer ones run at store speed.
+//
+// One wave owns its 64 atoms from start to end: no block barriers after the prologue, no global atomics; integer
+// addition is associative, so the sums do not depend on the order in which hits are drained (bit-reproducible).
+// Arithmetic of this kernel is contracted (a*b+c -> fma), like nvcc's default for the reference's fp32 kernel.
+#include "kernels.h"
+#include "meso_device.h"
+
+namespace meso {
+
+#define RG_WAVES 4
+#define RG_RING 256                 // records per wave; a drain check every 2 slots keeps the fill below 64 + 128
+#define RG_OWNER_SHIFT 26
+#define RG_INDEX_MASK 0x03FFFFFFu
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+template <bool NT1, int OCC>
+__global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a)
+{
+#pragma clang fp contract(fast)
+    extern __shared__ double smem[];
+    float *cf32 = (float *)smem;
+    const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * N_COEFF;
+    for (int p = threadIdx.x; p < ncf; p += blockDim.x) cf32[p] = a.coeff32[p];
+    const size_t off = ((size_t)ncf * 4 + 15) & ~(size_t)15;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;
+    char *wb = (char *)smem + off + (size_t)w * per_wave;
+    float4 *own_c = (float4 *)wb;
+    float4 *own_v = own_c + 64;
+    float4 *ring = own_v + 64;          // (record word, partner x, y, z): the coordinate is not gathered twice
+    u64 *facc = (u64 *)(ring + RG_RING);
+
+    const int nbk = gridDim.x;
+    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
+    const int i = a.beg + blk * blockDim.x + threadIdx.x;
+    const bool mine = i < a.end;
+    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
+    int n = 0;
+    if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
+    own_c[lane] = c1;
+    own_v[lane] = v1;
+    facc[lane] = 0; facc[64 + lane] = 0; facc[128 + lane] = 0;
+    __syncthreads();   // coefficient table (multi-type) + this wave's own_c/own_v/facc
+
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.coord4, 0, a.nall * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, a.nall * 16, 0x00020000);
+    const u32 t1 = __float_as_uint(c1.w);
+    const float dtis = (float)a.dt_inv_sqrt;
+    const u32 lanehi = (u32)lane << RG_OWNER_SHIFT;
+    const int nch = (n + 7) >> 3;
+    int nchmax = nch;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nchmax = max(nchmax, __shfl_xor(nchmax, o, 64));
+    nchmax = __builtin_amdgcn_readfirstlane(nchmax);
+
+    int qhead = 0, qtail = 0;     // wave-uniform
+    int pn = 0;                   // records of the batch whose gathers are in flight
+    u32 pe = 0;
+    float4 pc2 = make_float4(0.f, 0.f, 0.f, 0.f), pv2 = pc2;
+
+    // evaluate the pending batch (lane = hit)
+    auto compute = [&]() {
+        if (pn > 0) {
+            if (lane < pn) {
+                const u32 owner = pe >> RG_OWNER_SHIFT;
+                const float4 ci = own_c[owner], vi = own_v[owner];
+                float c_cutinv, c_ew, c_a0, c_gamma, c_sigma;
+                if (NT1) {
+                    c_cutinv = (float)a.cf1[P_CUTINV]; c_ew = (float)a.cf1[P_EXPW]; c_a0 = (float)a.cf1[P_A0];
+                    c_gamma = (float)a.cf1[P_GAMMA]; c_sigma = (float)a.cf1[P_SIGMA];
+                } else {
+                    const float *cf = cf32 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * N_COEFF;
+                    c_cutinv = cf[P_CUTINV]; c_ew = cf[P_EXPW]; c_a0 = cf[P_A0]; c_gamma = cf[P_GAMMA]; c_sigma = cf[P_SIGMA];
+                }
+                const float dx = ci.x - pc2.x, dy = ci.y - pc2.y, dz = ci.z - pc2.z;
+                const float rsq = dx * dx + dy * dy + dz * dz;
+                const float rn = gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w));
+                const float rinv = __builtin_amdgcn_rsqf(rsq);
+                const float r = rsq * rinv;
+                const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;
+                const float dot = dx * dvx + dy * dvy + dz * dvz;
+                const float wc = 1.0f - r * c_cutinv;
+                float wr = wc;
+                if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
+                float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
+                fpair *= rinv;
+                __hip_atomic_fetch_add(&facc[owner], to_fixed(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&facc[64 + owner], to_fixed(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&facc[128 + owner], to_fixed(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            pn = 0;
+        }
+    };
+    // request the partner words of the next nb queued records
+    auto issue = [&](int nb) {
+        if (lane < nb) {
+            const float4 rec = ring[(qhead + lane) & (RG_RING - 1)];
+            pe = __float_as_uint(rec.x);
+            pc2 = make_float4(rec.y, rec.z, rec.w, 0.f);
+            const u32 joff = (pe & RG_INDEX_MASK) << 4;
+            if (!NT1) pc2.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, (int)joff + 12, 0, 0));   // partner type
+            pv2 = buf_load4(rv, joff);
+        }
+        pn = nb;
+        qhead += nb;
+    };
+
+    const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);
+    int4 w0 = make_int4(0, 0, 0, 0), w1 = w0;
+    if (nch > 0) { w0 = rows[0]; w1 = rows[1]; }
+#pragma unroll 1
+    for (int c = 0; c < nchmax; c++) {
+        const bool active = c < nch;
+        const int j[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        if (c + 1 < nch) { w0 = rows[(size_t)(c + 1) * 128]; w1 = rows[(size_t)(c + 1) * 128 + 1]; }
+        float4 c2[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) c2[q] = buf_load4(rc, active ? ((u32)j[q] << 4) : 0xFFFFFFF0u);   // out of range: returns 0, no fetch
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
+            const float rsq = dx * dx + dy * dy + dz * dz;
+            const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
+            const bool hit = active && rsq < cutsq && rsq >= (float)MESO_EPSILON_SQ;    // tail slots hold i itself: rsq = 0
+            const u64 m = __ballot(hit);
+            if (hit) ring[(qtail + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))) & (RG_RING - 1)] =
+                    make_float4(__uint_as_float((u32)j[q] | lanehi), c2[q].x, c2[q].y, c2[q].z);
+            qtail += __popcll(m);
+            if (q & 1) {
+                while (qtail - qhead >= 64) { compute(); issue(64); }
+            }
+        }
+    }
+    compute();
+    while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
+
+    if (mine) {
+        const double fx = from_fixed(facc[lane]), fy = from_fixed(facc[64 + lane]), fz = from_fixed(facc[128 + lane]);
+        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
+        else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
+    }
+}
+
+void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s)
+{
+    int n = p.end - p.beg;
+    if (n <= 0) return;
+    const bool nt1 = p.ntypes == 1;
+    size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * 4;
+    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;
+    size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
+    dim3 grid(((n + 64 * RG_WAVES - 1) / (64 * RG_WAVES) + 7) / 8 * 8), block(64 * RG_WAVES);
+    // p.debug 3/4: occupancy ablation - pad the LDS request so that only 3 / 4 workgroups fit a CU (default: 5)
+    if (p.debug == 3) sm = 53 * 1024;
+    if (p.debug == 4) sm = 40 * 1024;
+    if (!nt1) hipLaunchKernelGGL((k_pair_dpd_ring<false, 5>), grid, block, sm, s, p);
+    else hipLaunchKernelGGL((k_pair_dpd_ring<true, 5>), grid, block, sm, s, p);
+}
+
+} // namespace meso

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 PATHS = {"lane": (("layout", 0), ("pair_kernel", 0)), "tile": (("layout", 0), ("pair_kernel", 1)),
          "brick": (("layout", 1), ("pair_kernel", 1)), "brick-rows+lane": (("layout", 1), ("pair_kernel", 0)),
          "cell+mlp": (("layout", 2), ("pair_kernel", 2)), "cell+mlpc": (("layout", 2), ("pair_kernel", 3)),
-         "bins+mlpc": (("layout", 0), ("pair_kernel", 3))}
+         "bins+mlpc": (("layout", 0), ("pair_kernel", 3)), "cell+ring": (("layout", 2), ("pair_kernel", 5))}
 
 
 @pytest.fixture(scope="module")
@@ -190,7 +190,7 @@ def test_kernels_agree_on_a_large_box(Meso, style, tol):
     """32^3 (131 k atoms, 512+ workgroups, XCD remap active): every force kernel against the lane-per-atom one.
     (A register-spilling build of the compacted fp64 kernel was correct at 25^3 and wrong here.)"""
     ref = None
-    for path in ("cell-lane", "cell+mlp", "cell+mlpc", "brick", "tile"):
+    for path in ("cell-lane", "cell+mlp", "cell+mlpc", "cell+ring", "brick", "tile"):
         opts = {"cell-lane": (("layout", 2), ("pair_kernel", 0)), "cell+mlp": (("layout", 2), ("pair_kernel", 4))}.get(path, PATHS.get(path))
         m, _ = _engine(Meso, 32, style=style, opts=opts)
         m.force_clear("local")
