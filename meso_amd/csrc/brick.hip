@@ -1,50 +1,39 @@
-// Brick kernels: the MI355X-first layout of the DPD hot path.
+// Brick kernels: the LDS-staged layout of the DPD hot path (engine option layout=1).
 //
-// Local atoms are sorted by [border bit][Morton(bin)][Morton(sub-cell)] (atom_meso.cu:268-308), so every
-// aligned group of 32 Morton codes is a 4x4x2 brick of bins whose atoms are contiguous in memory, and ghosts
-// are sorted by Morton(bin) behind them.  One workgroup owns one (section, brick): it copies the brick's
-// 6x6x4-bin halo (~1270 atoms at rho=4) from HBM into LDS ONCE, as whole bin runs, and every neighbour
-// gather of the force kernel and of the list builder then hits LDS instead of L2 (the lane-per-atom kernel
-// measured 48 % L1 / 54 % L2 hit rates and 4x the algorithmic bytes at the fabric: profiles/r01_pmc_*).
-// Neighbour rows hold 16-bit halo-local indices (half the table traffic of the reference's int rows).
-// Row layout stays transposed per 64-atom tile: entry p of atom i at table16[((i>>6)*n_col + p)*64 + (i&63)].
+// Local atoms are sorted by [border bit][Morton(bin)][Morton(sub-cell)] (atom_meso.cu:268-308), so every aligned
+// group of 64 Morton codes is a 4x4x4 brick of bins whose atoms are contiguous in memory (one run per section:
+// bulk, border), and ghosts are sorted by Morton(bin) behind them.  One workgroup owns one brick.  A per-rebuild
+// PLAN kernel writes, for every brick, the map "halo slot -> global atom index" of its 6x6x6-bin neighbourhood
+// (~1900 atoms at rho=4, whole bin runs in halo-bin order).  The list builder and the force kernel copy the
+// neighbourhood's coordinates from HBM into LDS ONCE per launch with coalesced reads, and every neighbour gather
+// then hits LDS: the lane-per-atom gathers of the cell-ordered kernels are bound by the L1 tag rate (one 128-byte
+// line per clock per CU, ~50 lines per 64-lane gather; profiles/r01_notes.md), LDS serves 4 random 16-byte reads
+// per clock.  Neighbour rows hold 16-bit halo-local BYTE offsets (slot * 16): half the table traffic of the
+// reference's int rows and no address arithmetic in the scan.
+//   rows:  8 entries = one 16-byte word; word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63)   (a wave reads 1 KiB)
 //
-// Replaces gpu_build_neighbor_list + gpu_join/transpose (neigh_build_meso.cu:20-240) and gpu_dpd /
-// gpu_dpd_fast (pair_dpd_meso.cu:91-205, pair_dpd_fast_meso.cu:91-205); membership test and per-pair
-// arithmetic are unchanged, so results agree with the lane-per-atom kernels to summation order.
+// Replaces gpu_build_neighbor_list + gpu_join/transpose (neigh_build_meso.cu:20-240) and gpu_dpd_fast
+// (pair_dpd_fast_meso.cu:91-205); membership test and per-pair arithmetic are those of the other kernels, so
+// results agree to summation order (and the fp32 force sums are order-independent 64-bit fixed point).
 #include "kernels.h"
 #include "meso_device.h"
-#include <type_traits>
 
 namespace meso {
 
-#define BRK_HX 6
-#define BRK_HY 6
-#define BRK_HZ 4
-#define BRK_NHB (BRK_HX * BRK_HY * BRK_HZ)
-#define BRK_THREADS 320
+#define BRK_CODES 64
+#define BRK_H 6
+#define BRK_NHB (BRK_H * BRK_H * BRK_H)
+#define BRK_THREADS 640
 #define BRK_WAVES (BRK_THREADS / 64)
-#define BRK_MAXH 1664          // halo atoms staged per brick (mean 1267 at rho=4, sigma ~36)
-#define BRK_MAXOWN 512
-#define BRK_RING 128
+#define BRK_MAXH 2176          // halo atoms staged per brick (mean ~1900 at rho=4; Poisson sigma ~44)
+#define BRK_MAXOWN 704         // atoms owned per brick (mean ~563, sigma ~24)
+#define BRK_HOFF_PITCH 448      // hoff[0..216] + hloc[224 + hb]: locals (bulk + border runs) of each halo bin
+#define BRK_HLOC 224
+#define BRK_HDR_PITCH 8
+#define BRK_RING 256
+#define BRK_OWNER_SHIFT 16
 
-struct BrickHdr {
-    int hoff[BRK_NHB + 1];
-    int hs0[BRK_NHB], hl0[BRK_NHB], hs1[BRK_NHB], hl1[BRK_NHB], hs2[BRK_NHB];
-    int ostart[33];
-    int wtot[4];
-    int nh, n_own, o0, sec;
-};
-
-// Row layout: 8 consecutive 16-bit entries of one atom are one 16-byte word; a wave reads 64 such words
-// (1 KiB, fully coalesced) per 8 candidates:  word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63),  c = p>>3.
 __device__ inline size_t row_word(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
-
-__device__ inline float dist2(float4 a, float4 b)
-{
-    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    return dx * dx + dy * dy + dz * dz;
-}
 
 __device__ inline u32 compact3(u32 x)
 {
@@ -56,323 +45,501 @@ __device__ inline u32 compact3(u32 x)
     return x;
 }
 
-// returns false (block-uniform) when the brick owns no atoms
-__device__ inline bool brick_setup(const BrickArgs &g, BrickHdr &H, int *overflow)
+// XCD-aware order: workgroups b and b+8 share an L2, so each XCD walks a contiguous run of the ACTIVE list (the
+// compacted, Morton-ordered ids of the bricks that own atoms).  The count may live on the device (no host round trip
+// between the compaction and the launches): the grid then covers every brick and the surplus workgroups exit.
+__device__ inline int brick_slot(const BrickArgs &g)
 {
-    const int tid = threadIdx.x;
-    // XCD-aware order: blocks b and b+8 share an L2, so each XCD walks a contiguous run of the active list
-    const int nb2 = gridDim.x;
-    int slot = (nb2 & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nb2 >> 3) + (blockIdx.x >> 3));
-    if (slot >= g.nactive) return false;
-    const int blk = g.active[slot];
-    const int sec = blk / g.nbricks, B = blk % g.nbricks;
-    if (tid <= 32) H.ostart[tid] = g.estart[(size_t)sec * g.M + 32 * B + tid];
-    __syncthreads();
-    const int o0 = H.ostart[0], n_own = H.ostart[32] - o0;
-    if (n_own <= 0) return false;
-    const u32 code0 = 32u * (u32)B;
+    const int na = g.nactive_dev ? *g.nactive_dev : g.nactive;
+    const int per = (na + 7) >> 3;
+    const int r = (int)(blockIdx.x >> 3);
+    if (r >= per) return -1;
+    const int slot = (int)(blockIdx.x & 7) * per + r;
+    return slot < na ? slot : -1;
+}
+
+// =========================================================================================
+// plan: halo map, halo-bin offsets, own-atom slots (once per rebuild)
+// =========================================================================================
+__global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict__ overflow)
+{
+    __shared__ int hoff[BRK_NHB + 1];
+    __shared__ int hs0[BRK_NHB], hl0[BRK_NHB], hs1[BRK_NHB], hl1[BRK_NHB], hs2[BRK_NHB];
+    __shared__ int ostart[2][BRK_CODES + 1];
+    __shared__ int wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int slot = brick_slot(g);
+    if (slot < 0) return;
+    const int B = g.active ? g.active[slot] : slot;
+    if (tid <= BRK_CODES) {
+        ostart[0][tid] = g.estart[(size_t)BRK_CODES * B + tid];
+        ostart[1][tid] = g.estart[(size_t)g.M + (size_t)BRK_CODES * B + tid];
+    }
+    const u32 code0 = (u32)BRK_CODES * (u32)B;
     const int bx0 = (int)compact3(code0), by0 = (int)compact3(code0 >> 1), bz0 = (int)compact3(code0 >> 2);
     int tot = 0;
     if (tid < BRK_NHB) {
-        int hx = bx0 - 1 + tid % BRK_HX, hy = by0 - 1 + (tid / BRK_HX) % BRK_HY, hz = bz0 - 1 + tid / (BRK_HX * BRK_HY);
+        const int hx = bx0 - 1 + tid % BRK_H, hy = by0 - 1 + (tid / BRK_H) % BRK_H, hz = bz0 - 1 + tid / (BRK_H * BRK_H);
         int s0 = 0, l0 = 0, s1 = 0, l1 = 0, s2 = 0, l2 = 0;
         if (hx >= 0 && hx < g.mbin[0] && hy >= 0 && hy < g.mbin[1] && hz >= 0 && hz < g.mbin[2]) {
-            u32 m = interleave3((u32)hx, (u32)hy, (u32)hz);
+            const u32 m = interleave3((u32)hx, (u32)hy, (u32)hz);
             s0 = g.estart[m]; l0 = g.estart[m + 1] - s0;
             s1 = g.estart[(size_t)g.M + m]; l1 = g.estart[(size_t)g.M + m + 1] - s1;
             s2 = g.ghost_base + g.gstart[m]; l2 = g.gstart[m + 1] - g.gstart[m];
         }
-        H.hs0[tid] = s0; H.hl0[tid] = l0; H.hs1[tid] = s1; H.hl1[tid] = l1; H.hs2[tid] = s2;
+        hs0[tid] = s0; hl0[tid] = l0; hs1[tid] = s1; hl1[tid] = l1; hs2[tid] = s2;
         tot = l0 + l1 + l2;
     }
-    // exclusive scan of tot over the first 3 waves
     int incl = tot;
-    const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(incl, o, 64);
+        const int t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
-    if (lane == 63 && w < 3) H.wtot[w] = incl;
+    if (lane == 63) wtot[w] = incl;
     __syncthreads();
-    if (tid < BRK_NHB) {
-        int base = 0;
-        for (int k = 0; k < w; k++) base += H.wtot[k];
-        H.hoff[tid] = base + incl - tot;
-        if (tid == BRK_NHB - 1) H.hoff[BRK_NHB] = base + incl;
-    }
+    int base = 0;
+    for (int k = 0; k < w; k++) base += wtot[k];
+    if (tid < BRK_NHB) hoff[tid] = base + incl - tot;
+    if (tid == BRK_NHB - 1) hoff[BRK_NHB] = base + incl;
     __syncthreads();
-    const int nh = H.hoff[BRK_NHB];
-    if (nh > BRK_MAXH || n_own > BRK_MAXOWN) {
-        if (tid == 0) atomicMax(overflow, 100000 + (nh > BRK_MAXH ? nh : n_own));
-        return false;
+    const int nh = hoff[BRK_NHB];
+    const int o0 = ostart[0][0], n0 = ostart[0][BRK_CODES] - o0, o1 = ostart[1][0], n1 = ostart[1][BRK_CODES] - o1;
+    int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
+    if (n0 + n1 == 0) {                       // a brick that owns nothing (identity active list)
+        if (tid == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 0; }
+        return;
     }
-    if (tid == 0) { H.nh = nh; H.n_own = n_own; H.o0 = o0; H.sec = sec; }
-    __syncthreads();
-    return true;
-}
-
-// halo-local index -> global (cell-order) atom index
-__device__ inline int halo_src(const BrickHdr &H, int h)
-{
-    int lo = 0, hi = BRK_NHB;            // largest hb with hoff[hb] <= h
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (H.hoff[mid] <= h) lo = mid; else hi = mid;
+    if (nh > BRK_MAXH || n0 + n1 > BRK_MAXOWN) {
+        if (tid == 0) {
+            atomicMax(overflow, 100000 + (nh > BRK_MAXH ? nh : n0 + n1));
+            hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 0;
+        }
+        return;
     }
-    int off = h - H.hoff[lo];
-    if (off < H.hl0[lo]) return H.hs0[lo] + off;
-    off -= H.hl0[lo];
-    if (off < H.hl1[lo]) return H.hs1[lo] + off;
-    return H.hs2[lo] + (off - H.hl1[lo]);
-}
-
-// own atom o (0-based inside the brick section) -> its brick-local bin k (0..31) and halo-local index
-__device__ inline int own_loc(const BrickHdr &H, int o, int &hb_out)
-{
-    const int i = H.o0 + o;
-    int lo = 0, hi = 32;                 // largest k with ostart[k] <= i
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (H.ostart[mid] <= i) lo = mid; else hi = mid;
+    if (tid == 0) { hdr[0] = nh; hdr[1] = o0; hdr[2] = n0; hdr[3] = o1; hdr[4] = n1; }
+    for (int t = tid; t <= BRK_NHB; t += 256) g.hoff[(size_t)slot * BRK_HOFF_PITCH + t] = hoff[t];
+    if (tid < BRK_NHB) g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + tid] = hl0[tid] + hl1[tid];
+    // halo slot -> global (cell-order) atom index
+    for (int h = tid; h < nh; h += 256) {
+        int lo = 0, hi = BRK_NHB;            // largest hb with hoff[hb] <= h
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (hoff[mid] <= h) lo = mid; else hi = mid;
+        }
+        int off = h - hoff[lo], src;
+        if (off < hl0[lo]) src = hs0[lo] + off;
+        else if ((off -= hl0[lo]) < hl1[lo]) src = hs1[lo] + off;
+        else src = hs2[lo] + (off - hl1[lo]);
+        g.hmap[(size_t)slot * BRK_MAXH + h] = (u32)src;
     }
-    const int k = lo;
-    const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1), kz = (k >> 2) & 1;
-    const int hb = (kx + 1) + BRK_HX * ((ky + 1) + BRK_HY * (kz + 1));
-    hb_out = hb;
-    return H.hoff[hb] + (H.sec ? H.hl0[hb] : 0) + (i - H.ostart[k]);
+    // own atom -> (halo slot, halo bin)
+    for (int s = 0; s < 2; s++) {
+        const int ns = s ? n1 : n0;
+        for (int o = tid; o < ns; o += 256) {
+            const int i = ostart[s][0] + o;
+            int lo = 0, hi = BRK_CODES;      // largest k with ostart[s][k] <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (ostart[s][mid] <= i) lo = mid; else hi = mid;
+            }
+            const int k = lo;
+            const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
+                      kz = ((k >> 2) & 1) | (((k >> 5) & 1) << 1);
+            const int hb = (kx + 1) + BRK_H * ((ky + 1) + BRK_H * (kz + 1));
+            const int hslot = hoff[hb] + (s ? hl0[hb] : 0) + (i - ostart[s][k]);
+            g.own_info[i] = (u32)hslot | ((u32)hb << 16);
+        }
+    }
 }
 
 // =========================================================================================
 // neighbour table builder
 // =========================================================================================
-__global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const float4 *__restrict__ coord4,
-                                                            float rc2, int n_col, int *__restrict__ count,
-                                                            unsigned short *__restrict__ table16,
-                                                            int *__restrict__ overflow)
+__global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
+                                                            int n_col, int *__restrict__ count,
+                                                            unsigned short *__restrict__ table16, int *__restrict__ overflow)
 {
-    __shared__ BrickHdr H;
+#pragma clang fp contract(fast)
     __shared__ float4 hc[BRK_MAXH];
-    if (!brick_setup(g, H, overflow)) return;
+    __shared__ int hoff[BRK_NHB + 1];
+    __shared__ u32 stage[8 * BRK_THREADS];      // stage[q][thread]: the open 8-entry chunk of each lane
     const int tid = threadIdx.x;
-    for (int h = tid; h < H.nh; h += BRK_THREADS) hc[h] = coord4[halo_src(H, h)];
+    const int slot = brick_slot(g);
+    if (slot < 0) return;
+    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
+    const int nh = hdr[0], o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
+    if (n0 + n1 == 0) return;
+    for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
+    for (int h = tid; h < nh; h += BRK_THREADS) hc[h] = coord4[g.hmap[(size_t)slot * BRK_MAXH + h]];
     __syncthreads();
-    for (int o = tid; o < H.n_own; o += BRK_THREADS) {
-        int hb;
-        const int loc = own_loc(H, o, hb);
-        const int i = H.o0 + o;
+    uint4 *rows = (uint4 *)table16;
+    for (int o = tid; o < n0 + n1; o += BRK_THREADS) {
+        const int i = o < n0 ? o0 + o : o1 + (o - n0);
+        const u32 info = g.own_info[i];
+        const int loc = (int)(info & 0xFFFFu), hb = (int)(info >> 16);
         const float4 ci = hc[loc];
-        uint4 *rows = (uint4 *)table16;
         int n = 0;
-        u64 lo = 0, hi = 0;
-        auto push = [&](int k) {
-            int q = n & 7;
-            if (q < 4) lo |= (u64)(u32)k << (16 * q);
-            else hi |= (u64)(u32)k << (16 * (q - 4));
-            if (q == 7) {
-                if (n < n_col) rows[row_word(i, n >> 3, n_col)] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-                lo = 0; hi = 0;
+        auto flush = [&](int c) {
+            const u32 e0 = stage[tid], e1 = stage[BRK_THREADS + tid], e2 = stage[2 * BRK_THREADS + tid],
+                      e3 = stage[3 * BRK_THREADS + tid], e4 = stage[4 * BRK_THREADS + tid], e5 = stage[5 * BRK_THREADS + tid],
+                      e6 = stage[6 * BRK_THREADS + tid], e7 = stage[7 * BRK_THREADS + tid];
+            rows[row_word(i, c, n_col)] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
+        };
+        auto test = [&](int k, const float4 c) {
+            const float dx = ci.x - c.x, dy = ci.y - c.y, dz = ci.z - c.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d <= rc2 && k != loc) {
+                stage[(n & 7) * BRK_THREADS + tid] = (u32)k << 4;        // byte offset into the staged coordinates
+                if ((n & 7) == 7 && n < n_col) flush(n >> 3);
+                n++;
             }
-            n++;
         };
 #pragma unroll 1
         for (int r = 0; r < 9; r++) {
-            // x-adjacent halo bins are consecutive halo-bin indices: one contiguous run of halo-local slots
-            const int hrow = hb + (r % 3 - 1) * BRK_HX + (r / 3 - 1) * BRK_HX * BRK_HY;
-            const int kb = H.hoff[hrow - 1], ke = H.hoff[hrow + 2];
+            // x-adjacent halo bins are consecutive halo-bin indices: one contiguous run of halo slots per (y,z) row
+            const int hrow = hb + (r % 3 - 1) * BRK_H + (r / 3 - 1) * BRK_H * BRK_H;
+            const int kb = hoff[hrow - 1], ke = hoff[hrow + 2];
             int k = kb;
-            for (; k + 4 <= ke; k += 4) {       // 4 LDS gathers in flight per lane
-                float4 c0 = hc[k], c1 = hc[k + 1], c2 = hc[k + 2], c3 = hc[k + 3];
-                float d0 = dist2(ci, c0), d1 = dist2(ci, c1), d2 = dist2(ci, c2), d3 = dist2(ci, c3);
-                if (k != loc && d0 <= rc2) push(k);
-                if (k + 1 != loc && d1 <= rc2) push(k + 1);
-                if (k + 2 != loc && d2 <= rc2) push(k + 2);
-                if (k + 3 != loc && d3 <= rc2) push(k + 3);
+            for (; k + 4 <= ke; k += 4) {       // 4 LDS reads in flight per lane
+                const float4 c0 = hc[k], c1 = hc[k + 1], c2 = hc[k + 2], c3 = hc[k + 3];
+                test(k, c0); test(k + 1, c1); test(k + 2, c2); test(k + 3, c3);
             }
-            for (; k < ke; k++) {
-                float d0 = dist2(ci, hc[k]);
-                if (k != loc && d0 <= rc2) push(k);
-            }
+            for (; k < ke; k++) test(k, hc[k]);
         }
-        if ((n & 7) && n < n_col) rows[row_word(i, n >> 3, n_col)] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+        // tail chunk: unused slots point at the atom itself (rsq = 0 is rejected by the force kernel)
+        if ((n & 7) && n < n_col) {
+            for (int q = n & 7; q < 8; q++) stage[q * BRK_THREADS + tid] = (u32)loc << 4;
+            flush(n >> 3);
+        }
         if (n > n_col) { atomicMax(overflow, n); n = n_col; }
         count[i] = n;
     }
 }
 
-// halo-local rows -> global-index rows (for the lane-per-atom kernels, energy/virial steps and the tests)
-__global__ void __launch_bounds__(BRK_THREADS) k_brick_convert(BrickArgs g, int n_col, const int *__restrict__ count,
-                                                              const unsigned short *__restrict__ table16,
-                                                              int *__restrict__ table32, int *__restrict__ overflow)
+
+// =========================================================================================
+// neighbour table builder, wave-per-bin ballot stenciling (cell-ordered layout, global-index rows)
+// =========================================================================================
+// The reference's formulation (gpu_build_neighbor_list, neigh_build_meso.cu:20-119: a warp walks the stencil of one
+// bin, ballot + popc compaction, no global atomics) on wave64 with the neighbourhood in LDS:
+//   lanes = candidates: the 27-bin stencil of an own bin is 9 contiguous runs of halo slots (x-adjacent halo bins
+//     are consecutive), ~237 atoms = 4 batches of 64, each candidate read from LDS once per group of own atoms;
+//   own atoms of the bin are taken 8 at a time: their coordinates are held in SGPRs, every (own atom, batch) step is 6 VALU for the distance, one compare, ballot, mbcnt and a 2-byte LDS
+//     store of the candidate's slot into the atom's staged row;
+//   rows leave LDS as whole 32-byte chunks of the chunked-8 table (8 lanes per atom), slots translated to global
+//     indices on the way out, tail slots padded with the atom itself.
+// Entry order inside a row is (batch, lane): deterministic, and different from the lane-per-atom builders.
+#define TB_G 8
+#define TB_ROWCAP 192
+
+template <bool EXCL>
+__global__ void __launch_bounds__(BRK_THREADS, 2) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
+                                                              int n_col, int *__restrict__ count, int *__restrict__ table,
+                                                              int *__restrict__ overflow, ExclArgs ex)
 {
-    __shared__ BrickHdr H;
-    if (!brick_setup(g, H, overflow)) return;
-    for (int o = threadIdx.x; o < H.n_own; o += BRK_THREADS) {
-        const int i = H.o0 + o;
+#pragma clang fp contract(fast)
+    __shared__ float4 hc[BRK_MAXH];
+    __shared__ u32 hgi[BRK_MAXH];
+    __shared__ int hoff[BRK_NHB + 1];
+    __shared__ int hloc[BRK_NHB];
+    __shared__ unsigned short rowbuf[BRK_WAVES][TB_G][TB_ROWCAP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int slot = brick_slot(g);
+    if (slot < 0) return;
+    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
+    const int nh = hdr[0];
+    if (hdr[2] + hdr[4] == 0) return;
+    for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
+    for (int t = tid; t < BRK_NHB; t += BRK_THREADS) hloc[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + t];
+    for (int h = tid; h < nh; h += BRK_THREADS) {
+        const u32 src = g.hmap[(size_t)slot * BRK_MAXH + h];
+        hgi[h] = src;
+        hc[h] = coord4[src];
+    }
+    __syncthreads();
+    int4 *rows = (int4 *)table;
+    unsigned short (*myrow)[TB_ROWCAP] = rowbuf[w];
+
+    for (int k = w; k < BRK_CODES; k += BRK_WAVES) {
+        const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
+                  kz = ((k >> 2) & 1) | (((k >> 5) & 1) << 1);
+        const int hb = (kx + 1) + BRK_H * ((ky + 1) + BRK_H * (kz + 1));
+        // wave-uniform values are forced into SGPRs: counters, branches and the own coordinates then stay scalar
+        const int own0 = __builtin_amdgcn_readfirstlane(hoff[hb]), na = __builtin_amdgcn_readfirstlane(hloc[hb]);
+        if (na == 0) continue;
+        // the 9 candidate runs and their prefix
+        int rstart[9], pre[10];
+        pre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int hrow = hb + (r % 3 - 1) * BRK_H + (r / 3 - 1) * BRK_H * BRK_H;
+            rstart[r] = __builtin_amdgcn_readfirstlane(hoff[hrow - 1]);
+            pre[r + 1] = pre[r] + (__builtin_amdgcn_readfirstlane(hoff[hrow + 2]) - rstart[r]);
+        }
+        const int ncand = pre[9];
+        const int nbatch = (ncand + 63) >> 6;
+
+        for (int g0 = 0; g0 < na; g0 += TB_G) {
+            const int ng = min(TB_G, na - g0);
+            // own atoms of this group: global index and coordinates through the scalar unit
+            int gi[TB_G];
+            float ox[TB_G], oy[TB_G], oz[TB_G];
+#pragma unroll
+            for (int t = 0; t < TB_G; t++) {
+                gi[t] = 0; ox[t] = oy[t] = oz[t] = 0.f;
+                if (t < ng) {
+                    gi[t] = __builtin_amdgcn_readfirstlane((int)hgi[own0 + g0 + t]);
+                    const float4 c = hc[own0 + g0 + t];           // one LDS word for the whole wave, then SGPRs
+                    ox[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.x)));
+                    oy[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.y)));
+                    oz[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.z)));
+                }
+            }
+            int nrow[TB_G];
+#pragma unroll
+            for (int t = 0; t < TB_G; t++) nrow[t] = 0;
+
+            for (int b = 0; b < nbatch; b++) {
+                const int id = (b << 6) + lane;
+                int base = rstart[0];
+#pragma unroll
+                for (int r = 1; r < 9; r++) base = id >= pre[r] ? rstart[r] - pre[r] : base;
+                const bool valid = id < ncand;
+                const int cs = valid ? id + base : 0;
+                float4 c = hc[cs];
+                c.x = valid ? c.x : 1.0e18f;          // never inside the cutoff
+                int ctag = 0;
+                if (EXCL) ctag = ex.tagc[hgi[cs]];
+#pragma unroll
+                for (int t = 0; t < TB_G; t++) {
+                    if (t < ng) {
+                        const float dx = ox[t] - c.x, dy = oy[t] - c.y, dz = oz[t] - c.z;
+                        const float d = dx * dx + dy * dy + dz * dz;
+                        bool hit = (d <= rc2) & (cs != own0 + g0 + t);
+                        if (EXCL) {
+                            // gpu_filter_exclusion (neigh_build_meso.cu:497-544): drop special partners by tag
+                            const int nsp = ex.nspecial[gi[t]];
+                            for (int sp = 0; sp < nsp; sp++) hit = hit & (ex.special[(size_t)gi[t] * ex.msp + sp] != ctag);
+                        }
+                        const u64 m = __builtin_amdgcn_ballot_w64(hit);
+                        if (m) {
+                            const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
+                            if (hit) myrow[t][min(pos, (u32)(TB_ROWCAP - 1))] = (unsigned short)cs;
+                            nrow[t] += __popcll(m);
+                        }
+                    }
+                }
+            }
+            // rows out: 8 lanes per atom, one 32-byte chunk per lane and pass
+            const int t = lane >> 3;
+            int n = nrow[0], i = gi[0];
+#pragma unroll
+            for (int u = 1; u < TB_G; u++) { n = t == u ? nrow[u] : n; i = t == u ? gi[u] : i; }
+            if (t < ng) {
+                if ((lane & 7) == 0) {
+                    if (n > n_col) atomicMax(overflow, n);
+                    count[i] = min(n, n_col);
+                }
+                const int nn = min(n, min(n_col, TB_ROWCAP));
+                for (int c = lane & 7; c * 8 < nn; c += 8) {
+                    const uint4 pk = *(const uint4 *)&myrow[t][c * 8];
+                    const u32 wv[4] = {pk.x, pk.y, pk.z, pk.w};
+                    int e[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const u32 sl = (q & 1) ? (wv[q >> 1] >> 16) : (wv[q >> 1] & 0xFFFFu);
+                        e[q] = c * 8 + q < nn ? (int)hgi[sl < (u32)BRK_MAXH ? sl : 0] : i;
+                    }
+                    int4 *wr = rows + 2 * row_word8(i, c, n_col);
+                    wr[0] = make_int4(e[0], e[1], e[2], e[3]);
+                    wr[1] = make_int4(e[4], e[5], e[6], e[7]);
+                }
+            }
+        }
+    }
+}
+
+// halo-local rows -> global-index rows, transposed 64-atom tiles (for the lane-per-atom kernels, energy/virial
+// steps and the introspection calls)
+__global__ void __launch_bounds__(256) k_brick_convert(BrickArgs g, int n_col, const int *__restrict__ count,
+                                                      const unsigned short *__restrict__ table16,
+                                                      int *__restrict__ table32)
+{
+    const int slot = brick_slot(g);
+    if (slot < 0) return;
+    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
+    const int o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
+    const u32 *hmap = g.hmap + (size_t)slot * BRK_MAXH;
+    for (int o = threadIdx.x; o < n0 + n1; o += 256) {
+        const int i = o < n0 ? o0 + o : o1 + (o - n0);
         const size_t base = ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
         const int n = count[i];
         for (int p = 0; p < n; p++)
-            table32[base + (size_t)p * 64] = halo_src(H, (int)table16[row_word(i, p >> 3, n_col) * 8 + (p & 7)]);
+            table32[base + (size_t)p * 64] = (int)hmap[table16[row_word(i, p >> 3, n_col) * 8 + (p & 7)] >> 4];
     }
 }
 
 // =========================================================================================
-// pair force
+// pair force (dpd/fast/meso)
 // =========================================================================================
-template <bool FAST>
-__global__ void __launch_bounds__(BRK_THREADS) k_brick_pair(BrickArgs g, PairArgs a,
-                                                           const unsigned short *__restrict__ table16,
-                                                           int *__restrict__ overflow)
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT1>
+__global__ void __launch_bounds__(BRK_THREADS, 2) k_brick_pair(BrickArgs g, PairArgs a,
+                                                              const unsigned short *__restrict__ table16)
 {
-    // fp32 style: 64-bit fixed-point sums (ds_add_u64; float LDS atomics serialise on gfx950, see pair_ring.hip)
-    typedef typename std::conditional<FAST, u64, double>::type acc_t;
-    __shared__ BrickHdr H;
-    __shared__ float4 hc[BRK_MAXH];
-    __shared__ float4 hv[BRK_MAXH];
-    __shared__ int ring[BRK_WAVES][BRK_RING];
-    __shared__ unsigned short oloc[BRK_MAXOWN];
-    __shared__ acc_t facc[3][BRK_MAXOWN];
-    extern __shared__ double cf_dyn[];
-    double *cf64 = cf_dyn;
-    float *cf32 = (float *)cf_dyn;
+#pragma clang fp contract(fast)
+    __shared__ float4 hc[BRK_MAXH];              // staged coordinates (x, y, z, type)
+    __shared__ u32 hgi[BRK_MAXH];                // halo slot -> global index (velocity gathers of the hits)
+    __shared__ u32 ring[BRK_WAVES][BRK_RING];    // per wave: queued hits, owner lane << 16 | partner byte offset
+    __shared__ u64 facc[BRK_WAVES][3][64];       // per wave: force sums, 2^-32 fixed point
+    extern __shared__ float cf32[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ncf = a.ntypes * a.ntypes * N_COEFF;
-    for (int p = tid; p < ncf; p += BRK_THREADS) {
-        if (FAST) cf32[p] = a.coeff32[p];
-        else cf64[p] = a.coeff64[p];
-    }
-    if (!brick_setup(g, H, overflow)) return;
-    // work-range filter (compute_bulk / compute_border): section 0 = bulk, 1 = border
-    if (H.o0 >= a.end || H.o0 + H.n_own <= a.beg) return;
-    for (int h = tid; h < H.nh; h += BRK_THREADS) {
-        int src = halo_src(H, h);
+    const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * N_COEFF;
+    for (int p = tid; p < ncf; p += BRK_THREADS) cf32[p] = a.coeff32[p];
+    const int slot = brick_slot(g);
+    if (slot < 0) return;
+    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
+    const int nh = hdr[0], o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
+    const int n_own = n0 + n1;
+    if (n_own == 0) return;
+    // work-range filter (compute_bulk / compute_border): nothing of this brick inside [beg, end)
+    if ((n0 == 0 || o0 >= a.end || o0 + n0 <= a.beg) && (n1 == 0 || o1 >= a.end || o1 + n1 <= a.beg)) return;
+    for (int h = tid; h < nh; h += BRK_THREADS) {
+        const u32 src = g.hmap[(size_t)slot * BRK_MAXH + h];
+        hgi[h] = src;
         hc[h] = a.coord4[src];
-        hv[h] = a.veloc4[src];
-    }
-    for (int o = tid; o < H.n_own; o += BRK_THREADS) {
-        int hb;
-        oloc[o] = (unsigned short)own_loc(H, o, hb);
-        facc[0][o] = 0; facc[1][o] = 0; facc[2][o] = 0;
     }
     __syncthreads();
     if (a.debug == 1) return;
 
-    const u64 lt = (1ULL << lane) - 1ULL;
-    const float dtis32 = (float)a.dt_inv_sqrt;
-    int *myring = ring[w];
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, a.nall * 16, 0x00020000);
+    const float dtis = (float)a.dt_inv_sqrt;
+    const uint4 *rows = (const uint4 *)table16;
+    u32 *myring = ring[w];
+    u64 *myf = &facc[w][0][0];
+    const char *hcb = (const char *)hc;
 
-    for (int obase = w * 64; obase < H.n_own; obase += BRK_WAVES * 64) {
+    for (int obase = w * 64; obase < n_own; obase += BRK_WAVES * 64) {
         const int o = obase + lane;
-        const bool mine = o < H.n_own;
-        const int i = H.o0 + o;
-        int n = 0, loc = 0;
-        float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mine) { loc = oloc[o]; c1 = hc[loc]; n = a.count[i]; }
+        const int i = o < n0 ? o0 + o : o1 + (o - n0);
+        const bool mine = o < n_own && i >= a.beg && i < a.end;
+        int n = 0;
+        u32 myoff = 0;
+        float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
+        if (mine) {
+            myoff = (g.own_info[i] & 0xFFFFu) << 4;
+            c1 = *(const float4 *)(hcb + myoff);
+            v1 = a.veloc4[i];
+            n = a.count[i];
+        }
+        myf[lane] = 0; myf[64 + lane] = 0; myf[128 + lane] = 0;
         const u32 t1 = __float_as_uint(c1.w);
-        const uint4 *rows = (const uint4 *)table16;
-        int nmax = n;
+        const u32 lanehi = (u32)lane << BRK_OWNER_SHIFT;
+        const int nch = (n + 7) >> 3;
+        int nchmax = nch;
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) nmax = max(nmax, __shfl_xor(nmax, s, 64));
-        int qhead = 0, qtail = 0;
+        for (int s = 32; s > 0; s >>= 1) nchmax = max(nchmax, __shfl_xor(nchmax, s, 64));
+        nchmax = __builtin_amdgcn_readfirstlane(nchmax);
 
-        auto drain = [&](int nb) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < nb && a.debug != 2) {
-                int pk = myring[(qhead + lane) & (BRK_RING - 1)];
-                int j = pk & 0xFFFF, oo = pk >> 16;
-                int li = oloc[oo];
-                float4 ci = hc[li], vi = hv[li], cj = hc[j], vj = hv[j];
-                u32 si = __float_as_uint(vi.w), sj = __float_as_uint(vj.w);
-                int cidx = __float_as_uint(ci.w) * a.ntypes + __float_as_uint(cj.w);
-                if (FAST) {
-                    const float *cf = cf32 + cidx * N_COEFF;
-                    float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
-                    float rsq = dx * dx + dy * dy + dz * dz;
-                    float rn = gaussian_tea_fast(si, sj);
-                    float rinv = __builtin_amdgcn_rsqf(rsq);
-                    float r = rsq * rinv;
-                    float dvx = vi.x - vj.x, dvy = vi.y - vj.y, dvz = vi.z - vj.z;
-                    float dot = dx * dvx + dy * dvy + dz * dvz;
-                    float wc = 1.0f - r * cf[P_CUTINV];
-                    float ew = cf[P_EXPW];
-                    float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
-                    float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
+        int qhead = 0, qtail = 0;     // wave-uniform
+        int pn = 0;                   // hits of the batch whose velocity gathers are in flight
+        u32 pe = 0;
+        float4 pv2 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        auto compute = [&]() {        // evaluate the pending batch (lane = hit)
+            if (pn > 0) {
+                // the owner's slot and velocity come from the owner lane's registers: fetched with every lane enabled
+                // (a bpermute reads 0 from disabled lanes)
+                const u32 owner = pe >> BRK_OWNER_SHIFT;
+                const int oaddr = (int)(owner << 2);
+                const u32 ooff = (u32)__builtin_amdgcn_ds_bpermute(oaddr, (int)myoff);
+                float4 vi;
+                vi.x = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.x)));
+                vi.y = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.y)));
+                vi.z = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.z)));
+                vi.w = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.w)));
+                if (lane < pn) {
+                    const float4 ci = *(const float4 *)(hcb + ooff), cj = *(const float4 *)(hcb + (pe & 0xFFFFu));
+                    float c_cutinv, c_ew, c_a0, c_gamma, c_sigma;
+                    if (NT1) {
+                        c_cutinv = (float)a.cf1[P_CUTINV]; c_ew = (float)a.cf1[P_EXPW]; c_a0 = (float)a.cf1[P_A0];
+                        c_gamma = (float)a.cf1[P_GAMMA]; c_sigma = (float)a.cf1[P_SIGMA];
+                    } else {
+                        const float *cf = cf32 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(cj.w)) * N_COEFF;
+                        c_cutinv = cf[P_CUTINV]; c_ew = cf[P_EXPW]; c_a0 = cf[P_A0]; c_gamma = cf[P_GAMMA]; c_sigma = cf[P_SIGMA];
+                    }
+                    const float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
+                    const float rsq = dx * dx + dy * dy + dz * dz;
+                    const float rn = gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w));
+                    const float rinv = __builtin_amdgcn_rsqf(rsq);
+                    const float r = rsq * rinv;
+                    const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;
+                    const float dot = dx * dvx + dy * dvy + dz * dvz;
+                    const float wc = 1.0f - r * c_cutinv;
+                    float wr = wc;
+                    if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
+                    float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
                     fpair *= rinv;
-                    __hip_atomic_fetch_add((u64 *)&facc[0][oo], to_fixed(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add((u64 *)&facc[1][oo], to_fixed(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add((u64 *)&facc[2][oo], to_fixed(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                } else {
-                    const double *cf = cf64 + cidx * N_COEFF;
-                    double dx = (double)ci.x - (double)cj.x, dy = (double)ci.y - (double)cj.y, dz = (double)ci.z - (double)cj.z;
-                    double rsq = dx * dx + dy * dy + dz * dz;
-                    double rn = gaussian_tea(si, sj);
-                    double rinv = rsqrt(rsq);
-                    double r = rsq * rinv;
-                    double dvx = (double)vi.x - (double)vj.x, dvy = (double)vi.y - (double)vj.y, dvz = (double)vi.z - (double)vj.z;
-                    double dot = dx * dvx + dy * dvy + dz * dvz;
-                    double wc = 1.0 - r * cf[P_CUTINV];
-                    double ew = cf[P_EXPW];
-                    double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
-                    double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
-                    fpair *= rinv;
-                    __hip_atomic_fetch_add((double *)&facc[0][oo], dx * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add((double *)&facc[1][oo], dy * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add((double *)&facc[2][oo], dz * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&myf[owner], to_fixed(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&myf[64 + owner], to_fixed(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&myf[128 + owner], to_fixed(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
+                pn = 0;
             }
+        };
+        auto issue = [&](int nb) {    // request the partner velocities of the next nb queued hits
+            if (lane < nb) {
+                pe = myring[(qhead + lane) & (BRK_RING - 1)];
+                const u32 gj = hgi[(pe & 0xFFFFu) >> 4];
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(gj << 4), 0, 0);
+                pv2 = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+            pn = nb;
             qhead += nb;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
 
-        const int nchunk = (nmax + 7) >> 3;
+        const uint4 *myrows = rows + row_word(mine ? i : 0, 0, a.n_col);
         uint4 wcur = make_uint4(0, 0, 0, 0);
-        if (mine && n > 0) wcur = rows[row_word(i, 0, a.n_col)];
-        for (int c = 0; c < nchunk; c++) {
-            // prefetch the next 8 entries of my row while this chunk is tested
-            uint4 wnext = make_uint4(0, 0, 0, 0);
-            if (mine && (c + 1) * 8 < n) wnext = rows[row_word(i, c + 1, a.n_col)];
+        if (nch > 0) wcur = myrows[0];
+#pragma unroll 1
+        for (int c = 0; c < nchmax; c++) {
+            const bool active = c < nch;
             const u32 ww[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
-            int jj[8];
-            float4 cc[8];
+            if (c + 1 < nch) wcur = myrows[(size_t)(c + 1) * 64];
+            // two half-chunks of 4: LDS latency is short, and 4 partner coordinates in flight keep the kernel at
+            // 80 VGPRs (two workgroups of 10 waves per CU need 6 wave slots on a SIMD)
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                jj[q] = (int)((ww[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
-                cc[q] = hc[jj[q]];            // entries past my count are 0: a valid slot, masked below
-            }
+            for (int hq = 0; hq < 2; hq++) {
+                u32 joff[4];
+                float4 c2[4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const bool active = c * 8 + q < n;
-                const float4 c2 = cc[q];
-                const int cidx = t1 * a.ntypes + __float_as_uint(c2.w);
-                bool hit;
-                if (FAST) {
-                    float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
-                    float rsq = dx * dx + dy * dy + dz * dz;
-                    hit = active && rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
-                } else {
-                    double dx = (double)c1.x - (double)c2.x, dy = (double)c1.y - (double)c2.y, dz = (double)c1.z - (double)c2.z;
-                    double rsq = dx * dx + dy * dy + dz * dz;
-                    hit = active && rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
+                for (int q = 0; q < 4; q++) {
+                    const u32 word = ww[2 * hq + (q >> 1)];
+                    joff[q] = (q & 1) ? (word >> 16) : (word & 0xFFFFu);
+                    c2[q] = *(const float4 *)(hcb + joff[q]);      // lanes past their row re-read a valid slot; masked below
                 }
-                const u64 m = __ballot(hit);
-                if (m) {
-                    if (hit) myring[(qtail + __popcll(m & lt)) & (BRK_RING - 1)] = jj[q] | (o << 16);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
+                    const float rsq = dx * dx + dy * dy + dz * dz;
+                    const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
+                    const bool hit = active & (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ);    // tail slots hold the atom itself
+                    const u64 m = __builtin_amdgcn_ballot_w64(hit);
+                    if (hit) myring[(qtail + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))) & (BRK_RING - 1)] = joff[q] | lanehi;
                     qtail += __popcll(m);
-                    if (qtail - qhead >= 64) drain(64);
+                    if (q & 1) {
+                        while (qtail - qhead >= 64) { compute(); issue(64); }
+                    }
                 }
             }
-            wcur = wnext;
         }
-        if (qtail > qhead) drain(qtail - qhead);
+        compute();
+        while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
-        if (mine && i >= a.beg && i < a.end) {
-            double fx, fy, fz;
-            if (FAST) { fx = from_fixed((u64)facc[0][o]); fy = from_fixed((u64)facc[1][o]); fz = from_fixed((u64)facc[2][o]); }
-            else { fx = (double)facc[0][o]; fy = (double)facc[1][o]; fz = (double)facc[2][o]; }
+        if (mine) {
+            const double fx = from_fixed(myf[lane]), fy = from_fixed(myf[64 + lane]), fz = from_fixed(myf[128 + lane]);
             if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
             else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
         }
@@ -419,32 +586,36 @@ __global__ void __launch_bounds__(256) k_ghost_morton(const double *__restrict__
 
 static inline int brick_grid(const BrickArgs &g) { return (g.nactive + 7) / 8 * 8; }
 
-// flag[b] = 1 if (section, brick) b owns atoms; the engine scans the flags and compacts the ids
-__global__ void __launch_bounds__(256) k_brick_flags(const int *__restrict__ estart, int M, int nb2, int *__restrict__ flag)
+// flag[b] = 1 if brick b owns atoms (bulk or border section); the engine scans the flags and compacts the ids
+__global__ void __launch_bounds__(256) k_brick_flags(const int *__restrict__ estart, int M, int nb, int *__restrict__ flag)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb2) return;
-    int nbricks = M / 32, sec = b / nbricks, B = b % nbricks;
-    size_t e0 = (size_t)sec * M + 32 * (size_t)B;
-    flag[b] = estart[e0 + 32] > estart[e0] ? 1 : 0;
+    if (b >= nb) return;
+    const size_t e0 = (size_t)BRK_CODES * b, e1 = (size_t)M + e0;
+    flag[b] = (estart[e0 + BRK_CODES] > estart[e0] || estart[e1 + BRK_CODES] > estart[e1]) ? 1 : 0;
 }
-__global__ void __launch_bounds__(256) k_brick_compact(const int *__restrict__ flag, const int *__restrict__ pos, int nb2,
+__global__ void __launch_bounds__(256) k_brick_compact(const int *__restrict__ flag, const int *__restrict__ pos, int nb,
                                                        int *__restrict__ active, int *__restrict__ nactive)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb2) return;
+    if (b >= nb) return;
     if (flag[b]) active[pos[b]] = b;
-    if (b == nb2 - 1) *nactive = pos[b] + flag[b];
+    if (b == nb - 1) *nactive = pos[b] + flag[b];
 }
+int brick_codes() { return BRK_CODES; }
+size_t brick_hmap_pitch() { return BRK_MAXH; }
+size_t brick_hoff_pitch() { return BRK_HOFF_PITCH; }
+size_t brick_hdr_pitch() { return BRK_HDR_PITCH; }
+
 void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s)
 {
-    int nb2 = 2 * (M / 32);
-    hipLaunchKernelGGL(k_brick_flags, dim3((nb2 + 255) / 256), dim3(256), 0, s, estart, M, nb2, flag);
+    int nb = M / BRK_CODES;
+    hipLaunchKernelGGL(k_brick_flags, dim3((nb + 255) / 256), dim3(256), 0, s, estart, M, nb, flag);
 }
 void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s)
 {
-    int nb2 = 2 * (M / 32);
-    hipLaunchKernelGGL(k_brick_compact, dim3((nb2 + 255) / 256), dim3(256), 0, s, flag, pos, nb2, active, nactive);
+    int nb = M / BRK_CODES;
+    hipLaunchKernelGGL(k_brick_compact, dim3((nb + 255) / 256), dim3(256), 0, s, flag, pos, nb, active, nactive);
 }
 
 void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s)
@@ -466,6 +637,28 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
                            nghost, key, val);
 }
 
+void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s)
+{
+    if (g.nactive <= 0) return;
+    hipLaunchKernelGGL(k_brick_plan, dim3(brick_grid(g)), dim3(256), 0, s, g, overflow);
+}
+
+void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
+                       const ExclArgs *excl, hipStream_t s)
+{
+    if (g.nactive <= 0) return;
+    ExclArgs ex = {nullptr, nullptr, nullptr, 0};
+    if (excl && excl->tagc) {
+        ex = *excl;
+        hipLaunchKernelGGL((k_tile_build<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table,
+                           overflow, ex);
+    } else {
+        hipLaunchKernelGGL((k_tile_build<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table,
+                           overflow, ex);
+    }
+}
+int tile_build_rowcap() { return TB_ROWCAP; }
+
 void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,
                         unsigned short *table16, int *overflow, hipStream_t s)
 {
@@ -475,20 +668,19 @@ void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int
 }
 
 void launch_brick_convert(const BrickArgs &g, int n_col, const int *count, const unsigned short *table16, int *table32,
-                          int *overflow, hipStream_t s)
+                          hipStream_t s)
 {
     if (g.nactive <= 0) return;
-    hipLaunchKernelGGL(k_brick_convert, dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, n_col, count, table16, table32,
-                       overflow);
+    hipLaunchKernelGGL(k_brick_convert, dim3(brick_grid(g)), dim3(256), 0, s, g, n_col, count, table16, table32);
 }
 
-void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, int fast, int *overflow,
-                       hipStream_t s)
+void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, hipStream_t s)
 {
     if (p.end <= p.beg || g.nactive <= 0) return;
-    size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? 4 : 8);
-    if (fast) hipLaunchKernelGGL((k_brick_pair<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16, overflow);
-    else hipLaunchKernelGGL((k_brick_pair<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16, overflow);
+    const bool nt1 = p.ntypes == 1;
+    size_t sm = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * 4;
+    if (nt1) hipLaunchKernelGGL((k_brick_pair<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16);
+    else hipLaunchKernelGGL((k_brick_pair<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16);
 }
 
 } // namespace meso

@@ -188,6 +188,9 @@ private:
     int *estart = nullptr, *gstart = nullptr, *gslot = nullptr;
     int4 *binrange = nullptr;
     int *brick_flag = nullptr, *brick_pos = nullptr, *brick_active = nullptr;
+    int *brick_hoff = nullptr, *brick_hdr = nullptr;
+    uint32_t *brick_hmap = nullptr, *brick_own = nullptr;
+    size_t brick_cap = 0;
     size_t estart_cap = 0;
     unsigned short *table16 = nullptr;
     bool table32_valid = false;

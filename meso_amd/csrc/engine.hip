@@ -80,6 +80,7 @@ void Engine::free_all()
     sort_temp = nullptr;
     dfree(estart); dfree(gstart); dfree(gslot); dfree(table16);
     dfree(brick_flag); dfree(brick_pos); dfree(brick_active); dfree(binrange);
+    dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
     dfree(d_partial); dfree(d_scalar); dfree(d_flags); dfree(sendlist_aux);
     if (stage_send) (void)hipFree(stage_send);
@@ -329,6 +330,8 @@ int Engine::alloc_atoms(int cap)
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
         dfree(table16);
         HIPCHK(dalloc(table16, table_tiles * 64 * (size_t)n_col));
+        dfree(brick_own);
+        HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
     nmax = cap;
     return 0;
@@ -639,6 +642,8 @@ int Engine::init_params()
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
         dfree(table16);
         HIPCHK(dalloc(table16, table_tiles * 64 * (size_t)n_col));
+        dfree(brick_own);
+        HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
     {
         int max_bin = std::max(geom.mbin[0], std::max(geom.mbin[1], geom.mbin[2]));
@@ -663,7 +668,15 @@ int Engine::init_params()
                 sort_temp_bytes = tb;
             }
         }
-        bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / 32);
+        if (layout >= 1 && M / brick_codes() + 8 > brick_cap) {
+            dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr);
+            brick_cap = M / brick_codes() + 8;
+            HIPCHK(dalloc(brick_hoff, brick_cap * brick_hoff_pitch()));
+            HIPCHK(dalloc(brick_hmap, brick_cap * brick_hmap_pitch()));
+            HIPCHK(dalloc(brick_hdr, brick_cap * brick_hdr_pitch()));
+        }
+        bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / brick_codes());
+        bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
         for (int d = 0; d < 3; d++) bargs.mbin[d] = geom.mbin[d];
     }
     if (geom.nbin + 1 > bin_cap) {
@@ -787,12 +800,13 @@ int Engine::build_cells_and_table()
         // locals are already cell-ordered by the reorder sort; only the ghosts need binning
         tbegin("bin");
         launch_estart(rkey, nlocal, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);
-        if (layout == 1) {
-            launch_brick_flags(estart, bargs.M, brick_flag, stream);
-            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, brick_flag, brick_pos, 2 * bargs.nbricks, stream));
-            launch_brick_compact(brick_flag, brick_pos, bargs.M, brick_active, d_flags + 2, stream);
-            HIPCHK(hipMemcpyAsync(h_flags + 2, d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
-        }
+        // ids of the bricks that own atoms, compacted in Morton order; the count stays on the device
+        launch_brick_flags(estart, bargs.M, brick_flag, stream);
+        HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, brick_flag, brick_pos, bargs.nbricks, stream));
+        launch_brick_compact(brick_flag, brick_pos, bargs.M, brick_active, d_flags + 2, stream);
+        bargs.active = brick_active;
+        bargs.nactive = bargs.nbricks;
+        bargs.nactive_dev = d_flags + 2;
         launch_ghost_morton(cur, geom, nlocal, nghost, bin_key, bin_val, stream);
         if (nghost > 0)
             HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nghost,
@@ -805,18 +819,27 @@ int Engine::build_cells_and_table()
         TRY(halo_forward_seed(0));
         TRY(rebuild_topology());
         if (layout == 1) {
-            HIPCHK(hipStreamSynchronize(stream));
-            bargs.active = brick_active;
-            bargs.nactive = h_flags[2];
+            bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
             tbegin("neigh");
+            launch_brick_plan(bargs, d_flags, stream);
             launch_brick_build(bargs, coord4, rc2, n_col, pair_count, table16, d_flags, stream);
             tend("neigh");
             table32_valid = false;
         } else {
             tbegin("neigh");
-            launch_bin_ranges(estart, gstart, bargs.M, nlocal, binrange, stream);
             ExclArgs ex = {nullptr, nullptr, nullptr, 0};
             if (have_bonds && msp > 0) { ex.tagc = tagc; ex.nspecial = cur.nspecial; ex.special = cur.special; ex.msp = msp; }
+            if (neigh_kernel == 1 && n_col <= tile_build_rowcap()) {
+                // wave-per-bin ballot builder on LDS-staged neighbourhoods (every brick: empty ones exit at once)
+                bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
+                launch_brick_plan(bargs, d_flags, stream);
+                launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, stream);
+                tend("neigh");
+                table32_valid = true;
+                nbuild++;
+                return 0;
+            }
+            launch_bin_ranges(estart, gstart, bargs.M, nlocal, binrange, stream);
             launch_cell_build(coord4, rkey, reorder_sub_bits(geom), binrange, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count, pair_table,
                               d_flags, have_bonds ? &ex : nullptr, stream);
             tend("neigh");
@@ -853,7 +876,7 @@ int Engine::build_cells_and_table()
 int Engine::ensure_table32()
 {
     if (layout != 1 || table32_valid) return 0;
-    launch_brick_convert(bargs, n_col, pair_count, table16, pair_table, d_flags, stream);
+    launch_brick_convert(bargs, n_col, pair_count, table16, pair_table, stream);
     table32_valid = true;
     return 0;
 }
@@ -969,9 +992,10 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.accumulate = 1;
     p.debug = 0;
     p.chunked = layout == 2 ? 1 : 0;
-    if (layout == 1 && !ev && pair_kernel == 1) {
+    if (layout == 1 && !ev && pair_kernel == 1 && pair_style == 1) {
+        p.nall = nlocal + nghost;
         tbegin("pair");
-        launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
+        launch_brick_pair(bargs, p, table16, stream);
         tend("pair");
         return 0;
     }
@@ -1031,9 +1055,10 @@ int Engine::run(int nsteps)
             p.beg = split ? (part == 0 ? 0 : n_bulk) : 0;
             p.end = split ? (part == 0 ? n_bulk : nlocal) : nlocal;
             if (split && part == 1) TRY(halo_wait());
-            if (layout == 1 && pair_kernel == 1) {
+            if (layout == 1 && pair_kernel == 1 && pair_style == 1) {
+                p.nall = nlocal + nghost;
                 tbegin("pair");
-                launch_brick_pair(bargs, p, table16, pair_style, d_flags, stream);
+                launch_brick_pair(bargs, p, table16, stream);
                 tend("pair");
             } else {
                 TRY(ensure_table32());

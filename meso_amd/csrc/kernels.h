@@ -135,10 +135,26 @@ struct BrickArgs {
     int ghost_base;      // == nlocal: ghosts live behind the locals in the merged arrays
     int M;               // Morton codes per section (power of 8)
     int mbin[3];
-    int nbricks;         // M / 32
-    const int *active;   // [nactive] ids (section*nbricks + brick) of bricks that own atoms
-    int nactive;
+    int nbricks;         // M / 64
+    const int *active;   // [nactive] ids of bricks that own atoms; null: identity (every brick, empty ones exit)
+    int nactive;         // launch bound: number of active bricks, or of all bricks when the count is only on the device
+    const int *nactive_dev;   // null: nactive is exact
+    // written by the plan kernel once per rebuild (pitches: brick_*_pitch())
+    int *hoff;           // [slot][217] first halo slot of each halo bin
+    uint32_t *hmap;      // [slot][nh]  halo slot -> global atom index
+    int *hdr;            // [slot]{nh, o0, n0, o1, n1}: halo size, own runs of the bulk and border sections
+    uint32_t *own_info;  // [nlocal]    own atom -> halo slot | halo bin << 16
 };
+int brick_codes();
+size_t brick_hmap_pitch();
+size_t brick_hoff_pitch();
+size_t brick_hdr_pitch();
+void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s);
+struct ExclArgs;
+// cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows
+void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
+                       const ExclArgs *excl, hipStream_t s);
+int tile_build_rowcap();
 void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s);
 void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s);
 void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s);
@@ -148,9 +164,9 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
 void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,
                         unsigned short *table16, int *overflow, hipStream_t s);
 void launch_brick_convert(const BrickArgs &g, int n_col, const int *count, const unsigned short *table16,
-                          int *table32, int *overflow, hipStream_t s);
-void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, int fast,
-                       int *overflow, hipStream_t s);
+                          int *table32, hipStream_t s);
+// dpd/fast/meso only (the fp64 style runs on the converted global-index rows)
+void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, hipStream_t s);
 
 // ---- bonded topology (bond.hip) -----------------------------------------------------------------------
 void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, int *tagc, hipStream_t s);

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a
             const float rsq = dx * dx + dy * dy + dz * dz;
             const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
             const bool hit = active && rsq < cutsq && rsq >= (float)MESO_EPSILON_SQ;    // tail slots hold i itself: rsq = 0
-            const u64 m = __ballot(hit);
+            const u64 m = __builtin_amdgcn_ballot_w64(hit);
             if (hit) ring[(qtail + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))) & (RG_RING - 1)] =
                     make_float4(__uint_as_float((u32)j[q] | lanehi), c2[q].x, c2[q].y, c2[q].z);
             qtail += __popcll(m);
