@@ -230,16 +230,16 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const 
 //   rows leave LDS as whole 32-byte chunks of the chunked-8 table (8 lanes per atom), slots translated to global
 //     indices on the way out, tail slots padded with the atom itself.
 // Entry order inside a row is (batch, lane): deterministic, and different from the lane-per-atom builders.
-#define TB_G 8
+#define TB_G 4
 #define TB_ROWCAP 192
 
 template <bool EXCL>
-__global__ void __launch_bounds__(BRK_THREADS, 2) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
+__global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
                                                               int n_col, int *__restrict__ count, int *__restrict__ table,
-                                                              int *__restrict__ overflow, ExclArgs ex)
+                                                              int *__restrict__ overflow, ExclArgs ex, int dbg)
 {
 #pragma clang fp contract(fast)
-    __shared__ float4 hc[BRK_MAXH];
+    __shared__ float hx[BRK_MAXH], hy[BRK_MAXH], hz[BRK_MAXH];   // SoA: candidate reads are consecutive slots
     __shared__ u32 hgi[BRK_MAXH];
     __shared__ int hoff[BRK_NHB + 1];
     __shared__ int hloc[BRK_NHB];
@@ -255,11 +255,12 @@ __global__ void __launch_bounds__(BRK_THREADS, 2) k_tile_build(BrickArgs g, cons
     for (int h = tid; h < nh; h += BRK_THREADS) {
         const u32 src = g.hmap[(size_t)slot * BRK_MAXH + h];
         hgi[h] = src;
-        hc[h] = coord4[src];
+        const float4 c = coord4[src];
+        hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
     }
     __syncthreads();
-    int4 *rows = (int4 *)table;
     unsigned short (*myrow)[TB_ROWCAP] = rowbuf[w];
+    if (dbg == 1) return;        // timing ablation: staging only
 
     for (int k = w; k < BRK_CODES; k += BRK_WAVES) {
         const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
@@ -280,9 +281,31 @@ __global__ void __launch_bounds__(BRK_THREADS, 2) k_tile_build(BrickArgs g, cons
         const int ncand = pre[9];
         const int nbatch = (ncand + 63) >> 6;
 
+        // candidates of the first 4 batches (256 atoms: the usual stencil holds ~237) stay in registers for all groups
+        // of this bin; later batches (denser systems) are reloaded per group
+        auto load_cand = [&](int b, int &cs, float &cx, float &cy, float &cz, int &ctag) {
+            const int id = (b << 6) + lane;
+            int base = rstart[0];
+#pragma unroll
+            for (int r = 1; r < 9; r++) base = id >= pre[r] ? rstart[r] - pre[r] : base;
+            const bool valid = id < ncand;
+            cs = valid ? id + base : 0;
+            cx = valid ? hx[cs] : 1.0e18f;       // never inside the cutoff
+            cy = hy[cs]; cz = hz[cs];
+            ctag = 0;
+            if (EXCL) ctag = ex.tagc[hgi[cs]];
+        };
+        int cs4[4], ct4[4];
+        float cx4[4], cy4[4], cz4[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            cs4[b] = 0; ct4[b] = 0; cx4[b] = 1.0e18f; cy4[b] = cz4[b] = 0.f;
+            if (b < nbatch) load_cand(b, cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+        }
+
         for (int g0 = 0; g0 < na; g0 += TB_G) {
             const int ng = min(TB_G, na - g0);
-            // own atoms of this group: global index and coordinates through the scalar unit
+            // own atoms of this group: global index and coordinates, wave-uniform (SGPRs)
             int gi[TB_G];
             float ox[TB_G], oy[TB_G], oz[TB_G];
 #pragma unroll
@@ -290,31 +313,21 @@ __global__ void __launch_bounds__(BRK_THREADS, 2) k_tile_build(BrickArgs g, cons
                 gi[t] = 0; ox[t] = oy[t] = oz[t] = 0.f;
                 if (t < ng) {
                     gi[t] = __builtin_amdgcn_readfirstlane((int)hgi[own0 + g0 + t]);
-                    const float4 c = hc[own0 + g0 + t];           // one LDS word for the whole wave, then SGPRs
-                    ox[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.x)));
-                    oy[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.y)));
-                    oz[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.z)));
+                    // one LDS word for the whole wave, then SGPRs
+                    ox[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hx[own0 + g0 + t])));
+                    oy[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hy[own0 + g0 + t])));
+                    oz[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hz[own0 + g0 + t])));
                 }
             }
             int nrow[TB_G];
 #pragma unroll
             for (int t = 0; t < TB_G; t++) nrow[t] = 0;
 
-            for (int b = 0; b < nbatch; b++) {
-                const int id = (b << 6) + lane;
-                int base = rstart[0];
-#pragma unroll
-                for (int r = 1; r < 9; r++) base = id >= pre[r] ? rstart[r] - pre[r] : base;
-                const bool valid = id < ncand;
-                const int cs = valid ? id + base : 0;
-                float4 c = hc[cs];
-                c.x = valid ? c.x : 1.0e18f;          // never inside the cutoff
-                int ctag = 0;
-                if (EXCL) ctag = ex.tagc[hgi[cs]];
+            auto scan = [&](const int cs, const float cx, const float cy, const float cz, const int ctag) {
 #pragma unroll
                 for (int t = 0; t < TB_G; t++) {
                     if (t < ng) {
-                        const float dx = ox[t] - c.x, dy = oy[t] - c.y, dz = oz[t] - c.z;
+                        const float dx = ox[t] - cx, dy = oy[t] - cy, dz = oz[t] - cz;
                         const float d = dx * dx + dy * dy + dz * dz;
                         bool hit = (d <= rc2) & (cs != own0 + g0 + t);
                         if (EXCL) {
@@ -322,38 +335,41 @@ __global__ void __launch_bounds__(BRK_THREADS, 2) k_tile_build(BrickArgs g, cons
                             const int nsp = ex.nspecial[gi[t]];
                             for (int sp = 0; sp < nsp; sp++) hit = hit & (ex.special[(size_t)gi[t] * ex.msp + sp] != ctag);
                         }
+                        // no "any hit?" branch: a batch of 64 candidates almost always holds one, and straight-line code lets
+                        // the chains of the group's atoms overlap
                         const u64 m = __builtin_amdgcn_ballot_w64(hit);
-                        if (m) {
-                            const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
-                            if (hit) myrow[t][min(pos, (u32)(TB_ROWCAP - 1))] = (unsigned short)cs;
-                            nrow[t] += __popcll(m);
-                        }
+                        const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
+                        if (hit) myrow[t][min(pos, (u32)(TB_ROWCAP - 1))] = (unsigned short)cs;
+                        nrow[t] += __popcll(m);
                     }
                 }
+            };
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (b < nbatch && dbg != 3) scan(cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+            for (int b = 4; b < nbatch; b++) {
+                int cs, ctag;
+                float cx, cy, cz;
+                load_cand(b, cs, cx, cy, cz, ctag);
+                scan(cs, cx, cy, cz, ctag);
             }
-            // rows out: 8 lanes per atom, one 32-byte chunk per lane and pass
-            const int t = lane >> 3;
-            int n = nrow[0], i = gi[0];
+            // rows out, lane = entry: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become global
+            // indices, the tail of the last chunk is padded with the atom itself
 #pragma unroll
-            for (int u = 1; u < TB_G; u++) { n = t == u ? nrow[u] : n; i = t == u ? gi[u] : i; }
-            if (t < ng) {
-                if ((lane & 7) == 0) {
-                    if (n > n_col) atomicMax(overflow, n);
-                    count[i] = min(n, n_col);
-                }
-                const int nn = min(n, min(n_col, TB_ROWCAP));
-                for (int c = lane & 7; c * 8 < nn; c += 8) {
-                    const uint4 pk = *(const uint4 *)&myrow[t][c * 8];
-                    const u32 wv[4] = {pk.x, pk.y, pk.z, pk.w};
-                    int e[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const u32 sl = (q & 1) ? (wv[q >> 1] >> 16) : (wv[q >> 1] & 0xFFFFu);
-                        e[q] = c * 8 + q < nn ? (int)hgi[sl < (u32)BRK_MAXH ? sl : 0] : i;
+            for (int t = 0; t < TB_G; t++) {
+                if (t < ng) {
+                    const int n = nrow[t], i = gi[t];
+                    if (lane == 0) {
+                        if (n > n_col) atomicMax(overflow, n);
+                        count[i] = min(n, n_col);
                     }
-                    int4 *wr = rows + 2 * row_word8(i, c, n_col);
-                    wr[0] = make_int4(e[0], e[1], e[2], e[3]);
-                    wr[1] = make_int4(e[4], e[5], e[6], e[7]);
+                    const int nn = dbg == 2 ? 0 : min(n, min(n_col, TB_ROWCAP));
+                    int *dst = table + row_word8(i, 0, n_col) * 8;
+                    for (int e = lane; e < ((nn + 7) & ~7); e += 64) {
+                        int val = i;
+                        if (e < nn) val = (int)hgi[myrow[t][e]];
+                        dst[(size_t)(e >> 3) * 512 + (e & 7)] = val;
+                    }
                 }
             }
         }
@@ -527,7 +543,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 2) k_brick_pair(BrickArgs g, Pair
                     const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
                     const bool hit = active & (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ);    // tail slots hold the atom itself
                     const u64 m = __builtin_amdgcn_ballot_w64(hit);
-                    if (hit) myring[(qtail + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))) & (BRK_RING - 1)] = joff[q] | lanehi;
+                    if (hit) myring[__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (BRK_RING - 1)] = joff[q] | lanehi;
                     qtail += __popcll(m);
                     if (q & 1) {
                         while (qtail - qhead >= 64) { compute(); issue(64); }
@@ -644,17 +660,17 @@ void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s)
 }
 
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
-                       const ExclArgs *excl, hipStream_t s)
+                       const ExclArgs *excl, int dbg, hipStream_t s)
 {
     if (g.nactive <= 0) return;
     ExclArgs ex = {nullptr, nullptr, nullptr, 0};
     if (excl && excl->tagc) {
         ex = *excl;
         hipLaunchKernelGGL((k_tile_build<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table,
-                           overflow, ex);
+                           overflow, ex, dbg);
     } else {
         hipLaunchKernelGGL((k_tile_build<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table,
-                           overflow, ex);
+                           overflow, ex, dbg);
     }
 }
 int tile_build_rowcap() { return TB_ROWCAP; }

@@ -833,7 +833,8 @@ int Engine::build_cells_and_table()
                 // wave-per-bin ballot builder on LDS-staged neighbourhoods (every brick: empty ones exit at once)
                 bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
                 launch_brick_plan(bargs, d_flags, stream);
-                launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, stream);
+                launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr,
+                                  pair_debug >= 10 ? pair_debug - 10 : 0, stream);
                 tend("neigh");
                 table32_valid = true;
                 nbuild++;
@@ -963,6 +964,8 @@ int Engine::force_clear(int r)
 void Engine::launch_pair(PairArgs &p, int ev)
 {
     p.nall = nlocal + nghost;
+    p.all_expw_one = 1;
+    for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
     const bool cell = layout == 2;
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
     else if ((pair_kernel == 5 || pair_kernel == 2) && cell && pair_style == 1) launch_pair_dpd_ring(p, stream);

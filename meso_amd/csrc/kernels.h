@@ -110,6 +110,7 @@ struct PairArgs {
     int chunked;          // 1: chunked-8 rows (cell-ordered builder), 0: transposed 64-atom tiles
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
     int nall;             // atoms in coord4/veloc4 (locals + ghosts): bound of the buffer-addressed gathers
+    int all_expw_one;     // every pair type has weight exponent 1 (no pow() in the kernel)
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // lane-per-atom with 8-deep memory-level parallelism (forces only)
@@ -153,7 +154,7 @@ void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s);
 struct ExclArgs;
 // cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
-                       const ExclArgs *excl, hipStream_t s);
+                       const ExclArgs *excl, int dbg, hipStream_t s);
 int tile_build_rowcap();
 void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s);
 void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s);

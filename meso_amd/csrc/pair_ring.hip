@@ -39,8 +39,9 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
 
-template <bool NT1, int OCC>
-__global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a)
+// EW1: every pair type has weight exponent s = 1 (the usual DPD choice): w_R = w_C, no pow()
+template <bool NT1, bool EW1>
+__global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
     extern __shared__ double smem[];
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a
     char *wb = (char *)smem + off + (size_t)w * per_wave;
     float4 *own_c = (float4 *)wb;
     float4 *own_v = own_c + 64;
-    float4 *ring = own_v + 64;          // (record word, partner x, y, z): the coordinate is not gathered twice
+    float4 *ring = own_v + 64;          // (partner x, y, z, record word): the coordinate is not gathered twice
     u64 *facc = (u64 *)(ring + RG_RING);
 
     const int nbk = gridDim.x;
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a
                 const float dot = dx * dvx + dy * dvy + dz * dvz;
                 const float wc = 1.0f - r * c_cutinv;
                 float wr = wc;
-                if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
+                if (!EW1 && c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
                 float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
                 fpair *= rinv;
                 __hip_atomic_fetch_add(&facc[owner], to_fixed(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -121,8 +122,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a
     auto issue = [&](int nb) {
         if (lane < nb) {
             const float4 rec = ring[(qhead + lane) & (RG_RING - 1)];
-            pe = __float_as_uint(rec.x);
-            pc2 = make_float4(rec.y, rec.z, rec.w, 0.f);
+            pe = __float_as_uint(rec.w);
+            pc2 = make_float4(rec.x, rec.y, rec.z, 0.f);
             const u32 joff = (pe & RG_INDEX_MASK) << 4;
             if (!NT1) pc2.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, (int)joff + 12, 0, 0));   // partner type
             pv2 = buf_load4(rv, joff);
@@ -137,6 +138,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a
 #pragma unroll 1
     for (int c = 0; c < nchmax; c++) {
         const bool active = c < nch;
+        const u64 actm = __builtin_amdgcn_ballot_w64(active);
         const int j[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         if (c + 1 < nch) { w0 = rows[(size_t)(c + 1) * 128]; w1 = rows[(size_t)(c + 1) * 128 + 1]; }
         float4 c2[8];
@@ -147,10 +149,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, OCC) k_pair_dpd_ring(PairArgs a
             const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
             const float rsq = dx * dx + dy * dy + dz * dz;
             const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
-            const bool hit = active && rsq < cutsq && rsq >= (float)MESO_EPSILON_SQ;    // tail slots hold i itself: rsq = 0
-            const u64 m = __builtin_amdgcn_ballot_w64(hit);
-            if (hit) ring[(qtail + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))) & (RG_RING - 1)] =
-                    make_float4(__uint_as_float((u32)j[q] | lanehi), c2[q].x, c2[q].y, c2[q].z);
+            // lane masks straight from the compares (LLVM predicates: 4 = OLT, 3 = OGE); tail slots hold i itself: rsq = 0
+            const u64 m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) & actm;
+            const bool hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & active;
+            if (hit) ring[__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1)] =
+                    make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float((u32)j[q] | lanehi));   // record word last: the loaded xyz tuple is stored as is
             qtail += __popcll(m);
             if (q & 1) {
                 while (qtail - qhead >= 64) { compute(); issue(64); }
@@ -179,8 +182,13 @@ void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s)
     // p.debug 3/4: occupancy ablation - pad the LDS request so that only 3 / 4 workgroups fit a CU (default: 5)
     if (p.debug == 3) sm = 53 * 1024;
     if (p.debug == 4) sm = 40 * 1024;
-    if (!nt1) hipLaunchKernelGGL((k_pair_dpd_ring<false, 5>), grid, block, sm, s, p);
-    else hipLaunchKernelGGL((k_pair_dpd_ring<true, 5>), grid, block, sm, s, p);
+    bool ew1 = true;
+    if (nt1) ew1 = p.cf1[P_EXPW] == 1.0;
+    else ew1 = p.all_expw_one != 0;
+    if (nt1 && ew1) hipLaunchKernelGGL((k_pair_dpd_ring<true, true>), grid, block, sm, s, p);
+    else if (nt1) hipLaunchKernelGGL((k_pair_dpd_ring<true, false>), grid, block, sm, s, p);
+    else if (ew1) hipLaunchKernelGGL((k_pair_dpd_ring<false, true>), grid, block, sm, s, p);
+    else hipLaunchKernelGGL((k_pair_dpd_ring<false, false>), grid, block, sm, s, p);
 }
 
 } // namespace meso
