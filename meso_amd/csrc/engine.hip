@@ -815,8 +815,10 @@ int Engine::build_cells_and_table()
         launch_invert_perm(bin_val, gslot, nghost, stream);
         bargs.ghost_base = nlocal;
         tend("bin");
-        TRY(merge_locals(0));
-        TRY(halo_forward_seed(0));
+        // merged arrays with the signatures of the CURRENT step: the force kernel of this step uses them as they are
+        const u32 sd_now = premix_tea<64>((u32)seed, (u32)ntimestep);
+        TRY(merge_locals(sd_now));
+        TRY(halo_forward_seed(sd_now));
         TRY(rebuild_topology());
         if (layout == 1) {
             bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
@@ -1036,11 +1038,12 @@ int Engine::run(int nsteps)
         if (!initial_done) TRY(nve_initial());
         int rebuild = 0;
         TRY(decide(&rebuild));
-        if (rebuild) { TRY(reneighbor()); merged = false; }
+        bool ghosts_fresh = false;
+        if (rebuild) { TRY(reneighbor()); merged = layout >= 1; ghosts_fresh = merged; }   // the rebuild merged with this step's seed
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
         const bool split = nranks > 1 && overlap && n_bulk > 0 && n_bulk < nlocal;
-        TRY(halo_forward_seed(sd, split));
+        if (!ghosts_fresh) TRY(halo_forward_seed(sd, split));
         PairArgs p;
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
         for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
@@ -1057,7 +1060,7 @@ int Engine::run(int nsteps)
         for (int part = 0; part < (split ? 2 : 1); part++) {
             p.beg = split ? (part == 0 ? 0 : n_bulk) : 0;
             p.end = split ? (part == 0 ? n_bulk : nlocal) : nlocal;
-            if (split && part == 1) TRY(halo_wait());
+            if (split && part == 1 && !ghosts_fresh) TRY(halo_wait());
             if (layout == 1 && pair_kernel == 1 && pair_style == 1) {
                 p.nall = nlocal + nghost;
                 tbegin("pair");
