@@ -60,6 +60,7 @@ public:
     int force_clear(int range);
     int pair_compute(int range, int eflag, int vflag);
     void launch_pair(PairArgs &p, int ev);
+    bool ring_selected() const;
 
     // computes
     int compute_temp(double *t);
@@ -158,6 +159,7 @@ private:
     int pair_kernel = 2;            // 0 lane-per-atom, 1 tile/brick, 2 auto (fp32 on cell rows: ring, fp64: MLP + compaction),
                                     // 3 MLP + ballot compaction, 4 MLP only
     int pair_debug = 0;             // timing ablations (bench only)
+    int fuse_pair = 1;              // step boundary in the epilogue of the fp32 ring kernel (no separate NVE pass, forces not stored)
     int fuse_step = 1;              // final(s)+initial(s+1)(+merge) in one kernel between steps of one run()
     int fuse_clear = 1;             // pair kernel writes f instead of clear + accumulate
     long natoms_total = 0;
@@ -166,6 +168,7 @@ private:
     int nmax = 0;
     AtomSoA cur{}, alt{};
     float4 *coord4 = nullptr, *veloc4 = nullptr;
+    float4 *coord4_next = nullptr, *veloc4_next = nullptr;   // written by the force kernel's step-boundary epilogue, then swapped in
     double *virial[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double *e_pair = nullptr;
     double *xhold = nullptr;

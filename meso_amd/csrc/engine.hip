@@ -69,7 +69,7 @@ void Engine::free_all()
 {
     if (stream) (void)hipStreamSynchronize(stream);
     free_soa(cur); free_soa(alt);
-    dfree(coord4); dfree(veloc4);
+    dfree(coord4); dfree(veloc4); dfree(coord4_next); dfree(veloc4_next);
     for (int k = 0; k < 6; k++) dfree(virial[k]);
     dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32);
@@ -239,6 +239,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "fuse_step") { fuse_step = (int)val; return 0; }
     if (key == "overlap") { overlap = (int)val; return 0; }
     if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
+    if (key == "fuse_pair") { fuse_pair = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
@@ -302,6 +303,7 @@ int Engine::alloc_atoms(int cap)
         HIPCHK(regrow(e_bond, 0, c, stream));
     }
     HIPCHK(regrow(coord4, 0, c, stream)); HIPCHK(regrow(veloc4, 0, c, stream));
+    HIPCHK(regrow(coord4_next, 0, c, stream)); HIPCHK(regrow(veloc4_next, 0, c, stream));
     for (int k = 0; k < 6; k++) HIPCHK(regrow(virial[k], 0, c, stream));
     HIPCHK(regrow(e_pair, 0, c, stream));
     HIPCHK(regrow(xhold, 0, 3 * c, stream));
@@ -963,8 +965,12 @@ int Engine::force_clear(int r)
 // local range are refreshed for LOCAL and BULK calls, the ghost range for LOCAL and BORDER calls, exactly the
 // split the reference uses to hide its host round trip.
 // kernel choice (option pair_kernel): 0 lane per atom, 1 tile, 2 auto, 3 mlpc, 4 mlp, 5 ring
+bool Engine::ring_selected() const { return (pair_kernel == 5 || pair_kernel == 2) && layout == 2 && pair_style == 1; }
+
 void Engine::launch_pair(PairArgs &p, int ev)
 {
+    const bool cell_ring = !ev && ring_selected();
+    if (!cell_ring) p.fuse_nve = 0;              // only the ring kernel has the epilogue
     p.nall = nlocal + nghost;
     p.all_expw_one = 1;
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
@@ -995,6 +1001,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
     p.beg = beg; p.end = end;
     p.accumulate = 1;
+    p.fuse_nve = 0;
     p.debug = 0;
     p.chunked = layout == 2 ? 1 : 0;
     if (layout == 1 && !ev && pair_kernel == 1 && pair_style == 1) {
@@ -1056,6 +1063,16 @@ int Engine::run(int nsteps)
         p.debug = pair_debug;
         p.chunked = layout == 2 ? 1 : 0;
         if (!fuse_clear) TRY(force_clear(0));
+        // step boundary in the force kernel's epilogue: final(s) + initial(s+1) + merge(s+1) of the atoms a launch owns;
+        // the merged arrays of step s+1 go to the second buffer (this step's are still being gathered from)
+        const int a1 = ago + 1;
+        const bool next_rebuild = dist_check || (a1 >= delay && a1 % every == 0);
+        const bool boundary_in_pair = fuse_pair && fuse_step && it + 1 < nsteps && !have_bonds && ring_selected();
+        p.fuse_nve = boundary_in_pair ? 1 : 0;
+        if (boundary_in_pair)
+            p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
+                                  0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
+                                  premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
         // bulk atoms have no ghost partners: their forces are computed while the ghosts are in flight
         for (int part = 0; part < (split ? 2 : 1); part++) {
             p.beg = split ? (part == 0 ? 0 : n_bulk) : 0;
@@ -1074,10 +1091,12 @@ int Engine::run(int nsteps)
             }
         }
         TRY(bond_compute(0));
-        if (fuse_step && it + 1 < nsteps) {
+        if (boundary_in_pair) {
+            if (!next_rebuild) { std::swap(coord4, coord4_next); std::swap(veloc4, veloc4_next); }
+            initial_done = true;
+            merged = !next_rebuild;
+        } else if (fuse_step && it + 1 < nsteps) {
             // one pass for final(s) + initial(s+1); the merge for s+1 rides along when s+1 provably keeps the table
-            const int a1 = ago + 1;
-            const bool next_rebuild = dist_check || (a1 >= delay && a1 % every == 0);
             tbegin("nve");
             launch_nve_boundary(cur, 0.5 * dt, dt, groupbit, nlocal, next_rebuild ? 0 : 1, coord4, veloc4,
                                 0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),

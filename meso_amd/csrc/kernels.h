@@ -93,6 +93,20 @@ void launch_neigh_build_wave(const float4 *coord4, const uint32_t *bin_of_atom, 
                              int *count, int *table, int *overflow, hipStream_t s);
 
 // ---- pair force (pair_dpd_meso.cu:91-205, pair_dpd_fast_meso.cu:91-205) -------------------------------
+struct NveArgs {
+    double *x[3], *v[3];
+    const double *mass;
+    const int *mask, *tag, *type;
+    double dtf, dtv;
+    int groupbit;
+    int merge;
+    float4 *coord4_next, *veloc4_next;
+    double cx, cy, cz;
+    uint32_t seed_next;
+};
+NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,
+                      float4 *veloc4_next, double cx, double cy, double cz, uint32_t seed_next);
+
 struct PairArgs {
     const float4 *coord4, *veloc4;
     const int *count, *table;
@@ -111,6 +125,9 @@ struct PairArgs {
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
     int nall;             // atoms in coord4/veloc4 (locals + ghosts): bound of the buffer-addressed gathers
     int all_expw_one;     // every pair type has weight exponent 1 (no pow() in the kernel)
+    // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
+    int fuse_nve;
+    NveArgs nve;
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // lane-per-atom with 8-deep memory-level parallelism (forces only)

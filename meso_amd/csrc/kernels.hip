@@ -97,46 +97,31 @@ void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStre
 // and (when step s+1 keeps the neighbour table) gpu_merge_xvt for step s+1.  Same operations in the same order as
 // the three separate kernels, so results are bit-identical; it saves two launches and re-reading v, f, x
 // (56 -> ~30 us per step on the 64^3 box).
-template <bool MERGE>
-__global__ void __launch_bounds__(256) k_nve_boundary(AtomSoA a, double dtf, double dtv, int groupbit, int n,
-                                                      float4 *__restrict__ coord4, float4 *__restrict__ veloc4, double cx,
-                                                      double cy, double cz, u32 seed_next)
+__global__ void __launch_bounds__(256) k_nve_boundary(NveArgs a, const double *__restrict__ fx, const double *__restrict__ fy,
+                                                      const double *__restrict__ fz, int n)
 {
-    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        double x = a.x[0][i], y = a.x[1][i], z = a.x[2][i];
-        double vx = a.v[0][i], vy = a.v[1][i], vz = a.v[2][i];
-        if (a.mask[i] & groupbit) {
-            const double dtfm = dtf * rcp_poly(a.mass[i]);
-            const double fx = a.f[0][i], fy = a.f[1][i], fz = a.f[2][i];
-            vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // final_integrate, step s
-            vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // initial_integrate, step s+1
-            x += dtv * vx; y += dtv * vy; z += dtv * vz;
-            a.v[0][i] = vx; a.v[1][i] = vy; a.v[2][i] = vz;
-            a.x[0][i] = x; a.x[1][i] = y; a.x[2][i] = z;
-        }
-        if (MERGE) {
-            float4 c;
-            c.x = (float)(x - cx); c.y = (float)(y - cy); c.z = (float)(z - cz);
-            c.w = __uint_as_float((u32)(a.type[i] - 1));
-            coord4[i] = c;
-            float4 v;
-            v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;
-            v.w = __uint_as_float(signature(seed_next, a.tag[i], v.x, v.y, v.z));
-            veloc4[i] = v;
-        }
-    }
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        nve_boundary_atom(a, i, fx[i], fy[i], fz[i]);
 }
 
 void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, int merge, float4 *coord4,
                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s)
 {
     if (n <= 0) return;
-    if (merge)
-        hipLaunchKernelGGL(k_nve_boundary<true>, dim3(capgrid(n, 256)), dim3(256), 0, s, a, dtf, dtv, groupbit, n, coord4,
-                           veloc4, cx, cy, cz, seed_next);
-    else
-        hipLaunchKernelGGL(k_nve_boundary<false>, dim3(capgrid(n, 256)), dim3(256), 0, s, a, dtf, dtv, groupbit, n, coord4,
-                           veloc4, cx, cy, cz, seed_next);
+    NveArgs nv = make_nve_args(a, dtf, dtv, groupbit, merge, coord4, veloc4, cx, cy, cz, seed_next);
+    hipLaunchKernelGGL(k_nve_boundary, dim3(capgrid(n, 256)), dim3(256), 0, s, nv, a.f[0], a.f[1], a.f[2], n);
+}
+
+NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,
+                      float4 *veloc4_next, double cx, double cy, double cz, uint32_t seed_next)
+{
+    NveArgs nv;
+    for (int d = 0; d < 3; d++) { nv.x[d] = a.x[d]; nv.v[d] = a.v[d]; }
+    nv.mass = a.mass; nv.mask = a.mask; nv.tag = a.tag; nv.type = a.type;
+    nv.dtf = dtf; nv.dtv = dtv; nv.groupbit = groupbit; nv.merge = merge;
+    nv.coord4_next = coord4_next; nv.veloc4_next = veloc4_next;
+    nv.cx = cx; nv.cy = cy; nv.cz = cz; nv.seed_next = seed_next;
+    return nv;
 }
 
 // ---- deterministic two-stage block reductions (replace gpu_reduce_sum_host, math_meso.h:677-692)

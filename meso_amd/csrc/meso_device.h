@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "kernels.h"
 
 namespace meso {
 
@@ -203,6 +204,33 @@ __device__ inline float gaussian_tea_fast(u32 u, u32 v)
     float lg = __builtin_amdgcn_logf((float)v1 * (float)MESO_2_TO_MINUS_32);
     float r = __builtin_amdgcn_sqrtf(-2.0f * (float)MESO_LN_2 * lg);
     return fmaxf(-4.0f, fminf(r * f, 4.0f));
+}
+
+// Step boundary of one atom: final_integrate of step s, initial_integrate of step s+1 (fix_nve_meso.cu:62-95,157-178)
+// and, when step s+1 keeps the neighbour table, gpu_merge_xvt for step s+1 (atom_vec_meso.cu:142-167).  One definition
+// for the stand-alone boundary kernel and for the force kernel's epilogue, so both produce the same bits.
+__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz)
+{
+    double x = a.x[0][i], y = a.x[1][i], z = a.x[2][i];
+    double vx = a.v[0][i], vy = a.v[1][i], vz = a.v[2][i];
+    if (a.mask[i] & a.groupbit) {
+        const double dtfm = a.dtf * rcp_poly(a.mass[i]);
+        vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // final_integrate, step s
+        vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // initial_integrate, step s+1
+        x += a.dtv * vx; y += a.dtv * vy; z += a.dtv * vz;
+        a.v[0][i] = vx; a.v[1][i] = vy; a.v[2][i] = vz;
+        a.x[0][i] = x; a.x[1][i] = y; a.x[2][i] = z;
+    }
+    if (a.merge) {
+        float4 c;
+        c.x = (float)(x - a.cx); c.y = (float)(y - a.cy); c.z = (float)(z - a.cz);
+        c.w = __uint_as_float((u32)(a.type[i] - 1));
+        a.coord4_next[i] = c;
+        float4 v;
+        v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;
+        v.w = __uint_as_float(signature(a.seed_next, a.tag[i], v.x, v.y, v.z));
+        a.veloc4_next[i] = v;
+    }
 }
 
 // bins: neighbor_meso.cu:410-412 clamp at [nmin,nmax)

@@ -164,8 +164,12 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
     while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
     if (mine) {
-        const double fx = from_fixed(facc[lane]), fy = from_fixed(facc[64 + lane]), fz = from_fixed(facc[128 + lane]);
-        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
+        double fx = from_fixed(facc[lane]), fy = from_fixed(facc[64 + lane]), fz = from_fixed(facc[128 + lane]);
+        if (a.fuse_nve) {
+            // final(s) + initial(s+1) (+ merge for s+1 into the other merged buffer: this step's is still being read)
+            if (a.accumulate) { fx += a.f[0][i]; fy += a.f[1][i]; fz += a.f[2][i]; }
+            nve_boundary_atom(a.nve, i, fx, fy, fz);
+        } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }
 }

@@ -204,16 +204,19 @@ def test_kernels_agree_on_a_large_box(Meso, style, tol):
             assert np.abs(f - ref).max() <= tol * np.abs(ref).max(), path
 
 
-def test_fused_step_boundary_is_bit_identical(Meso):
-    """final(s)+initial(s+1)+merge fused into one kernel gives the same bits as the three separate kernels."""
+@pytest.mark.parametrize("style", ["dpd/meso", "dpd/fast/meso"])
+def test_fused_step_boundary_is_bit_identical(Meso, style):
+    """final(s)+initial(s+1)+merge fused into one kernel - and, for the fp32 ring kernel, into the force kernel's own
+    epilogue - gives the same bits as the three separate kernels."""
     res = []
-    for fuse in (0, 1):
-        m, _ = _engine(Meso, 7, opts=(("fuse_step", fuse),))
+    for opts in ((("fuse_step", 0),), (("fuse_step", 1), ("fuse_pair", 0)), (("fuse_step", 1), ("fuse_pair", 1))):
+        m, _ = _engine(Meso, 7, style=style, opts=opts)
         m.run(17)
         res.append(m.gather())
         m.close()
-    for a, b in zip(res[0][:3], res[1][:3]):
-        assert np.array_equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0][:3], other[:3]):
+            assert np.array_equal(a, b)
 
 
 def test_momentum_and_thermostat(Meso):
