@@ -153,10 +153,36 @@ def main():
         phases[name] = {"ms_per_call": ms / calls if calls else None, "calls": calls}
     m.set_option("profile", 0)
     t_pair = phases["pair"]["ms_per_call"] * 1e-3
-    w = 8  # forces are stored as fp64 in both styles
     n_rank = m.counts()[0]                                          # atoms this rank's pair kernel covers
-    b_pair = n_rank * (16 + 16 + 4 + 4.0 * info["avg_count"] + 3 * w)
+    # ALGORITHMIC bytes per launch: own coord4 + veloc4, count, the stored row entries, and either
+    # the fp64 force store (pair kernel alone) or - when the step boundary runs in the kernel's epilogue (fp32 ring
+    # kernel) - what that boundary must move instead: x, v in (48 B) and out (48 B), mass/mask/tag/type (20 B) and the
+    # merged float4 pair of the next step (32 B, on the steps that keep the neighbour table).  The force itself then
+    # never leaves the registers.
+    fused = (phases["nve"]["calls"] or 0) <= 2 and (phases["pair"]["calls"] or 0) > 2
+    b_in = 16 + 16 + 4 + 4.0 * info["avg_count"]
+    b_pair_only = n_rank * (b_in + 3 * 8)
+    b_fused = n_rank * (b_in + 48 + 20 + 48 + 32.0 * (a.every - 1) / max(a.every, 1))
+    b_pair = b_fused if fused else b_pair_only
     achieved = b_pair / t_pair / 1e9
+    if a.style == "dpd/fast/meso":
+        kernel = "k_pair_dpd_ring" + (" + step-boundary epilogue (nve final/initial, merge)" if fused else "")
+    else:
+        kernel = "k_pair_dpd_mlpc"
+    pair_only = None
+    if fused:
+        # the force kernel on its own (boundary back in its separate kernel), for comparison with earlier rounds
+        m.set_option("fuse_pair", 0)
+        m.timer_reset()
+        m.set_option("profile", 1)
+        m.run(max(a.every, min(a.profile_steps, 50)))
+        ms, calls = m.timer("pair")
+        m.set_option("profile", 0)
+        m.set_option("fuse_pair", 1)
+        if calls:
+            t1 = ms / calls * 1e-3
+            pair_only = {"kernel": "k_pair_dpd_ring", "us_per_launch": t1 * 1e6, "bytes_per_launch": b_pair_only,
+                         "achieved": b_pair_only / t1 / 1e9, "frac": b_pair_only / t1 / 1e9 / HBM_PEAK_GBS}
     T = m.temperature()
     # the thermostat overshoots to ~1.5 in the first ~100 steps of a cold start and has relaxed to 1 by ~300
     settled = a.warmup + a.steps + a.profile_steps >= 500
@@ -168,7 +194,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if L == 64 and a.style == "dpd/fast/meso" and a.gpus == 1:
+        if L == 64 and a.style == "dpd/fast/meso" and a.gpus == 1 and tj.get("kernel") == kernel:
             traffic = tj["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -192,7 +218,8 @@ def main():
                    "avg_neighbors": info["avg_count"], "temperature_end": T},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_pair_dpd_mlp", "bytes_per_launch": b_pair, "us_per_launch": t_pair * 1e6},
+                     "kernel": kernel, "bytes_per_launch": b_pair, "us_per_launch": t_pair * 1e6,
+                     "pair_only": pair_only},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
     }
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:

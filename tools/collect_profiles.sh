@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the judged artefacts of one round on the GPU box (run through gpurun):
+#   tools/collect_profiles.sh r01      -> gpurun_out/r01_bench64_fast.json, r01_kernel_stats_64_fast.txt, r01_pmc_64_fast.txt
+set -e
+tag=$1
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout -k 10 400 python3 bench.py > gpurun_out/${tag}_bench64_fast.json 2> gpurun_out/${tag}_bench64_fast.err
+echo "bench done"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kt -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_kt.log 2>&1
+echo "kernel trace done"
+cd $R
+python3 - <<PY
+import csv, glob
+f = glob.glob("gpurun_out/${tag}_kt/**/*kernel_stats.csv", recursive=True)[0]
+with open("gpurun_out/${tag}_kernel_stats_64_fast.txt", "w") as o:
+    o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (64^3 rho=4, dpd/fast/meso, 200+1000+200(+50) steps)\n")
+    for r in csv.DictReader(open(f)):
+        o.write("%-90s calls %6s avg_us %9.2f total_ms %9.2f pct %6s\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"][:6]))
+PY
+bash tools/pmc_run.sh ${tag}_pmc
+( echo "# rocprofv3 --pmc <counters> -- python3 bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline   (64^3 rho=4, dpd/fast/meso; one pass per counter group; mean per dispatch)"; cat gpurun_out/${tag}_pmc.summary.txt ) > gpurun_out/${tag}_pmc_64_fast.txt
+echo "pmc done"
