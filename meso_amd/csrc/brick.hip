@@ -344,9 +344,36 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                     }
                 }
             };
+            auto scan_full = [&](const int cs, const float cx, const float cy, const float cz, const int ctag) {
 #pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (b < nbatch && dbg != 3) scan(cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+                for (int t = 0; t < TB_G; t++) {
+                    {
+                        const float dx = ox[t] - cx, dy = oy[t] - cy, dz = oz[t] - cz;
+                        const float d = dx * dx + dy * dy + dz * dz;
+                        bool hit = (d <= rc2) & (cs != own0 + g0 + t);
+                        if (EXCL) {
+                            // gpu_filter_exclusion (neigh_build_meso.cu:497-544): drop special partners by tag
+                            const int nsp = ex.nspecial[gi[t]];
+                            for (int sp = 0; sp < nsp; sp++) hit = hit & (ex.special[(size_t)gi[t] * ex.msp + sp] != ctag);
+                        }
+                        // no "any hit?" branch: a batch of 64 candidates almost always holds one, and straight-line code lets
+                        // the chains of the group's atoms overlap
+                        const u64 m = __builtin_amdgcn_ballot_w64(hit);
+                        const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
+                        if (hit) myrow[t][min(pos, (u32)(TB_ROWCAP - 1))] = (unsigned short)cs;
+                        nrow[t] += __popcll(m);
+                    }
+                }
+            };
+            if (nbatch >= 4 && ng == TB_G && dbg != 3) {
+                // the common case (4 full batches, 4 own atoms) without a single branch: 16 independent chains
+#pragma unroll
+                for (int b = 0; b < 4; b++) scan_full(cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (b < nbatch && dbg != 3) scan(cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+            }
             for (int b = 4; b < nbatch; b++) {
                 int cs, ctag;
                 float cx, cy, cz;
