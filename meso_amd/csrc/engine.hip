@@ -240,6 +240,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "overlap") { overlap = (int)val; return 0; }
     if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
     if (key == "fuse_pair") { fuse_pair = (int)val; return 0; }
+    if (key == "pair_share") { pair_share = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
@@ -973,6 +974,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     if (!cell_ring) p.fuse_nve = 0;              // only the ring kernel has the epilogue
     p.nall = nlocal + nghost;
     p.all_expw_one = 1;
+    p.share = (pair_share && (p.end == nlocal || (p.end & 255) == 0)) ? 1 : 0;
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
     const bool cell = layout == 2;
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);

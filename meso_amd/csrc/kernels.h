@@ -125,6 +125,7 @@ struct PairArgs {
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
     int nall;             // atoms in coord4/veloc4 (locals + ghosts): bound of the buffer-addressed gathers
     int all_expw_one;     // every pair type has weight exponent 1 (no pow() in the kernel)
+    int share;            // ring kernel: Newton pairing inside a workgroup allowed (end == nlocal or a multiple of 256)
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;
     NveArgs nve;

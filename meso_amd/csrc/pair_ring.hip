@@ -18,6 +18,13 @@
 //     group: ds_add_f32 579, ds_add_f64 56, ds_add_u64 30, ds_add_u32 21, plain 12-byte stores 21 - the float
 //     LDS atomics serialise, the integer ones run at store speed.
 //
+// Newton pairing inside a workgroup (SHARE): the 256 atoms of a workgroup are an aligned group of the cell-ordered
+// storage order, and 64 % of the in-range pairs (56 % of the row entries) have both atoms in one such group
+// (tools/measure_sharing.py).  For those the entry with the lower index is evaluated once and added to BOTH atoms
+// (the accumulators are workgroup-shared; integer sums commute, so waves may add in any order), the mirrored entry
+// (partner index < own index, same group) is neither gathered nor tested.  The decision needs only the two indices, so
+// rows stay complete full-list rows for every other kernel.
+//
 // One wave owns its 64 atoms from start to end: no block barriers after the prologue, no global atomics; integer
 // addition is associative, so the sums do not depend on the order in which hits are drained (bit-reproducible).
 // Arithmetic of this kernel is contracted (a*b+c -> fma), like nvcc's default for the reference's fp32 kernel.
@@ -29,7 +36,8 @@ namespace meso {
 #define RG_WAVES 4
 #define RG_RING 256                 // records per wave; a drain check every 2 slots keeps the fill below 64 + 128
 #define RG_OWNER_SHIFT 26
-#define RG_INDEX_MASK 0x03FFFFFFu
+#define RG_SHARED_BIT 0x02000000u   // record: evaluate once, add to owner and partner
+#define RG_INDEX_MASK 0x01FFFFFFu
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -40,7 +48,7 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 }
 
 // EW1: every pair type has weight exponent s = 1 (the usual DPD choice): w_R = w_C, no pow()
-template <bool NT1, bool EW1>
+template <bool NT1, bool EW1, bool SHARE>
 __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
@@ -50,24 +58,27 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
     for (int p = threadIdx.x; p < ncf; p += blockDim.x) cf32[p] = a.coeff32[p];
     const size_t off = ((size_t)ncf * 4 + 15) & ~(size_t)15;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;
-    char *wb = (char *)smem + off + (size_t)w * per_wave;
+    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16;
+    u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
+    char *wb = (char *)smem + off + 3 * 64 * RG_WAVES * 8 + (size_t)w * per_wave;
     float4 *own_c = (float4 *)wb;
     float4 *own_v = own_c + 64;
     float4 *ring = own_v + 64;          // (partner x, y, z, record word): the coordinate is not gathered twice
-    u64 *facc = (u64 *)(ring + RG_RING);
 
     const int nbk = gridDim.x;
     const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
-    const int i = a.beg + blk * blockDim.x + threadIdx.x;
+    const int blockbase = a.beg + blk * (int)blockDim.x;     // SHARE: beg is a multiple of 256 (launcher)
+    const int i = blockbase + (int)threadIdx.x;
     const bool mine = i < a.end;
     float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
     int n = 0;
     if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
     own_c[lane] = c1;
     own_v[lane] = v1;
-    facc[lane] = 0; facc[64 + lane] = 0; facc[128 + lane] = 0;
-    __syncthreads();   // coefficient table (multi-type) + this wave's own_c/own_v/facc
+    constexpr int NB = 64 * RG_WAVES;
+    const int ob = w * 64 + lane;                            // my slot in the workgroup's accumulators
+    facc[ob] = 0; facc[NB + ob] = 0; facc[2 * NB + ob] = 0;
+    __syncthreads();   // coefficient table (multi-type), accumulators, this wave's own_c/own_v
 
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.coord4, 0, a.nall * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, a.nall * 16, 0x00020000);
@@ -111,9 +122,19 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
                 if (!EW1 && c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
                 float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
                 fpair *= rinv;
-                __hip_atomic_fetch_add(&facc[owner], to_fixed(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&facc[64 + owner], to_fixed(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&facc[128 + owner], to_fixed(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const u64 qx = to_fixed(dx * fpair), qy = to_fixed(dy * fpair), qz = to_fixed(dz * fpair);
+                const u32 oo = (u32)(w * 64) + owner;
+                __hip_atomic_fetch_add(&facc[oo], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&facc[NB + oo], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&facc[2 * NB + oo], qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (SHARE && (pe & RG_SHARED_BIT)) {
+                    // the partner is one of this workgroup's atoms: it receives the opposite force now and skips its own
+                    // (mirrored) row entry
+                    const u32 pj = (pe & RG_INDEX_MASK) - (u32)blockbase;
+                    __hip_atomic_fetch_add(&facc[pj], 0ull - qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&facc[NB + pj], 0ull - qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&facc[2 * NB + pj], 0ull - qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
             pn = 0;
         }
@@ -142,18 +163,36 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
         const int j[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         if (c + 1 < nch) { w0 = rows[(size_t)(c + 1) * 128]; w1 = rows[(size_t)(c + 1) * 128 + 1]; }
         float4 c2[8];
+        bool use[8], shb[8];
+        u64 usem[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) c2[q] = buf_load4(rc, active ? ((u32)j[q] << 4) : 0xFFFFFFF0u);   // out of range: returns 0, no fetch
+        for (int q = 0; q < 8; q++) {
+            use[q] = active;
+            shb[q] = false;
+            usem[q] = actm;
+            if (SHARE) {
+                // (lane masks from the same compares through the icmp builtins: 36 = ULT)
+                usem[q] = actm & ~(__builtin_amdgcn_uicmp((u32)j[q] ^ (u32)i, 256u, 36) & __builtin_amdgcn_uicmp((u32)j[q], (u32)i, 36));
+                // same aligned 256-group: lower partner index = mirrored entry, not looked at; higher (and one of this
+                // launch's atoms) = evaluated once for both
+                const bool same = ((u32)j[q] ^ (u32)i) < 256u;
+                use[q] = active & !(same & ((u32)j[q] < (u32)i));
+                shb[q] = same & ((u32)j[q] > (u32)i) & ((u32)j[q] < (u32)a.end);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) c2[q] = buf_load4(rc, use[q] ? ((u32)j[q] << 4) : 0xFFFFFFF0u);   // out of range: returns 0, no fetch
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
             const float rsq = dx * dx + dy * dy + dz * dz;
             const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
             // lane masks straight from the compares (LLVM predicates: 4 = OLT, 3 = OGE); tail slots hold i itself: rsq = 0
-            const u64 m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) & actm;
-            const bool hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & active;
+            const u64 m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) &
+                          usem[q];
+            const bool hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & use[q];
             if (hit) ring[__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1)] =
-                    make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float((u32)j[q] | lanehi));   // record word last: the loaded xyz tuple is stored as is
+                    make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float((u32)j[q] | ((SHARE && shb[q]) ? lanehi | RG_SHARED_BIT : lanehi)));   // record word last
             qtail += __popcll(m);
             if (q & 1) {
                 while (qtail - qhead >= 64) { compute(); issue(64); }
@@ -163,8 +202,9 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
     compute();
     while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
+    if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
     if (mine) {
-        double fx = from_fixed(facc[lane]), fy = from_fixed(facc[64 + lane]), fz = from_fixed(facc[128 + lane]);
+        double fx = from_fixed(facc[ob]), fy = from_fixed(facc[NB + ob]), fz = from_fixed(facc[2 * NB + ob]);
         if (a.fuse_nve) {
             // final(s) + initial(s+1) (+ merge for s+1 into the other merged buffer: this step's is still being read)
             if (a.accumulate) { fx += a.f[0][i]; fy += a.f[1][i]; fz += a.f[2][i]; }
@@ -180,7 +220,7 @@ void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s)
     if (n <= 0) return;
     const bool nt1 = p.ntypes == 1;
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * 4;
-    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;
+    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
     dim3 grid(((n + 64 * RG_WAVES - 1) / (64 * RG_WAVES) + 7) / 8 * 8), block(64 * RG_WAVES);
     // p.debug 3/4: occupancy ablation - pad the LDS request so that only 3 / 4 workgroups fit a CU (default: 5)
@@ -189,10 +229,21 @@ void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s)
     bool ew1 = true;
     if (nt1) ew1 = p.cf1[P_EXPW] == 1.0;
     else ew1 = p.all_expw_one != 0;
-    if (nt1 && ew1) hipLaunchKernelGGL((k_pair_dpd_ring<true, true>), grid, block, sm, s, p);
-    else if (nt1) hipLaunchKernelGGL((k_pair_dpd_ring<true, false>), grid, block, sm, s, p);
-    else if (ew1) hipLaunchKernelGGL((k_pair_dpd_ring<false, true>), grid, block, sm, s, p);
-    else hipLaunchKernelGGL((k_pair_dpd_ring<false, false>), grid, block, sm, s, p);
+    // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom
+    const bool share = p.share != 0 && (p.beg & 255) == 0;
+#define RG_LAUNCH(A, B, C) hipLaunchKernelGGL((k_pair_dpd_ring<A, B, C>), grid, block, sm, s, p)
+    if (share) {
+        if (nt1 && ew1) RG_LAUNCH(true, true, true);
+        else if (nt1) RG_LAUNCH(true, false, true);
+        else if (ew1) RG_LAUNCH(false, true, true);
+        else RG_LAUNCH(false, false, true);
+    } else {
+        if (nt1 && ew1) RG_LAUNCH(true, true, false);
+        else if (nt1) RG_LAUNCH(true, false, false);
+        else if (ew1) RG_LAUNCH(false, true, false);
+        else RG_LAUNCH(false, false, false);
+    }
+#undef RG_LAUNCH
 }
 
 } // namespace meso
