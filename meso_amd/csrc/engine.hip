@@ -1051,7 +1051,10 @@ int Engine::run(int nsteps)
         if (rebuild) { TRY(reneighbor()); merged = layout >= 1; ghosts_fresh = merged; }   // the rebuild merged with this step's seed
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
-        const bool split = nranks > 1 && overlap && n_bulk > 0 && n_bulk < nlocal;
+        // bulk/border split point, rounded down to the force kernel's 256-atom groups (Newton pairing needs whole groups);
+        // the few bulk atoms behind it simply wait for the ghosts too
+        const int n_split = n_bulk & ~255;
+        const bool split = nranks > 1 && overlap && n_split > 0 && n_split < nlocal;
         if (!ghosts_fresh) TRY(halo_forward_seed(sd, split));
         PairArgs p;
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
@@ -1077,8 +1080,8 @@ int Engine::run(int nsteps)
                                   premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
         // bulk atoms have no ghost partners: their forces are computed while the ghosts are in flight
         for (int part = 0; part < (split ? 2 : 1); part++) {
-            p.beg = split ? (part == 0 ? 0 : n_bulk) : 0;
-            p.end = split ? (part == 0 ? n_bulk : nlocal) : nlocal;
+            p.beg = split ? (part == 0 ? 0 : n_split) : 0;
+            p.end = split ? (part == 0 ? n_split : nlocal) : nlocal;
             if (split && part == 1 && !ghosts_fresh) TRY(halo_wait());
             if (layout == 1 && pair_kernel == 1 && pair_style == 1) {
                 p.nall = nlocal + nghost;

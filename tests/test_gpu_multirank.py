@@ -92,19 +92,23 @@ def test_migration_and_rebuilds_conserve_atoms(style):
     assert abs(T[0] - Tref[0]) < 0.08 and all(abs(t - T[0]) < 1e-9 for t in T)
 
 
-def test_overlapped_refresh_is_bit_identical():
-    """bulk kernel || ghost exchange on the side stream, then border kernel == one kernel after the exchange."""
-    a = _run_ranks(4, (2, 2, 1), 12, "dpd/meso", 3.0, 12, overlap=0)[1]
-    b = _run_ranks(4, (2, 2, 1), 12, "dpd/meso", 3.0, 12, overlap=1)[1]
+@pytest.mark.parametrize("style,L", [("dpd/meso", 12), ("dpd/fast/meso", 16)])
+def test_overlapped_refresh_is_bit_identical(style, L):
+    """bulk kernel || ghost exchange on the side stream, then border kernel == one kernel after the exchange.
+    fp32 style: the ring kernel with its step-boundary epilogue and workgroup Newton pairing runs in both parts (the
+    split point is a multiple of its 256-atom groups; fixed-point sums do not depend on the launch structure)."""
+    a = _run_ranks(4, (2, 2, 1), L, style, 3.0, 12, overlap=0)[1]
+    b = _run_ranks(4, (2, 2, 1), L, style, 3.0, 12, overlap=1)[1]
     for u, w in zip(a[:3], b[:3]):
         assert np.array_equal(u, w)
 
 
-def test_sigma0_trajectory_is_grid_independent():
+@pytest.mark.parametrize("style,tol", [("dpd/meso", 2e-6), ("dpd/fast/meso", 2e-4)])
+def test_sigma0_trajectory_is_grid_independent(style, tol):
     L = 12
-    _, ref1, _, _, (x, v, lo, hi) = _run_ranks(1, (1, 1, 1), L, "dpd/meso", 0.0, 20)
-    _, got1, _, _, _ = _run_ranks(8, (2, 2, 2), L, "dpd/meso", 0.0, 20)
+    _, ref1, _, _, (x, v, lo, hi) = _run_ranks(1, (1, 1, 1), L, style, 0.0, 20)
+    _, got1, _, _, _ = _run_ranks(8, (2, 2, 2), L, style, 0.0, 20)
     prd = hi - lo
     d = got1[0] - ref1[0]
     d -= np.round(d / prd) * prd
-    assert np.abs(d).max() < 2e-6 and np.abs(got1[1] - ref1[1]).max() < 2e-5
+    assert np.abs(d).max() < tol and np.abs(got1[1] - ref1[1]).max() < 10 * tol
