@@ -50,6 +50,9 @@ __device__ inline u32 compact3(u32 x)
 // between the compaction and the launches): the grid then covers every brick and the surplus workgroups exit.
 __device__ inline int brick_slot(const BrickArgs &g)
 {
+    // identity list (list builder of the cell-ordered layout): consecutive workgroup ids are spread over the XCDs by the
+    // hardware, so consecutive Morton bricks - full and empty ones alike - are shared out evenly with no compaction pass
+    if (!g.active) return (int)blockIdx.x < g.nactive ? (int)blockIdx.x : -1;
     const int na = g.nactive_dev ? *g.nactive_dev : g.nactive;
     const int per = (na + 7) >> 3;
     const int r = (int)(blockIdx.x >> 3);

@@ -718,13 +718,23 @@ void Engine::range(int r, int &beg, int &end) const
 // MesoAtom::sort_local (atom_meso.cu:343-384) + transfer_post_sort, all device resident
 int Engine::reorder_locals()
 {
-    if (nlocal == 0) { n_bulk = 0; return 0; }
+    if (nlocal == 0) {
+        n_bulk = 0;
+        if (layout >= 1) launch_estart(rkey, 0, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);   // an empty rank: all zero
+        return 0;
+    }
     tbegin("reorder");
     int bits = reorder_key_bits(geom);
     launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
     HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
-    HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
-    launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
+    if (layout >= 1) {
+        // first index of every extended code ([border][Morton(bin)]); the border section starts at estart[M] = n_bulk
+        launch_estart(rkey, nlocal, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);
+        HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    } else {
+        HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
+        launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
+    }
     launch_permute_atoms(cur, alt, rval, nlocal, stream);
     std::swap(cur, alt);
     HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -802,14 +812,19 @@ int Engine::build_cells_and_table()
     if (layout >= 1) {
         // locals are already cell-ordered by the reorder sort; only the ghosts need binning
         tbegin("bin");
-        launch_estart(rkey, nlocal, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);
-        // ids of the bricks that own atoms, compacted in Morton order; the count stays on the device
-        launch_brick_flags(estart, bargs.M, brick_flag, stream);
-        HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, brick_flag, brick_pos, bargs.nbricks, stream));
-        launch_brick_compact(brick_flag, brick_pos, bargs.M, brick_active, d_flags + 2, stream);
-        bargs.active = brick_active;
-        bargs.nactive = bargs.nbricks;
-        bargs.nactive_dev = d_flags + 2;
+        if (layout == 1) {
+            // ids of the bricks that own atoms, compacted in Morton order; the count stays on the device
+            launch_brick_flags(estart, bargs.M, brick_flag, stream);
+            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, brick_flag, brick_pos, bargs.nbricks, stream));
+            launch_brick_compact(brick_flag, brick_pos, bargs.M, brick_active, d_flags + 2, stream);
+            bargs.active = brick_active;
+            bargs.nactive = bargs.nbricks;
+            bargs.nactive_dev = d_flags + 2;
+        } else {
+            bargs.active = nullptr;          // every brick, in workgroup-id order (brick_slot)
+            bargs.nactive = bargs.nbricks;
+            bargs.nactive_dev = nullptr;
+        }
         launch_ghost_morton(cur, geom, nlocal, nghost, bin_key, bin_val, stream);
         if (nghost > 0)
             HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nghost,
