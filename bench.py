@@ -165,10 +165,8 @@ def main():
     b_fused = n_rank * (b_in + 48 + 20 + 48 + 32.0 * (a.every - 1) / max(a.every, 1))
     b_pair = b_fused if fused else b_pair_only
     achieved = b_pair / t_pair / 1e9
-    if a.style == "dpd/fast/meso":
-        kernel = "k_pair_dpd_ring" + (" + step-boundary epilogue (nve final/initial, merge)" if fused else "")
-    else:
-        kernel = "k_pair_dpd_mlpc"
+    kernel = "k_pair_dpd_ring" + ("" if a.style == "dpd/fast/meso" else "<fp64>")
+    kernel += " + step-boundary epilogue (nve final/initial, merge)" if fused else ""
     pair_only = None
     if fused:
         # the force kernel on its own (boundary back in its separate kernel), for comparison with earlier rounds
@@ -181,7 +179,7 @@ def main():
         m.set_option("fuse_pair", 1)
         if calls:
             t1 = ms / calls * 1e-3
-            pair_only = {"kernel": "k_pair_dpd_ring", "us_per_launch": t1 * 1e6, "bytes_per_launch": b_pair_only,
+            pair_only = {"kernel": kernel.split(" + ")[0], "us_per_launch": t1 * 1e6, "bytes_per_launch": b_pair_only,
                          "achieved": b_pair_only / t1 / 1e9, "frac": b_pair_only / t1 / 1e9 / HBM_PEAK_GBS}
     T = m.temperature()
     # the thermostat overshoots to ~1.5 in the first ~100 steps of a cold start and has relaxed to 1 by ~300

@@ -981,7 +981,7 @@ int Engine::force_clear(int r)
 // local range are refreshed for LOCAL and BULK calls, the ghost range for LOCAL and BORDER calls, exactly the
 // split the reference uses to hide its host round trip.
 // kernel choice (option pair_kernel): 0 lane per atom, 1 tile, 2 auto, 3 mlpc, 4 mlp, 5 ring
-bool Engine::ring_selected() const { return (pair_kernel == 5 || pair_kernel == 2) && layout == 2 && pair_style == 1; }
+bool Engine::ring_selected() const { return (pair_kernel == 5 || pair_kernel == 2) && layout == 2; }
 
 void Engine::launch_pair(PairArgs &p, int ev)
 {
@@ -993,7 +993,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
     const bool cell = layout == 2;
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
-    else if ((pair_kernel == 5 || pair_kernel == 2) && cell && pair_style == 1) launch_pair_dpd_ring(p, stream);
+    else if ((pair_kernel == 5 || pair_kernel == 2) && cell) launch_pair_dpd_ring(p, pair_style, stream);
     else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
     else if (pair_kernel == 2 || pair_kernel == 4 || pair_kernel == 5 || cell) launch_pair_dpd_mlp(p, pair_style, stream);
     else launch_pair_dpd_tile(p, pair_style, stream);

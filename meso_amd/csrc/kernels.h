@@ -137,7 +137,7 @@ void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
 void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s);
 // fp32 style on chunked-8 rows: light cutoff scan per lane, hits compacted into a per-wave LDS ring of 4-byte
 // records, heavy phase on full waves with the partner data re-gathered through buffer loads (pair_ring.hip)
-void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s);
+void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s);
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
 void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
 struct ExclArgs;

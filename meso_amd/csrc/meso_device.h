@@ -206,6 +206,43 @@ __device__ inline float gaussian_tea_fast(u32 u, u32 v)
     return fmaxf(-4.0f, fminf(r * f, 4.0f));
 }
 
+// dpd/meso pair force in the reference's mixed precision (fp32 operands, fp64 arithmetic; gpu_dpd<0>
+// pair_dpd_meso.cu:120-160), one definition for the force kernels; compiled uncontracted (explicit fma only).
+struct PairCoeff64 { double cutinv, expw, a0, gamma, sigma; };
+template <bool EW1>
+__device__ inline void pair_dpd_f64(const float4 ci, const float4 cj, const float4 vi, const float4 vj, const PairCoeff64 &c,
+                                    double dt_inv_sqrt, double &fx, double &fy, double &fz)
+{
+    const double dx = (double)ci.x - (double)cj.x, dy = (double)ci.y - (double)cj.y, dz = (double)ci.z - (double)cj.z;
+    const double rsq = dx * dx + dy * dy + dz * dz;
+    const double rn = gaussian_tea(__float_as_uint(vi.w), __float_as_uint(vj.w));
+    const double rinv = rsqrt(rsq);
+    const double r = rsq * rinv;
+    const double dvx = (double)vi.x - (double)vj.x, dvy = (double)vi.y - (double)vj.y, dvz = (double)vi.z - (double)vj.z;
+    const double dot = dx * dvx + dy * dvy + dz * dvz;
+    const double wc = 1.0 - r * c.cutinv;
+    double wr = wc;
+    if (!EW1 && c.expw != 1.0) wr = powd_poly(wc, c.expw);
+    double fpair = c.a0 * wc - (c.gamma * wr * wr * dot * rinv) + (c.sigma * wr * rn * dt_inv_sqrt);
+    fpair *= rinv;
+    fx = dx * fpair; fy = dy * fpair; fz = dz * fpair;
+}
+__device__ inline double rsq_f64(const float4 a, const float4 b)
+{
+    const double dx = (double)a.x - (double)b.x, dy = (double)a.y - (double)b.y, dz = (double)a.z - (double)b.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+// fp64 force component -> 64-bit fixed point with 36 fractional bits (1.5e-11 resolution, +-32768 range; the argument
+// is clamped): adding 1.5 * 2^16 puts the value into the mantissa of a double whose ulp is 2^-36, and the difference of
+// the bit patterns IS the two's-complement fixed-point number.
+#define MESO_FIXED36_MAGIC 98304.0
+__device__ inline u64 to_fixed36(double x)
+{
+    x = fmin(fmax(x, -32000.0), 32000.0);
+    return (u64)__double_as_longlong(x + MESO_FIXED36_MAGIC) - (u64)__double_as_longlong(MESO_FIXED36_MAGIC);
+}
+__device__ inline double from_fixed36(u64 a) { return (double)(long long)a * (1.0 / 68719476736.0); }
+
 // Step boundary of one atom: final_integrate of step s, initial_integrate of step s+1 (fix_nve_meso.cu:62-95,157-178)
 // and, when step s+1 keeps the neighbour table, gpu_merge_xvt for step s+1 (atom_vec_meso.cu:142-167).  One definition
 // for the stand-alone boundary kernel and for the force kernel's epilogue, so both produce the same bits.

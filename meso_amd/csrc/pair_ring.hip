@@ -48,15 +48,21 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 }
 
 // EW1: every pair type has weight exponent s = 1 (the usual DPD choice): w_R = w_C, no pow()
-template <bool NT1, bool EW1, bool SHARE>
-__global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
+// FAST: dpd/fast/meso (fp32 arithmetic, contracted); otherwise dpd/meso (fp64 arithmetic on the fp32 operands through the
+// uncontracted functions of meso_device.h, 36-fractional-bit fixed-point sums)
+template <bool FAST, bool NT1, bool EW1, bool SHARE>
+__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? 5 : 2) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
     extern __shared__ double smem[];
     float *cf32 = (float *)smem;
+    double *cf64 = smem;
     const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * N_COEFF;
-    for (int p = threadIdx.x; p < ncf; p += blockDim.x) cf32[p] = a.coeff32[p];
-    const size_t off = ((size_t)ncf * 4 + 15) & ~(size_t)15;
+    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
+        if (FAST) cf32[p] = a.coeff32[p];
+        else cf64[p] = a.coeff64[p];
+    }
+    const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t per_wave = 64 * 16 * 2 + RG_RING * 16;
     u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
@@ -102,27 +108,41 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
             if (lane < pn) {
                 const u32 owner = pe >> RG_OWNER_SHIFT;
                 const float4 ci = own_c[owner], vi = own_v[owner];
-                float c_cutinv, c_ew, c_a0, c_gamma, c_sigma;
-                if (NT1) {
-                    c_cutinv = (float)a.cf1[P_CUTINV]; c_ew = (float)a.cf1[P_EXPW]; c_a0 = (float)a.cf1[P_A0];
-                    c_gamma = (float)a.cf1[P_GAMMA]; c_sigma = (float)a.cf1[P_SIGMA];
+                u64 qx, qy, qz;
+                if (FAST) {
+                    float c_cutinv, c_ew, c_a0, c_gamma, c_sigma;
+                    if (NT1) {
+                        c_cutinv = (float)a.cf1[P_CUTINV]; c_ew = (float)a.cf1[P_EXPW]; c_a0 = (float)a.cf1[P_A0];
+                        c_gamma = (float)a.cf1[P_GAMMA]; c_sigma = (float)a.cf1[P_SIGMA];
+                    } else {
+                        const float *cf = cf32 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * N_COEFF;
+                        c_cutinv = cf[P_CUTINV]; c_ew = cf[P_EXPW]; c_a0 = cf[P_A0]; c_gamma = cf[P_GAMMA]; c_sigma = cf[P_SIGMA];
+                    }
+                    const float dx = ci.x - pc2.x, dy = ci.y - pc2.y, dz = ci.z - pc2.z;
+                    const float rsq = dx * dx + dy * dy + dz * dz;
+                    const float rn = gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w));
+                    const float rinv = __builtin_amdgcn_rsqf(rsq);
+                    const float r = rsq * rinv;
+                    const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;
+                    const float dot = dx * dvx + dy * dvy + dz * dvz;
+                    const float wc = 1.0f - r * c_cutinv;
+                    float wr = wc;
+                    if (!EW1 && c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
+                    float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
+                    fpair *= rinv;
+                    qx = to_fixed(dx * fpair); qy = to_fixed(dy * fpair); qz = to_fixed(dz * fpair);
                 } else {
-                    const float *cf = cf32 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * N_COEFF;
-                    c_cutinv = cf[P_CUTINV]; c_ew = cf[P_EXPW]; c_a0 = cf[P_A0]; c_gamma = cf[P_GAMMA]; c_sigma = cf[P_SIGMA];
+                    PairCoeff64 pc;
+                    if (NT1) {
+                        pc.cutinv = a.cf1[P_CUTINV]; pc.expw = a.cf1[P_EXPW]; pc.a0 = a.cf1[P_A0]; pc.gamma = a.cf1[P_GAMMA]; pc.sigma = a.cf1[P_SIGMA];
+                    } else {
+                        const double *cf = cf64 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * N_COEFF;
+                        pc.cutinv = cf[P_CUTINV]; pc.expw = cf[P_EXPW]; pc.a0 = cf[P_A0]; pc.gamma = cf[P_GAMMA]; pc.sigma = cf[P_SIGMA];
+                    }
+                    double fx, fy, fz;
+                    pair_dpd_f64<EW1>(ci, pc2, vi, pv2, pc, a.dt_inv_sqrt, fx, fy, fz);
+                    qx = to_fixed36(fx); qy = to_fixed36(fy); qz = to_fixed36(fz);
                 }
-                const float dx = ci.x - pc2.x, dy = ci.y - pc2.y, dz = ci.z - pc2.z;
-                const float rsq = dx * dx + dy * dy + dz * dz;
-                const float rn = gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w));
-                const float rinv = __builtin_amdgcn_rsqf(rsq);
-                const float r = rsq * rinv;
-                const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;
-                const float dot = dx * dvx + dy * dvy + dz * dvz;
-                const float wc = 1.0f - r * c_cutinv;
-                float wr = wc;
-                if (!EW1 && c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
-                float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
-                fpair *= rinv;
-                const u64 qx = to_fixed(dx * fpair), qy = to_fixed(dy * fpair), qz = to_fixed(dz * fpair);
                 const u32 oo = (u32)(w * 64) + owner;
                 __hip_atomic_fetch_add(&facc[oo], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[NB + oo], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -184,13 +204,21 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
         for (int q = 0; q < 8; q++) c2[q] = buf_load4(rc, use[q] ? ((u32)j[q] << 4) : 0xFFFFFFF0u);   // out of range: returns 0, no fetch
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
-            const float rsq = dx * dx + dy * dy + dz * dz;
-            const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
             // lane masks straight from the compares (LLVM predicates: 4 = OLT, 3 = OGE); tail slots hold i itself: rsq = 0
-            const u64 m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) &
-                          usem[q];
-            const bool hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & use[q];
+            u64 m;
+            bool hit;
+            if (FAST) {
+                const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
+                const float rsq = dx * dx + dy * dy + dz * dz;
+                const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
+                m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) & usem[q];
+                hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & use[q];
+            } else {
+                const double rsq = rsq_f64(c1, c2[q]);
+                const double cutsq = NT1 ? a.cf1[P_CUTSQ] : cf64[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
+                m = __builtin_amdgcn_fcmp(rsq, cutsq, 4) & __builtin_amdgcn_fcmp(rsq, MESO_EPSILON_SQ, 3) & usem[q];
+                hit = (rsq < cutsq) & (rsq >= MESO_EPSILON_SQ) & use[q];
+            }
             if (hit) ring[__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1)] =
                     make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float((u32)j[q] | ((SHARE && shb[q]) ? lanehi | RG_SHARED_BIT : lanehi)));   // record word last
             qtail += __popcll(m);
@@ -204,7 +232,9 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
 
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
     if (mine) {
-        double fx = from_fixed(facc[ob]), fy = from_fixed(facc[NB + ob]), fz = from_fixed(facc[2 * NB + ob]);
+        double fx, fy, fz;
+        if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
+        else { fx = from_fixed36(facc[ob]); fy = from_fixed36(facc[NB + ob]); fz = from_fixed36(facc[2 * NB + ob]); }
         if (a.fuse_nve) {
             // final(s) + initial(s+1) (+ merge for s+1 into the other merged buffer: this step's is still being read)
             if (a.accumulate) { fx += a.f[0][i]; fy += a.f[1][i]; fz += a.f[2][i]; }
@@ -214,12 +244,12 @@ __global__ void __launch_bounds__(64 * RG_WAVES, 5) k_pair_dpd_ring(PairArgs a)
     }
 }
 
-void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s)
+void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
 {
     int n = p.end - p.beg;
     if (n <= 0) return;
     const bool nt1 = p.ntypes == 1;
-    size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * 4;
+    size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? 4 : 8);
     size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
     dim3 grid(((n + 64 * RG_WAVES - 1) / (64 * RG_WAVES) + 7) / 8 * 8), block(64 * RG_WAVES);
@@ -231,18 +261,21 @@ void launch_pair_dpd_ring(const PairArgs &p, hipStream_t s)
     else ew1 = p.all_expw_one != 0;
     // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom
     const bool share = p.share != 0 && (p.beg & 255) == 0;
-#define RG_LAUNCH(A, B, C) hipLaunchKernelGGL((k_pair_dpd_ring<A, B, C>), grid, block, sm, s, p)
-    if (share) {
-        if (nt1 && ew1) RG_LAUNCH(true, true, true);
-        else if (nt1) RG_LAUNCH(true, false, true);
-        else if (ew1) RG_LAUNCH(false, true, true);
-        else RG_LAUNCH(false, false, true);
-    } else {
-        if (nt1 && ew1) RG_LAUNCH(true, true, false);
-        else if (nt1) RG_LAUNCH(true, false, false);
-        else if (ew1) RG_LAUNCH(false, true, false);
-        else RG_LAUNCH(false, false, false);
+#define RG_LAUNCH(F, A, B, C) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C>), grid, block, sm, s, p)
+#define RG_PICK(F)                                        \
+    if (share) {                                          \
+        if (nt1 && ew1) RG_LAUNCH(F, true, true, true);   \
+        else if (nt1) RG_LAUNCH(F, true, false, true);    \
+        else if (ew1) RG_LAUNCH(F, false, true, true);    \
+        else RG_LAUNCH(F, false, false, true);            \
+    } else {                                              \
+        if (nt1 && ew1) RG_LAUNCH(F, true, true, false);  \
+        else if (nt1) RG_LAUNCH(F, true, false, false);   \
+        else if (ew1) RG_LAUNCH(F, false, true, false);   \
+        else RG_LAUNCH(F, false, false, false);           \
     }
+    if (fast) { RG_PICK(true) } else { RG_PICK(false) }
+#undef RG_PICK
 #undef RG_LAUNCH
 }
 
