@@ -440,26 +440,43 @@ __global__ void __launch_bounds__(BORDER_CHUNK) k_border_count(const double *__r
                                                                const double *__restrict__ z, int beg, int end,
                                                                Slabs sl, int *__restrict__ chunk_count, int nchunk)
 {
+    // per-wave ballots for all 27 directions, ONE barrier, then 27 threads add the wave totals
+    __shared__ int wave_tot[27][BORDER_CHUNK / 64];
     int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int flags = 0;
     if (i < end) flags = near_flags(x[i], y[i], z[i], sl.lo, sl.hi);
+#pragma unroll 1
     for (int dir = 0; dir < 27; dir++) {
-        if (dir == 13) continue;
-        int c = __syncthreads_count(flags && in_dir(flags, dir));
-        if (threadIdx.x == 0) chunk_count[dir * nchunk + blockIdx.x] = c;
+        const u64 m = __ballot(dir != 13 && flags && in_dir(flags, dir));
+        if (lane == 0) wave_tot[dir][w] = __popcll(m);
     }
-    if (threadIdx.x == 0) chunk_count[13 * nchunk + blockIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        int c = 0;
+        for (int k = 0; k < BORDER_CHUNK / 64; k++) c += wave_tot[threadIdx.x][k];
+        chunk_count[threadIdx.x * nchunk + blockIdx.x] = c;
+    }
 }
 
 // same two-pass compaction keyed by a per-atom direction code (migration: code 13 = the atom stays)
 __global__ void __launch_bounds__(BORDER_CHUNK) k_code_count(const int *__restrict__ code, int beg, int end,
                                                              int *__restrict__ chunk_count, int nchunk)
 {
+    __shared__ int wave_tot[27][BORDER_CHUNK / 64];
     int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int c0 = i < end ? code[i] : -1;
+#pragma unroll 1
     for (int dir = 0; dir < 27; dir++) {
-        int c = __syncthreads_count(c0 == dir);
-        if (threadIdx.x == 0) chunk_count[dir * nchunk + blockIdx.x] = c;
+        const u64 m = __ballot(c0 == dir);
+        if (lane == 0) wave_tot[dir][w] = __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        int c = 0;
+        for (int k = 0; k < BORDER_CHUNK / 64; k++) c += wave_tot[threadIdx.x][k];
+        chunk_count[threadIdx.x * nchunk + blockIdx.x] = c;
     }
 }
 
@@ -467,20 +484,24 @@ __global__ void __launch_bounds__(BORDER_CHUNK) k_code_fill(const int *__restric
                                                             const int *__restrict__ chunk_offset, int nchunk,
                                                             int *__restrict__ list)
 {
-    __shared__ int wave_tot[BORDER_CHUNK / 64];
+    __shared__ int wave_tot[27][BORDER_CHUNK / 64];
     int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int c0 = i < end ? code[i] : -1;
+#pragma unroll 1
     for (int dir = 0; dir < 27; dir++) {
-        bool hit = c0 == dir;
-        u64 m = __ballot(hit);
-        int pre = __popcll(m & ((1ULL << lane) - 1ULL));
-        if (lane == 0) wave_tot[w] = __popcll(m);
-        __syncthreads();
+        const u64 m = __ballot(c0 == dir);
+        if (lane == 0) wave_tot[dir][w] = __popcll(m);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int dir = 0; dir < 27; dir++) {
+        const bool hit = c0 == dir;
+        const u64 m = __ballot(hit);
+        if (!m) continue;
         int base = chunk_offset[dir * nchunk + blockIdx.x];
-        for (int k = 0; k < w; k++) base += wave_tot[k];
-        if (hit) list[base + pre] = i;
-        __syncthreads();
+        for (int k = 0; k < w; k++) base += wave_tot[dir][k];
+        if (hit) list[base + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
     }
 }
 
@@ -509,22 +530,26 @@ __global__ void __launch_bounds__(BORDER_CHUNK) k_border_fill(const double *__re
                                                               const int *__restrict__ chunk_offset, int nchunk,
                                                               int *__restrict__ sendlist)
 {
-    __shared__ int wave_tot[BORDER_CHUNK / 64];
+    __shared__ int wave_tot[27][BORDER_CHUNK / 64];
     int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int flags = 0;
     if (i < end) flags = near_flags(x[i], y[i], z[i], sl.lo, sl.hi);
+#pragma unroll 1
+    for (int dir = 0; dir < 27; dir++) {
+        const u64 m = __ballot(dir != 13 && flags && in_dir(flags, dir));
+        if (lane == 0) wave_tot[dir][w] = __popcll(m);
+    }
+    __syncthreads();                        // one barrier for all directions
+#pragma unroll 1
     for (int dir = 0; dir < 27; dir++) {
         if (dir == 13) continue;
-        bool hit = flags && in_dir(flags, dir);
-        u64 m = __ballot(hit);
-        int pre = __popcll(m & ((1ULL << lane) - 1ULL));
-        if (lane == 0) wave_tot[w] = __popcll(m);
-        __syncthreads();
+        const bool hit = flags && in_dir(flags, dir);
+        const u64 m = __ballot(hit);
+        if (!m) continue;
         int base = chunk_offset[dir * nchunk + blockIdx.x];
-        for (int k = 0; k < w; k++) base += wave_tot[k];
-        if (hit) sendlist[base + pre] = i;
-        __syncthreads();
+        for (int k = 0; k < w; k++) base += wave_tot[dir][k];
+        if (hit) sendlist[base + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
     }
 }
 
