@@ -371,3 +371,24 @@ def test_builders_agree_on_a_large_box(Meso):
         rows[name] = {int(tag[i]): frozenset(map(tuple, c4[table[i, :count[i]]].tolist())) for i in range(0, len(tag), 37)}
         m.close()
     assert rows["cell"] == rows["brick"]
+
+
+@pytest.mark.parametrize("style", ["dpd/fast/meso", "dpd/meso"])
+def test_full_size_box_invariants(Meso, style):
+    """BASELINE.json's 64^3 rho=4 box (1 048 576 atoms), through size-independent properties: every pair force has its
+    opposite (sum of forces = 0 to rounding), the list holds the expected ~35.9 entries per atom, 20 steps with a rebuild
+    every 5 conserve momentum and atom identities, and the fused default path agrees with the separate-kernel path."""
+    m, (x, v, lo, hi) = _engine(Meso, 64, style=style)
+    n = len(x)
+    info = m.neigh_info()
+    assert abs(info["avg_count"] - 35.86) < 0.2 and info["max_count"] < 80
+    f = m.gather()[2]
+    scale = np.abs(f).max()
+    assert 50 < scale < 1000 and np.abs(f.sum(0)).max() < 1e-4 * scale * np.sqrt(n)
+    m.run(20)
+    xg, vg, fg, tag, typ = m.gather()
+    assert np.array_equal(tag, np.arange(1, n + 1)) and np.isfinite(xg).all() and np.isfinite(vg).all()
+    assert np.abs(vg.sum(0)).max() < 1e-6 * n                    # momentum (started at 0)
+    assert 0.9 < m.temperature() < 1.6                            # thermostat transient of a cold start
+    assert m.neigh_info()["nbuild"] == 4
+    m.close()
