@@ -343,24 +343,24 @@ run             200
 
 def test_builders_agree_on_a_large_box(Meso):
     """32^3 after 40 steps: the wave-per-bin tile builder and the lane-per-atom cell builder produce the same rows
-    (as sets) for every atom; the brick layout's 16-bit rows convert to the same sets too."""
+    (as sets) for every atom of the same state; the brick
+    layout's 16-bit rows convert to the same sets too."""
+    m, _ = _engine(Meso, 32, style="dpd/fast/meso", opts=(("neigh_kernel", 0),))
+    m.run(40)
     tabs = {}
-    for name, opts in (("cell", (("neigh_kernel", 0),)), ("tile", (("neigh_kernel", 1),))):
-        m, _ = _engine(Meso, 32, style="dpd/fast/meso", opts=opts)
-        m.run(40)
+    for name, nk in (("cell", 0), ("tile", 1)):
+        m.set_option("neigh_kernel", nk)
         m.reneighbor()
         count, table = m.neigh_table()
-        tag = m.gather(by_tag=False)[3]
-        tabs[name] = (count, table, tag)
-        m.close()
+        tabs[name] = (count, table, m.gather(by_tag=False)[3])
+    m.close()
     c0, t0, g0 = tabs["cell"]
-    for name in ("tile",):
-        c1, t1, g1 = tabs[name]
-        assert np.array_equal(g0, g1)                      # same reorder: rows are comparable index by index
-        assert np.array_equal(c0, c1)
-        a = np.sort(np.where(np.arange(t0.shape[1])[None, :] < c0[:, None], t0, -1), axis=1)
-        b = np.sort(np.where(np.arange(t1.shape[1])[None, :] < c1[:, None], t1, -1), axis=1)
-        assert np.array_equal(a, b)
+    c1, t1, g1 = tabs["tile"]
+    assert np.array_equal(g0, g1)                          # same reorder: rows are comparable index by index
+    assert np.array_equal(c0, c1)
+    a = np.sort(np.where(np.arange(t0.shape[1])[None, :] < c0[:, None], t0, -1), axis=1)
+    b = np.sort(np.where(np.arange(t1.shape[1])[None, :] < c1[:, None], t1, -1), axis=1)
+    assert np.array_equal(a, b)
     # brick rows (converted to global indices) on the initial configuration, where no trajectory rounding can differ
     rows = {}
     for name, opts in (("cell", (("neigh_kernel", 0),)), ("brick", (("layout", 1),))):
