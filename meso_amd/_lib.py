@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmeso_hip.so")
+# MESO_LIB: another build of the same library inside the tree (A/B timing of kernel variants in one GPU session)
+LIB_PATH = os.environ.get("MESO_LIB") or os.path.join(_HERE, "libmeso_hip.so")
 
 _vp, _i, _d, _f = C.c_void_p, C.c_int, C.c_double, C.c_float
 _i64, _u32, _sz, _cp = C.c_int64, C.c_uint32, C.c_size_t, C.c_char_p
