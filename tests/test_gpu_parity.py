@@ -392,3 +392,42 @@ def test_full_size_box_invariants(Meso, style):
     assert 0.9 < m.temperature() < 1.6                            # thermostat transient of a cold start
     assert m.neigh_info()["nbuild"] == 4
     m.close()
+
+
+@pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-9), ("dpd/fast/meso", 2e-3)])
+@pytest.mark.parametrize("path", ["default", "lane", "cell+mlp", "cell+mlpc", "brick"])
+def test_general_coefficients_noncubic_box(Meso, oracle, style, tol, path):
+    """Two atom types, per-pair cutoffs (1.0 / 0.8 / 0.9), weight exponents s = 1, 0.5 and 2 (the pow() branches), a
+    10 x 8 x 12 box: forces of every kernel against the oracle."""
+    from oracle.meso_sim import MesoRefSim
+    rng = np.random.default_rng(77)
+    lo, hi = np.zeros(3), np.array([10.0, 8.0, 12.0])
+    n = int(4 * np.prod(hi))
+    x = rng.random((n, 3)) * hi
+    v = rng.normal(size=(n, 3))
+    v -= v.mean(0)
+    types = (rng.random(n) < 0.4).astype(np.int32) + 1
+    coeffs = {(1, 1): (15.0, 4.5, 3.0, 1.0, 1.0), (2, 2): (25.0, 4.0, 2.5, 0.5, 0.8), (1, 2): (40.0, 5.0, 3.5, 2.0, 0.9)}
+    s = MesoRefSim(x, v, lo, hi, types=types, ntypes=2, fast=(style != "dpd/meso"))
+    for (i, j), c in coeffs.items():
+        s.pair_coeff(i, j, *c)
+    s.setup()
+    m = Meso()
+    opts = {"default": (), "lane": (("pair_kernel", 0),)}.get(path, PATHS.get(path))
+    for k, val in opts:
+        m.set_option(k, val)
+    m.read_atoms(x, v, lo, hi, types=types, ntypes=2)
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=5, check=False)
+    m.pair_style(style, 1.0, DP_RUN["seed"])
+    for (i, j), c in coeffs.items():
+        m.pair_coeff(i, j, *c)
+    m.timestep(0.005)
+    m.setup()
+    m.force_clear("local")
+    m.compute()
+    f = m.gather()[2]
+    m.close()
+    # uniformly random positions contain a few very close pairs: compare relative to each atom's own force scale
+    scale = np.maximum(np.abs(s.f).max(1, keepdims=True), np.median(np.abs(s.f)))
+    assert (np.abs(f - s.f) / scale).max() < (tol if style == "dpd/meso" else 5 * tol)
