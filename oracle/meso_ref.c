@@ -72,15 +72,24 @@ uint meso_mantissa(float u, float v, float w)
 #define TEA_K3 0x7E95761Eu
 #define TEA_DT 0x9E3779B9u
 
-void meso_tea_core(int rounds, uint *pv0, uint *pv1)
+/* The cipher core with the key as an argument: the reference's __TEA_core (math_meso.h:450-464) is the Tiny Encryption
+ * Algorithm of Wheeler & Needham (1994) with a fixed key (math_meso.h:444-448) and a template round count; with the key
+ * exposed the structure is pinned by the published known-answer vectors of TEA (tests/test_oracle_meso.py). */
+void meso_tea_core_key(int rounds, const uint key[4], uint *pv0, uint *pv1)
 {
     uint v0 = *pv0, v1 = *pv1, sum = 0;
     for (int n = 0; n < rounds; n++) {
         sum += TEA_DT;
-        v0 += ((v1 << 4) + TEA_K0) ^ (v1 + sum) ^ ((v1 >> 5) + TEA_K1);
-        v1 += ((v0 << 4) + TEA_K2) ^ (v0 + sum) ^ ((v0 >> 5) + TEA_K3);
+        v0 += ((v1 << 4) + key[0]) ^ (v1 + sum) ^ ((v1 >> 5) + key[1]);
+        v1 += ((v0 << 4) + key[2]) ^ (v0 + sum) ^ ((v0 >> 5) + key[3]);
     }
     *pv0 = v0; *pv1 = v1;
+}
+
+void meso_tea_core(int rounds, uint *pv0, uint *pv1)
+{
+    static const uint key[4] = {TEA_K0, TEA_K1, TEA_K2, TEA_K3};
+    meso_tea_core_key(rounds, key, pv0, pv1);
 }
 
 uint meso_premix_tea(int rounds, uint v0, uint v1)

@@ -7,6 +7,36 @@ import pytest
 from meso_amd.datagen import make_box
 
 
+def test_tea_published_vectors(oracle):
+    """Known-answer vectors of the Tiny Encryption Algorithm (32 cycles): zero key / zero block, and the widely quoted
+    key 00112233 44556677 8899aabb ccddeeff with block 01234567 89abcdef.  Pins the cipher core (shift / add / xor
+    structure, delta, round order) that the reference instantiates with its own key and 4, 16 or 64 rounds."""
+    import ctypes as C
+    M = oracle.meso_lib()
+    M.meso_tea_core_key.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    M.meso_tea_core_key.restype = None
+
+    def enc(key, v0, v1):
+        k = (C.c_uint32 * 4)(*key)
+        a, b = C.c_uint32(v0), C.c_uint32(v1)
+        M.meso_tea_core_key(32, k, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    assert enc([0, 0, 0, 0], 0, 0) == (0x41EA3A0A, 0x94BAA940)
+    assert enc([0x00112233, 0x44556677, 0x8899AABB, 0xCCDDEEFF], 0x01234567, 0x89ABCDEF) == (0x126C6B92, 0xC0653A3E)
+    # the fixed-key entry point is the keyed one with the reference's key (math_meso.h:444-448)
+    ref_key = [0xA341316C, 0xC8013EA4, 0xAD90777D, 0x7E95761E]
+    for r in (4, 16, 64):
+        assert oracle.tea_core(r, 123, 456) == _enc_rounds(M, C, ref_key, r, 123, 456)
+
+
+def _enc_rounds(M, C, key, rounds, v0, v1):
+    k = (C.c_uint32 * 4)(*key)
+    a, b = C.c_uint32(v0), C.c_uint32(v1)
+    M.meso_tea_core_key(rounds, k, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def test_tea_known_structure(oracle):
     M = oracle.meso_lib()
     # one round by hand (math_meso.h:450-456)
