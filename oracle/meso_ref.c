@@ -11,6 +11,9 @@
  * What pins it instead (tests/test_oracle_meso.py):
  *   - at sigma=0 its forces agree with the golden-pinned stock-LAMMPS restatement
  *     (oracle/lmp_dpd_cpu.c) to the fp32-coordinate tolerance stated in the test;
+ *   - the cipher core against the published known-answer vectors of TEA (32 cycles,
+ *     zero key/block -> 41EA3A0A 94BAA940; key 00112233..ccddeeff, block 01234567
+ *     89abcdef -> 126C6B92 C0653A3E), the polynomials against libm;
  *   - TEA/Gaussian invariants (symmetry, |xi|<=4, moments), sum_i F_i = 0,
  *     neighbour set == brute force.
  *
