@@ -46,6 +46,7 @@ int meso_device_sync(meso_ctx *ctx);
  *   pair_share    1  ring kernel: pairs inside one aligned 256-atom group are evaluated once (Newton pairing)
  *   fuse_clear    1  force kernel writes f instead of clear + accumulate
  *   overlap       1  several ranks: ghost refresh on a side stream under the bulk force kernel
+ *   brick_margin  1  multiplier on the expected brick-neighbourhood population (raise for strongly inhomogeneous systems)
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */
 int meso_set_option(meso_ctx *ctx, const char *key, double value);
 

@@ -113,9 +113,9 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
         if (tid == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 0; }
         return;
     }
-    if (nh > BRK_MAXH || n0 + n1 > BRK_MAXOWN) {
+    if (nh > g.maxh || (g.maxown > 0 && n0 + n1 > g.maxown)) {
         if (tid == 0) {
-            atomicMax(overflow, 100000 + (nh > BRK_MAXH ? nh : n0 + n1));
+            atomicMax(overflow, 100000 + (nh > g.maxh ? nh : n0 + n1));
             hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 0;
         }
         return;
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
         if (off < hl0[lo]) src = hs0[lo] + off;
         else if ((off -= hl0[lo]) < hl1[lo]) src = hs1[lo] + off;
         else src = hs2[lo] + (off - hl1[lo]);
-        g.hmap[(size_t)slot * BRK_MAXH + h] = (u32)src;
+        g.hmap[(size_t)slot * g.maxh + h] = (u32)src;
     }
     // own atom -> (halo slot, halo bin)
     for (int s = 0; s < 2; s++) {
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const 
     const int nh = hdr[0], o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
     if (n0 + n1 == 0) return;
     for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
-    for (int h = tid; h < nh; h += BRK_THREADS) hc[h] = coord4[g.hmap[(size_t)slot * BRK_MAXH + h]];
+    for (int h = tid; h < nh; h += BRK_THREADS) hc[h] = coord4[g.hmap[(size_t)slot * g.maxh + h]];
     __syncthreads();
     uint4 *rows = (uint4 *)table16;
     for (int o = tid; o < n0 + n1; o += BRK_THREADS) {
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const 
 //     indices on the way out, tail slots padded with the atom itself.
 // Entry order inside a row is (batch, lane): deterministic, and different from the lane-per-atom builders.
 #define TB_G 4
-#define TB_ROWCAP 192
+#define TB_ROWCAP_MAX 1024         // rows are staged in LDS at their full capacity n_col (2 bytes per entry)
 
 template <bool EXCL>
 __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
@@ -242,11 +242,14 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                                                               int *__restrict__ overflow, ExclArgs ex, int dbg)
 {
 #pragma clang fp contract(fast)
-    __shared__ float hx[BRK_MAXH], hy[BRK_MAXH], hz[BRK_MAXH];   // SoA: candidate reads are consecutive slots
-    __shared__ u32 hgi[BRK_MAXH];
+    // staged neighbourhood, SoA (candidate reads are consecutive slots); sized at launch for g.maxh halo atoms, so denser
+    // systems trade occupancy for capacity instead of failing
+    extern __shared__ float tb_dyn[];
+    float *hx = tb_dyn, *hy = hx + g.maxh, *hz = hy + g.maxh;
+    u32 *hgi = (u32 *)(hz + g.maxh);
+    unsigned short *rowbuf = (unsigned short *)(hgi + g.maxh);          // [wave][TB_G][n_col]
     __shared__ int hoff[BRK_NHB + 1];
     __shared__ int hloc[BRK_NHB];
-    __shared__ unsigned short rowbuf[BRK_WAVES][TB_G][TB_ROWCAP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int slot = brick_slot(g);
     if (slot < 0) return;
@@ -256,13 +259,14 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
     for (int t = tid; t < BRK_NHB; t += BRK_THREADS) hloc[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + t];
     for (int h = tid; h < nh; h += BRK_THREADS) {
-        const u32 src = g.hmap[(size_t)slot * BRK_MAXH + h];
+        const u32 src = g.hmap[(size_t)slot * g.maxh + h];
         hgi[h] = src;
         const float4 c = coord4[src];
         hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
     }
     __syncthreads();
-    unsigned short (*myrow)[TB_ROWCAP] = rowbuf[w];
+    unsigned short *myrow0 = rowbuf + (size_t)w * TB_G * n_col;
+    auto myrow = [&](int t) { return myrow0 + t * n_col; };
     if (dbg == 1) return;        // timing ablation: staging only
 
     for (int k = w; k < BRK_CODES; k += BRK_WAVES) {
@@ -342,7 +346,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                         // the chains of the group's atoms overlap
                         const u64 m = __builtin_amdgcn_ballot_w64(hit);
                         const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
-                        if (hit) myrow[t][min(pos, (u32)(TB_ROWCAP - 1))] = (unsigned short)cs;
+                        if (hit) myrow(t)[min(pos, (u32)(n_col - 1))] = (unsigned short)cs;
                         nrow[t] += __popcll(m);
                     }
                 }
@@ -363,7 +367,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                         // the chains of the group's atoms overlap
                         const u64 m = __builtin_amdgcn_ballot_w64(hit);
                         const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
-                        if (hit) myrow[t][min(pos, (u32)(TB_ROWCAP - 1))] = (unsigned short)cs;
+                        if (hit) myrow(t)[min(pos, (u32)(n_col - 1))] = (unsigned short)cs;
                         nrow[t] += __popcll(m);
                     }
                 }
@@ -393,11 +397,11 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                         if (n > n_col) atomicMax(overflow, n);
                         count[i] = min(n, n_col);
                     }
-                    const int nn = dbg == 2 ? 0 : min(n, min(n_col, TB_ROWCAP));
+                    const int nn = dbg == 2 ? 0 : min(n, n_col);
                     int *dst = table + row_word8(i, 0, n_col) * 8;
                     for (int e = lane; e < ((nn + 7) & ~7); e += 64) {
                         int val = i;
-                        if (e < nn) val = (int)hgi[myrow[t][e]];
+                        if (e < nn) val = (int)hgi[myrow(t)[e]];
                         dst[(size_t)(e >> 3) * 512 + (e & 7)] = val;
                     }
                 }
@@ -416,7 +420,7 @@ __global__ void __launch_bounds__(256) k_brick_convert(BrickArgs g, int n_col, c
     if (slot < 0) return;
     const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
     const int o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
-    const u32 *hmap = g.hmap + (size_t)slot * BRK_MAXH;
+    const u32 *hmap = g.hmap + (size_t)slot * g.maxh;
     for (int o = threadIdx.x; o < n0 + n1; o += 256) {
         const int i = o < n0 ? o0 + o : o1 + (o - n0);
         const size_t base = ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
@@ -453,7 +457,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 2) k_brick_pair(BrickArgs g, Pair
     // work-range filter (compute_bulk / compute_border): nothing of this brick inside [beg, end)
     if ((n0 == 0 || o0 >= a.end || o0 + n0 <= a.beg) && (n1 == 0 || o1 >= a.end || o1 + n1 <= a.beg)) return;
     for (int h = tid; h < nh; h += BRK_THREADS) {
-        const u32 src = g.hmap[(size_t)slot * BRK_MAXH + h];
+        const u32 src = g.hmap[(size_t)slot * g.maxh + h];
         hgi[h] = src;
         hc[h] = a.coord4[src];
     }
@@ -649,7 +653,10 @@ __global__ void __launch_bounds__(256) k_brick_compact(const int *__restrict__ f
     if (b == nb - 1) *nactive = pos[b] + flag[b];
 }
 int brick_codes() { return BRK_CODES; }
-size_t brick_hmap_pitch() { return BRK_MAXH; }
+int brick_static_maxh() { return BRK_MAXH; }        // capacity of the brick-layout kernels (static LDS arrays)
+int brick_static_maxown() { return BRK_MAXOWN; }
+// largest halo the tile builder can stage: 160 KB of LDS minus its static part (row staging, bin offsets), 16 B per atom
+int tile_build_maxh_limit(int n_col) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / 16); }
 size_t brick_hoff_pitch() { return BRK_HOFF_PITCH; }
 size_t brick_hdr_pitch() { return BRK_HDR_PITCH; }
 
@@ -694,16 +701,21 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
 {
     if (g.nactive <= 0) return;
     ExclArgs ex = {nullptr, nullptr, nullptr, 0};
+    const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2;
+    if (dyn > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_tile_build<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipFuncSetAttribute((const void *)k_tile_build<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    }
     if (excl && excl->tagc) {
         ex = *excl;
-        hipLaunchKernelGGL((k_tile_build<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table,
+        hipLaunchKernelGGL((k_tile_build<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
                            overflow, ex, dbg);
     } else {
-        hipLaunchKernelGGL((k_tile_build<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table,
+        hipLaunchKernelGGL((k_tile_build<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
                            overflow, ex, dbg);
     }
 }
-int tile_build_rowcap() { return TB_ROWCAP; }
+int tile_build_rowcap() { return TB_ROWCAP_MAX; }
 
 void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,
                         unsigned short *table16, int *overflow, hipStream_t s)

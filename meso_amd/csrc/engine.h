@@ -195,6 +195,9 @@ private:
     int *brick_hoff = nullptr, *brick_hdr = nullptr;
     uint32_t *brick_hmap = nullptr, *brick_own = nullptr;
     size_t brick_cap = 0;
+    int brick_maxh_alloc = 0;
+    bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
+    double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)
     size_t estart_cap = 0;
     unsigned short *table16 = nullptr;
     bool table32_valid = false;

@@ -240,6 +240,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "overlap") { overlap = (int)val; return 0; }
     if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
     if (key == "fuse_pair") { fuse_pair = (int)val; return 0; }
+    if (key == "brick_margin") { if (val < 1.0) return fail(1, "brick_margin must be >= 1"); brick_margin = val; params_ready = false; return 0; }
     if (key == "pair_share") { pair_share = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
@@ -671,11 +672,26 @@ int Engine::init_params()
                 sort_temp_bytes = tb;
             }
         }
-        if (layout >= 1 && M / brick_codes() + 8 > brick_cap) {
+        // halo capacity of a brick (6x6x6 bins): mean + 6.5 sigma of a Poisson count at this density, times the option
+        // brick_margin for inhomogeneous systems.  The brick-layout kernels have static LDS arrays; the tile builder
+        // sizes its LDS at launch (occupancy drops from 3 to 2 workgroups per CU above ~2340 atoms) and falls back to the
+        // lane-per-atom builder when even one workgroup per CU could not hold the neighbourhood.
+        {
+            const double binvol = geom.binsize[0] * geom.binsize[1] * geom.binsize[2];
+            const double mean = density * 216.0 * binvol * brick_margin;
+            int want = ((int)std::ceil(mean + 6.5 * std::sqrt(mean)) + 63) / 64 * 64;
+            if (layout == 1) want = brick_static_maxh();
+            else if (want < brick_static_maxh()) want = brick_static_maxh();
+            tile_fits = want <= tile_build_maxh_limit(n_col);
+            bargs.maxh = want;
+            bargs.maxown = layout == 1 ? brick_static_maxown() : 0;
+        }
+        if (layout >= 1 && (M / brick_codes() + 8 > brick_cap || bargs.maxh != brick_maxh_alloc)) {
             dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr);
             brick_cap = M / brick_codes() + 8;
+            brick_maxh_alloc = bargs.maxh;
             HIPCHK(dalloc(brick_hoff, brick_cap * brick_hoff_pitch()));
-            HIPCHK(dalloc(brick_hmap, brick_cap * brick_hmap_pitch()));
+            HIPCHK(dalloc(brick_hmap, brick_cap * (size_t)bargs.maxh));
             HIPCHK(dalloc(brick_hdr, brick_cap * brick_hdr_pitch()));
         }
         bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / brick_codes());
@@ -849,7 +865,7 @@ int Engine::build_cells_and_table()
             tbegin("neigh");
             ExclArgs ex = {nullptr, nullptr, nullptr, 0};
             if (have_bonds && msp > 0) { ex.tagc = tagc; ex.nspecial = cur.nspecial; ex.special = cur.special; ex.msp = msp; }
-            if (neigh_kernel == 1 && n_col <= tile_build_rowcap()) {
+            if (neigh_kernel == 1 && n_col <= tile_build_rowcap() && tile_fits) {
                 // wave-per-bin ballot builder on LDS-staged neighbourhoods (every brick: empty ones exit at once)
                 bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
                 launch_brick_plan(bargs, d_flags, stream);
@@ -910,8 +926,8 @@ int Engine::check_overflow()
     if (h_flags[0]) {
         char buf[200];
         if (h_flags[0] >= 100000)
-            snprintf(buf, sizeof buf, "Brick halo overflow: %d atoms in one brick neighbourhood; local density too high",
-                     h_flags[0] - 100000);
+            snprintf(buf, sizeof buf, "Brick halo overflow: %d atoms in one brick neighbourhood (capacity %d); local density too "
+                     "high - raise option brick_margin or use neigh_kernel 0", h_flags[0] - 100000, bargs.maxh);
         else
             snprintf(buf, sizeof buf, "Pair table overflow: %d > %d; local density too high", h_flags[0], n_col);
         return fail(4, buf);

@@ -156,6 +156,8 @@ struct BrickArgs {
     int mbin[3];
     int nbricks;         // M / 64
     const int *active;   // [nactive] ids of bricks that own atoms; null: identity (every brick, empty ones exit)
+    int maxh;            // halo atoms a brick may hold (pitch of hmap, LDS of the tile builder); chosen from the density
+    int maxown;          // atoms a brick may own (0: unlimited - only the brick-layout kernels have a static bound)
     int nactive;         // launch bound: number of active bricks, or of all bricks when the count is only on the device
     const int *nactive_dev;   // null: nactive is exact
     // written by the plan kernel once per rebuild (pitches: brick_*_pitch())
@@ -165,7 +167,9 @@ struct BrickArgs {
     uint32_t *own_info;  // [nlocal]    own atom -> halo slot | halo bin << 16
 };
 int brick_codes();
-size_t brick_hmap_pitch();
+int brick_static_maxh();
+int brick_static_maxown();
+int tile_build_maxh_limit(int n_col);
 size_t brick_hoff_pitch();
 size_t brick_hdr_pitch();
 void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s);

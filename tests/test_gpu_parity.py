@@ -431,3 +431,36 @@ def test_general_coefficients_noncubic_box(Meso, oracle, style, tol, path):
     # uniformly random positions contain a few very close pairs: compare relative to each atom's own force scale
     scale = np.maximum(np.abs(s.f).max(1, keepdims=True), np.median(np.abs(s.f)))
     assert (np.abs(f - s.f) / scale).max() < (tol if style == "dpd/meso" else 5 * tol)
+
+
+@pytest.mark.parametrize("rho,L", [(6, 9), (10, 8)])
+def test_denser_fluids_use_a_larger_halo_capacity(Meso, oracle, rho, L):
+    """rho = 6 and 10 (the tile builder's LDS is sized from the density: ~2900 / ~4700 halo atoms per brick instead of
+    ~1900): default path against the oracle, and 10 steps keep every atom."""
+    from meso_amd.datagen import make_positions, make_velocities
+    from oracle.meso_sim import MesoRefSim
+    x = make_positions(L, rho=rho)
+    v = make_velocities(len(x), 4321)
+    lo, hi = np.zeros(3), np.full(3, float(L))
+    stride = 64 * rho
+    s = MesoRefSim(x, v, lo, hi, fast=True, stride=stride, dt=0.002)
+    s.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    s.setup()
+    m = Meso()
+    m.read_atoms(x, v, lo, hi)
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=5, check=False)
+    m.pair_style("dpd/fast/meso", 1.0, DP_RUN["seed"])
+    m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    m.timestep(0.002)
+    m.setup()
+    count, _ = m.neigh_table()
+    tag = m.gather(by_tag=False)[3]
+    assert np.array_equal(count[np.argsort(tag)], s.count)
+    m.force_clear("local")
+    m.compute()
+    f = m.gather()[2]
+    assert np.abs(f - s.f).max() < 2e-3 * np.abs(s.f).max()
+    m.run(10)
+    assert np.array_equal(m.gather()[3], np.arange(1, len(x) + 1))
+    m.close()
