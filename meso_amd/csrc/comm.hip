@@ -9,6 +9,7 @@
 // Transports: RCCL (ncclSend/ncclRecv grouped), LOCAL (several ranks inside one process, device-to-device
 // copies: how the multi-rank path is exercised on a single GPU), HOST (caller-supplied exchange on host buffers).
 #include "engine.h"
+#include <cstdlib>
 #include "meso_device.h"
 #include <algorithm>
 #include <condition_variable>
@@ -100,7 +101,8 @@ int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *uid, si
     for (int d = 0; d < 3; d++) procgrid[d] = pg[d];
     myloc[0] = rk % pg[0]; myloc[1] = (rk / pg[0]) % pg[1]; myloc[2] = rk / (pg[0] * pg[1]);
     params_ready = false;
-    if (nr == 1) return 0;
+    // one rank needs no transport; MESO_FORCE_RCCL=1 still creates the communicator (library coexistence test)
+    if (nr == 1 && !(transport == 1 && getenv("MESO_FORCE_RCCL"))) return 0;
     if (transport == 1) {
         if (!uid || uid_bytes < sizeof(ncclUniqueId)) return fail(1, "RCCL transport needs the 128-byte unique id of rank 0");
         ncclUniqueId id;

@@ -112,3 +112,41 @@ def test_sigma0_trajectory_is_grid_independent(style, tol):
     d = got1[0] - ref1[0]
     d -= np.round(d / prd) * prd
     assert np.abs(d).max() < tol and np.abs(got1[1] - ref1[1]).max() < 10 * tol
+
+
+def test_rccl_communicator_next_to_torch_distributed():
+    """bench.py's multi-GPU path in miniature on one GPU: torch.distributed (RCCL) is initialised first, then the engine
+    obtains an ncclUniqueId and creates ITS OWN communicator in the same process (world size 1) and runs a few steps.
+    Checks that the library's RCCL and the one torch loaded coexist; the N > 1 exchange itself runs over the LOCAL
+    transport in the tests above (the box has one GPU)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from meso_amd.api import Meso, nccl_unique_id
+    if not dist.is_nccl_available():
+        pytest.skip("torch built without RCCL")
+    os.environ["MESO_FORCE_RCCL"] = "1"
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        uid = torch.from_numpy(nccl_unique_id().copy()).cuda()
+        dist.broadcast(uid, 0)
+        x, v, lo, hi = make_box(8)
+        m = Meso(0)
+        m.comm_init(1, 0, (1, 1, 1), "rccl", uid.cpu().numpy())
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style("dpd/fast/meso", 1.0, 419084618)
+        m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+        m.timestep(0.005)
+        m.setup()
+        m.run(10)
+        assert 0.5 < m.temperature() < 2.0
+        m.close()
+    finally:
+        os.environ.pop("MESO_FORCE_RCCL", None)
+        if dist.is_initialized():
+            dist.destroy_process_group()
