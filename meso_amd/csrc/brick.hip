@@ -344,7 +344,9 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                         }
                         // no "any hit?" branch: a batch of 64 candidates almost always holds one, and straight-line code lets
                         // the chains of the group's atoms overlap
-                        const u64 m = __builtin_amdgcn_ballot_w64(hit);
+                        // lane mask straight from the compares (LLVM predicates: 5 = OLE, 33 = NE) unless exclusions apply
+                        const u64 m = EXCL ? __builtin_amdgcn_ballot_w64(hit)
+                                           : (__builtin_amdgcn_fcmpf(d, rc2, 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33));
                         const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
                         if (hit) myrow(t)[min(pos, (u32)(n_col - 1))] = (unsigned short)cs;
                         nrow[t] += __popcll(m);
@@ -365,7 +367,9 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                         }
                         // no "any hit?" branch: a batch of 64 candidates almost always holds one, and straight-line code lets
                         // the chains of the group's atoms overlap
-                        const u64 m = __builtin_amdgcn_ballot_w64(hit);
+                        // lane mask straight from the compares (LLVM predicates: 5 = OLE, 33 = NE) unless exclusions apply
+                        const u64 m = EXCL ? __builtin_amdgcn_ballot_w64(hit)
+                                           : (__builtin_amdgcn_fcmpf(d, rc2, 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33));
                         const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
                         if (hit) myrow(t)[min(pos, (u32)(n_col - 1))] = (unsigned short)cs;
                         nrow[t] += __popcll(m);
