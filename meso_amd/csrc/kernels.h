@@ -147,7 +147,8 @@ void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key
 // wave-per-tile, ballot-compacted variant (forces only)
 void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s);
 
-// ---- brick layout (brick.hip): Morton-aligned 4x4x2-bin bricks, halo staged in LDS, 16-bit rows ---------
+// ---- bricks (brick.hip): Morton-aligned 4x4x4-bin bricks with a per-rebuild plan of their 6x6x6-bin neighbourhoods; used by
+// the tile list builder of the cell-ordered layout and by the brick layout (LDS-staged force kernel, 16-bit rows) ---------
 struct BrickArgs {
     const int *estart;   // [2M+1] first local index per extended code (border*M + Morton(bin))
     const int *gstart;   // [M+1]  first sorted-ghost slot per Morton(bin)
