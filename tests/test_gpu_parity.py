@@ -464,3 +464,32 @@ def test_denser_fluids_use_a_larger_halo_capacity(Meso, oracle, rho, L):
     m.run(10)
     assert np.array_equal(m.gather()[3], np.arange(1, len(x) + 1))
     m.close()
+
+
+def test_nonperiodic_dimension_static(Meso):
+    """boundary p p f: no ghosts across the z faces.  Neighbour counts against an O(N^2) count with the minimum image in x
+    and y only, and every pair force has its opposite."""
+    x, v, lo, hi = make_box(7)
+    n = len(x)
+    m = Meso()
+    m.read_atoms(x, v, lo, hi, periodicity=(1, 1, 0))
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=5, check=False)
+    m.pair_style("dpd/fast/meso", 1.0, DP_RUN["seed"])
+    m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    m.timestep(0.005)
+    m.setup()
+    count, _ = m.neigh_table()
+    tag = m.gather(by_tag=False)[3]
+    f = m.gather()[2]
+    m.close()
+    xf = x.astype(np.float32).astype(np.float64)
+    prd = hi - lo
+    ref = np.zeros(n, int)
+    for i in range(n):
+        d = xf - xf[i]
+        d[:, :2] -= np.round(d[:, :2] / prd[:2]) * prd[:2]
+        ref[i] = ((d * d).sum(1) <= 1.3 ** 2).sum() - 1
+    got = count[np.argsort(tag)]
+    assert np.abs(got - ref).max() <= 1 and (got != ref).sum() <= 8      # fp32 skin-edge ties
+    assert np.abs(f.sum(0)).max() < 1e-4 * np.abs(f).max() * np.sqrt(n)
