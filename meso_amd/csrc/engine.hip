@@ -1027,6 +1027,8 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
     for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
     int ev = (eflag || vflag) ? 1 : 0;
+    // ev_setup: the per-atom virial of the atoms in this range starts from zero (the kernel accumulates, like the forces)
+    if (ev) for (int k = 0; k < 6; k++) launch_fill_f64(virial[k] + beg, 0.0, end - beg, stream);
     p.e_pair = ev ? e_pair : nullptr;
     for (int k = 0; k < 6; k++) p.virial[k] = ev ? virial[k] : nullptr;
     p.coeff64 = d_coeff64; p.coeff32 = d_coeff32; p.ntypes = ntypes;

@@ -493,3 +493,22 @@ def test_nonperiodic_dimension_static(Meso):
     got = count[np.argsort(tag)]
     assert np.abs(got - ref).max() <= 1 and (got != ref).sum() <= 8      # fp32 skin-edge ties
     assert np.abs(f.sum(0)).max() < 1e-4 * np.abs(f).max() * np.sqrt(n)
+
+
+@pytest.mark.parametrize("style", ["dpd/fast/meso", "dpd/meso"])
+def test_thermostat_statistics_match_the_reference_cpu_run(Meso, style):
+    """Statistical parity with the thermostat on (the TEA noise can never equal the CPU's RanMars stream): the 25^3 box
+    of example/simple (62 500 atoms, here the generator's deck) after 1000 steps against the reference binary's own CPU
+    run recorded in BASELINE.md section 2: T 1.0003, PE/atom 4.347, P 26.8-27.1 (sigma = 3, a = 15, gamma = 4.5)."""
+    m, (x, v, lo, hi) = _engine(Meso, 25, style=style)
+    m.run(1000)
+    T, pe, P = [], [], []
+    for _ in range(5):
+        m.run(20)
+        m.force_clear("local")
+        m.compute(eflag=1, vflag=1)                    # tally energy and virial at the current positions
+        T.append(m.temperature()); pe.append(m.pe() / len(x)); P.append(m.pressure())
+    m.close()
+    assert np.mean(T) == pytest.approx(1.000, abs=0.01)
+    assert np.mean(pe) == pytest.approx(4.347, abs=0.02)
+    assert 26.6 < np.mean(P) < 27.3
