@@ -59,6 +59,7 @@ public:
     int halo_forward();
     int force_clear(int range);
     int pair_compute(int range, int eflag, int vflag);
+    int tally_ev();
     void launch_pair(PairArgs &p, int ev);
     bool ring_selected() const;
 

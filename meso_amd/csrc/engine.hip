@@ -1187,6 +1187,21 @@ static int host_sum(double *d, int n, hipStream_t s, double &out)
     return 0;
 }
 
+// Energy and virial of the current configuration without disturbing the stored forces (thermo output between run chunks)
+int Engine::tally_ev()
+{
+    if (!is_setup) return fail(3, "tally before setup");
+    if (ev_valid) return 0;
+    for (int d = 0; d < 3; d++)
+        HIPCHK(hipMemcpyAsync(alt.f[d], cur.f[d], (size_t)nlocal * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    TRY(force_clear(0));
+    TRY(pair_compute(0, 1, 1));
+    TRY(bond_compute(1));
+    for (int d = 0; d < 3; d++)
+        HIPCHK(hipMemcpyAsync(cur.f[d], alt.f[d], (size_t)nlocal * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
 int Engine::compute_pe(double *pe)
 {
     if (!ev_valid) {

@@ -396,6 +396,23 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
                 double spcpu = (cpu > D.cpu_prev) ? (E.ntimestep - D.step_prev) / (cpu - D.cpu_prev) : 0.0;
                 snprintf(buf, sizeof buf, "%8ld %12.8g %12.6g %12.6g", (long)E.ntimestep, T, cpu, spcpu);
                 out += buf;
+                if (D.thermo_pe || D.thermo_press) {
+                    // energy / virial tallies of the current configuration (LAMMPS tallies them inside the force evaluation
+                    // of a thermo step; here the forces are left untouched so that the trajectory does not depend on the output)
+                    if ((r2 = E.tally_ev())) return r2;
+                    if (D.thermo_pe) {
+                        double pe = 0.0, eb = 0.0;
+                        if ((r2 = E.compute_pe(&pe)) || (r2 = E.compute_ebond(&eb))) return r2;
+                        snprintf(buf, sizeof buf, " %14.10g", (pe + eb) / std::max(1, D.natoms));     // thermo_modify norm yes (lj)
+                        out += buf;
+                    }
+                    if (D.thermo_press) {
+                        double pr = 0.0;
+                        if ((r2 = E.compute_pressure(&pr))) return r2;
+                        snprintf(buf, sizeof buf, " %14.10g", pr);
+                        out += buf;
+                    }
+                }
                 D.cpu_prev = cpu;
                 D.step_prev = E.ntimestep;
                 out += "\n";

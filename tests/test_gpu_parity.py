@@ -512,3 +512,38 @@ def test_thermostat_statistics_match_the_reference_cpu_run(Meso, style):
     assert np.mean(T) == pytest.approx(1.000, abs=0.01)
     assert np.mean(pe) == pytest.approx(4.347, abs=0.02)
     assert 26.6 < np.mean(P) < 27.3
+
+
+def test_script_thermo_pe_and_press_over_several_outputs(Meso, tmp_path):
+    """thermo_style custom step temp pe press with several thermo outputs in one run: every output tallies energy and
+    virial afresh (a per-atom virial that kept accumulating made the pressure grow from line to line)."""
+    from meso_amd.datagen import make_positions, write_data
+    L = 10
+    write_data(str(tmp_path / "10.data"), make_positions(L), np.zeros(3), np.full(3, float(L)))
+    deck = """dimension       3
+units           lj
+atom_style      dpd/atomic/meso
+neighbor        0.3 bin
+neigh_modify    delay 0 every 5 check no
+read_data       %s
+run_style       mvv/meso
+pair_style      dpd/fast/meso 1.0 419084618
+pair_coeff      1 1 15 4.5 3.0 1.0 1.0
+compute         mythermo all temp/meso
+velocity        all create 1.0 788662042 loop all
+fix             3 all nve/meso
+thermo_style    custom step temp cpu spcpu pe press
+thermo          100
+thermo_modify   temp mythermo
+timestep        0.005
+run             600
+""" % (tmp_path / "10.data")
+    p = tmp_path / "t.run"
+    p.write_text(deck)
+    with Meso() as m:
+        log = m.script(str(p))
+    rows = [ln.split() for ln in log.splitlines() if len(ln.split()) == 6 and ln.split()[0].isdigit()]   # step T cpu s/cpu pe press
+    assert [int(r[0]) for r in rows] == [0, 100, 200, 300, 400, 500, 600]
+    pe = np.array([float(r[4]) for r in rows]); pr = np.array([float(r[5]) for r in rows])
+    assert pe[0] == pytest.approx(5.63, abs=0.08) and np.all(np.abs(pe[3:] - 4.35) < 0.08)     # BASELINE.md: 5.628 -> 4.347
+    assert np.all((pr[3:] > 26.0) & (pr[3:] < 28.0))
