@@ -547,3 +547,32 @@ run             600
     pe = np.array([float(r[4]) for r in rows]); pr = np.array([float(r[5]) for r in rows])
     assert pe[0] == pytest.approx(5.63, abs=0.08) and np.all(np.abs(pe[3:] - 4.35) < 0.08)     # 5.628 -> 4.347
     assert np.all((pr[3:] > 26.0) & (pr[3:] < 28.0))
+
+
+@pytest.mark.parametrize("style,tol", [("dpd/fast/meso", 3e-5), ("dpd/meso", 1e-9)])
+def test_option_matrix_sigma0_trajectories(Meso, style, tol):
+    """Every combination of layout x force kernel x list builder x fusion switches (and, for the ring kernel, Newton
+    pairing / epilogue on and off) integrates the same sigma = 0 trajectory as the defaults (12 steps, 3 rebuilds)."""
+    import itertools
+    x, v, lo, hi = make_box(9)
+    prd = hi - lo
+
+    def run(opts):
+        m = Meso()
+        for k, val in opts.items():
+            m.set_option(k, val)
+        m.read_atoms(x, v, lo, hi); m.neighbor(0.3); m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style(style, 1.0, DP_RUN["seed"]); m.pair_coeff(1, 1, 15.0, 4.5, 0.0, 1.0, 1.0); m.timestep(0.005)
+        m.setup(); m.run(12)
+        out = m.gather()
+        m.close()
+        return out
+
+    ref = run({})
+    for layout, pk, nk, fs, fp, sh in itertools.product((0, 1, 2), (0, 1, 2, 3, 4, 5), (0, 1), (0, 1), (0, 1), (0, 1)):
+        if (fp, sh) != (1, 1) and (layout, pk) not in ((2, 2), (2, 5)):
+            continue                                               # switches that only the ring kernel reads
+        out = run({"layout": layout, "pair_kernel": pk, "neigh_kernel": nk, "fuse_step": fs, "fuse_pair": fp, "pair_share": sh})
+        d = out[0] - ref[0]
+        d -= np.round(d / prd) * prd
+        assert np.abs(d).max() < tol and np.abs(out[1] - ref[1]).max() < 50 * tol, (layout, pk, nk, fs, fp, sh)
