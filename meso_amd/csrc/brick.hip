@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const 
 template <bool EXCL>
 __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
                                                               int n_col, int *__restrict__ count, int *__restrict__ table,
-                                                              int *__restrict__ overflow, ExclArgs ex, int dbg)
+                                                              int *__restrict__ overflow, ExclArgs ex, int split, int dbg)
 {
 #pragma clang fp contract(fast)
     // staged neighbourhood, SoA (candidate reads are consecutive slots); sized at launch for g.maxh halo atoms, so denser
@@ -251,8 +251,11 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     __shared__ int hoff[BRK_NHB + 1];
     __shared__ int hloc[BRK_NHB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int slot = brick_slot(g);
-    if (slot < 0) return;
+    // few bricks (small boxes, sub-boxes of many ranks): `split` workgroups share one brick, each staging the neighbourhood
+    // and taking every split-th group of own bins - a brick then finishes sooner, which is what the launch waits for
+    const int part = (int)blockIdx.x % split;
+    const int slot = (int)blockIdx.x / split;
+    if (slot >= g.nactive) return;
     const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
     const int nh = hdr[0];
     if (hdr[2] + hdr[4] == 0) return;
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     auto myrow = [&](int t) { return myrow0 + t * n_col; };
     if (dbg == 1) return;        // timing ablation: staging only
 
-    for (int k = w; k < BRK_CODES; k += BRK_WAVES) {
+    for (int k = w + BRK_WAVES * part; k < BRK_CODES; k += BRK_WAVES * split) {
         const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
                   kz = ((k >> 2) & 1) | (((k >> 5) & 1) << 1);
         const int hb = (kx + 1) + BRK_H * ((ky + 1) + BRK_H * (kz + 1));
@@ -704,6 +707,10 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
                        const ExclArgs *excl, int dbg, hipStream_t s)
 {
     if (g.nactive <= 0) return;
+    // enough workgroups to occupy the card three deep (identity brick list: about half of the bricks own atoms)
+    int split = 1;
+    while (split < 4 && g.nactive * split < 2 * 3 * 256) split *= 2;
+    const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
     ExclArgs ex = {nullptr, nullptr, nullptr, 0};
     const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2;
     if (dyn > 48 * 1024) {
@@ -712,11 +719,11 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     }
     if (excl && excl->tagc) {
         ex = *excl;
-        hipLaunchKernelGGL((k_tile_build<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
-                           overflow, ex, dbg);
+        hipLaunchKernelGGL((k_tile_build<true>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
+                           overflow, ex, split, dbg);
     } else {
-        hipLaunchKernelGGL((k_tile_build<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
-                           overflow, ex, dbg);
+        hipLaunchKernelGGL((k_tile_build<false>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
+                           overflow, ex, split, dbg);
     }
 }
 int tile_build_rowcap() { return TB_ROWCAP_MAX; }
