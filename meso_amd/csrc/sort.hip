@@ -7,12 +7,17 @@
 
 namespace meso {
 
+// rocPRIM routes up to 1 048 576 items through its merge sort: one block sort + two launches per merge level.  Sorting
+// 4096 items per block (default 1024) removes two levels = four of the ~6 us launches the rebuild is bound by.
+using SortConfig = rocprim::radix_sort_config<rocprim::kernel_config<512, 8>, rocprim::merge_sort_config<512, 512, 8>,
+                                              rocprim::default_config>;
+
 size_t sort_temp_bytes_u32(int n)
 {
     size_t bytes = 0;
     rocprim::double_buffer<uint32_t> k(nullptr, nullptr);
     rocprim::double_buffer<int> v(nullptr, nullptr);
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, v, (size_t)n, 0, 32, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, k, v, (size_t)n, 0, 32, (hipStream_t)0);
     return bytes;
 }
 
@@ -21,7 +26,7 @@ size_t sort_temp_bytes_u64(int n)
     size_t bytes = 0;
     rocprim::double_buffer<unsigned long long> k(nullptr, nullptr);
     rocprim::double_buffer<int> v(nullptr, nullptr);
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, v, (size_t)n, 0, 64, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, k, v, (size_t)n, 0, 64, (hipStream_t)0);
     return bytes;
 }
 
@@ -38,7 +43,7 @@ hipError_t sort_pairs_u32(void *temp, size_t temp_bytes, uint32_t *&keys, uint32
 {
     rocprim::double_buffer<uint32_t> k(keys, keys_alt);
     rocprim::double_buffer<int> v(vals, vals_alt);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, (size_t)n, 0, (unsigned)bits, s);
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, k, v, (size_t)n, 0, (unsigned)bits, s);
     keys = k.current(); keys_alt = k.alternate();
     vals = v.current(); vals_alt = v.alternate();
     return e;
@@ -49,7 +54,7 @@ hipError_t sort_pairs_u64(void *temp, size_t temp_bytes, uint64_t *&keys, uint64
 {
     rocprim::double_buffer<unsigned long long> k((unsigned long long *)keys, (unsigned long long *)keys_alt);
     rocprim::double_buffer<int> v(vals, vals_alt);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, (size_t)n, 0, (unsigned)bits, s);
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, k, v, (size_t)n, 0, (unsigned)bits, s);
     keys = (uint64_t *)k.current(); keys_alt = (uint64_t *)k.alternate();
     vals = v.current(); vals_alt = v.alternate();
     return e;
