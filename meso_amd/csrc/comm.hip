@@ -570,7 +570,7 @@ int Engine::migrate()
     }
     // compact the stayers (their order is preserved; the reorder sort follows anyway)
     if (nstay != nlocal) {
-        launch_permute_atoms(cur, alt, sendlist + ds[13], nstay, stream);
+        launch_permute_atoms(cur, alt, sendlist + ds[13], nstay, 1, stream);
         std::swap(cur, alt);
     }
     TRY(ensure_capacity(nstay + nrecv_tot + 1));

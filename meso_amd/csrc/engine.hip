@@ -751,7 +751,7 @@ int Engine::reorder_locals()
         HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
         launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
     }
-    launch_permute_atoms(cur, alt, rval, nlocal, stream);
+    launch_permute_atoms(cur, alt, rval, nlocal, permute_forces ? 1 : 0, stream);
     std::swap(cur, alt);
     HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
@@ -1081,7 +1081,13 @@ int Engine::run(int nsteps)
         int rebuild = 0;
         TRY(decide(&rebuild));
         bool ghosts_fresh = false;
-        if (rebuild) { TRY(reneighbor()); merged = layout >= 1; ghosts_fresh = merged; }   // the rebuild merged with this step's seed
+        if (rebuild) {
+            permute_forces = false;                     // this step's force kernel overwrites them
+            int rr = reneighbor();
+            permute_forces = true;
+            if (rr) return rr;
+            merged = layout >= 1; ghosts_fresh = merged;    // the rebuild merged with this step's seed
+        }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
         // bulk/border split point, rounded down to the force kernel's 256-atom groups (Newton pairing needs whole groups);

@@ -53,7 +53,7 @@ int reorder_sub_bits(const BinGeom &g);
 void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi,
                          const int *dim_active, uint32_t *key, int *val, int n, hipStream_t s);
 void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
-void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, hipStream_t s);
+void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s);
 void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s);
 
 // ---- halo: border lists + pack (comm_meso.cu:41-186, atom_vec_dpd_atomic_meso.cu:61-244) --------------

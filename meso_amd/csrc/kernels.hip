@@ -362,7 +362,7 @@ void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int 
 }
 
 // gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
-__global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n)
+__global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n, int with_f)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
     if (i >= n) return;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
     for (int d = 0; d < 3; d++) {
         dst.x[d][i] = src.x[d][j];
         dst.v[d][i] = src.v[d][j];
-        dst.f[d][i] = src.f[d][j];
+        if (with_f) dst.f[d][i] = src.f[d][j];      // inside run() the forces are recomputed before anyone reads them
     }
     dst.tag[i] = src.tag[j];
     dst.type[i] = src.type[j];
@@ -390,9 +390,9 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
         for (int s = 0; s < src.msp; s++) dst.special[(size_t)i * src.msp + s] = src.special[(size_t)j * src.msp + s];
     }
 }
-void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, hipStream_t s)
+void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s)
 {
-    if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n);
+    if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f);
 }
 
 // gpu_permute_from2to (atom_meso.cu:310-314)
