@@ -197,6 +197,7 @@ private:
     uint32_t *brick_hmap = nullptr, *brick_own = nullptr;
     size_t brick_cap = 0;
     int brick_maxh_alloc = 0;
+    bool bulk_pending = false;      // n_bulk of the last reorder is still on its way to the host
     bool permute_forces = true;     // the reorder carries the forces along (not needed for the rebuilds inside run())
     bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
     double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)
