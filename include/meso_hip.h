@@ -89,6 +89,10 @@ int meso_special_bonds(meso_ctx *ctx, double w12, double w13, double w14);
 int meso_bonds_upload(meso_ctx *ctx, int nbonds, const int *tag_i, const int *tag_j, const int *bond_type);
 int meso_bond_style_harmonic(meso_ctx *ctx, int nbondtypes);
 int meso_bond_coeff(meso_ctx *ctx, int type, double k, double r0);
+/* BondStyle(fene/meso) bond_fene_meso.h:3, coefficients K R0 epsilon sigma (bond_fene_meso.cu:36-50; FENE + WCA, the
+ * log argument clamped at 0.1 as in gpu_bond_fene :103-109) */
+int meso_bond_style_fene(meso_ctx *ctx, int nbondtypes);
+int meso_bond_coeff_fene(meso_ctx *ctx, int type, double k, double r0, double epsilon, double sigma);
 int meso_bond_compute(meso_ctx *ctx, int eflag);          /* Bond::compute, adds to f */
 int meso_compute_ebond(meso_ctx *ctx, double *e_total);
 

@@ -118,6 +118,25 @@ void MesoHipBondHarmonic::coeff(int narg, char **arg)
   }
 }
 
+void MesoHipBondFENE::compute(int eflag, int) { MESO(meso_bond_compute(MesoHipContext::get(lmp), eflag)); }
+
+void MesoHipBondFENE::coeff(int narg, char **arg)
+{
+  if (narg != 5) error->all(FLERR, "Incorrect args for bond coefficients");
+  if (!allocated) {
+    allocated = 1;
+    memory->create(setflag, atom->nbondtypes + 1, "bond:setflag");
+    for (int i = 1; i <= atom->nbondtypes; i++) setflag[i] = 0;
+    MESO(meso_bond_style_fene(MesoHipContext::get(lmp), atom->nbondtypes));
+  }
+  int ilo, ihi;
+  force->bounds(arg[0], atom->nbondtypes, ilo, ihi);
+  for (int i = ilo; i <= ihi; i++) {
+    MESO(meso_bond_coeff_fene(MesoHipContext::get(lmp), i, atof(arg[1]), atof(arg[2]), atof(arg[3]), atof(arg[4])));
+    setflag[i] = 1;
+  }
+}
+
 /* ---------------------------------------------------------------------- fix nve/meso */
 
 MesoHipFixNVE::MesoHipFixNVE(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg)

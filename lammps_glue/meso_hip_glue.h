@@ -19,6 +19,7 @@ PairStyle(dpd/meso,MesoHipPairDPD)
 PairStyle(dpd/fast/meso,MesoHipPairDPDFast)
 #elif defined(BOND_CLASS)
 BondStyle(harmonic/meso,MesoHipBondHarmonic)
+BondStyle(fene/meso,MesoHipBondFENE)
 #elif defined(FIX_CLASS)
 FixStyle(nve/meso,MesoHipFixNVE)
 #elif defined(COMPUTE_CLASS)
@@ -76,6 +77,18 @@ class MesoHipBondHarmonic : public Bond {
   MesoHipBondHarmonic(class LAMMPS *lmp) : Bond(lmp) {}
   void compute(int, int);              /* meso_bond_compute */
   void coeff(int, char **);            /* bond_coeff type K r0 -> meso_bond_coeff */
+  double equilibrium_distance(int) { return 0.0; }
+  void write_restart(FILE *) {}
+  void read_restart(FILE *) {}
+  double single(int, double, int, int, double &) { return 0.0; }
+};
+
+/* bond_style fene/meso (replaces MesoBondFENE, bond_fene_meso.h:3): bond_coeff type K R0 epsilon sigma */
+class MesoHipBondFENE : public Bond {
+ public:
+  MesoHipBondFENE(class LAMMPS *lmp) : Bond(lmp) {}
+  void compute(int, int);              /* meso_bond_compute */
+  void coeff(int, char **);            /* -> meso_bond_coeff_fene */
   double equilibrium_distance(int) { return 0.0; }
   void write_restart(FILE *) {}
   void read_restart(FILE *) {}

@@ -42,6 +42,8 @@ SIGNATURES = {
     "meso_bonds_upload": (_i, [_vp, _i, _vp, _vp, _vp]),
     "meso_bond_style_harmonic": (_i, [_vp, _i]),
     "meso_bond_coeff": (_i, [_vp, _i, _d, _d]),
+    "meso_bond_style_fene": (_i, [_vp, _i]),
+    "meso_bond_coeff_fene": (_i, [_vp, _i, _d, _d, _d, _d]),
     "meso_bond_compute": (_i, [_vp, _i]),
     "meso_compute_ebond": (_i, [_vp, C.POINTER(_d)]),
     "meso_timestep": (_i, [_vp, _d]),

@@ -155,12 +155,24 @@ class Meso:
         self._setup_done = False
 
     def bond_style(self, style, nbondtypes):
-        if style != "harmonic/meso":
+        if style == "harmonic/meso":
+            self._ck(self.lib.meso_bond_style_harmonic(self._h, nbondtypes))
+        elif style == "fene/meso":
+            self._ck(self.lib.meso_bond_style_fene(self._h, nbondtypes))
+        else:
             raise MesoError("Unknown bond style " + style)
-        self._ck(self.lib.meso_bond_style_harmonic(self._h, nbondtypes))
+        self._bond_style = style
 
-    def bond_coeff(self, btype, k, r0):
-        self._ck(self.lib.meso_bond_coeff(self._h, btype, k, r0))
+    def bond_coeff(self, btype, k, r0, epsilon=None, sigma=None):
+        """bond_coeff type K r0 (harmonic/meso) or type K R0 epsilon sigma (fene/meso)"""
+        if getattr(self, "_bond_style", "harmonic/meso") == "fene/meso":
+            if epsilon is None or sigma is None:
+                raise MesoError("Incorrect args for bond coefficients")
+            self._ck(self.lib.meso_bond_coeff_fene(self._h, btype, k, r0, epsilon, sigma))
+        else:
+            if epsilon is not None or sigma is not None:
+                raise MesoError("Incorrect args for bond coefficients")
+            self._ck(self.lib.meso_bond_coeff(self._h, btype, k, r0))
 
     def bond_compute(self, eflag=0):
         self._ck(self.lib.meso_bond_compute(self._h, eflag))

@@ -145,6 +145,8 @@ int meso_special_bonds(meso_ctx *ctx, double w12, double w13, double w14) { CTX(
 int meso_bonds_upload(meso_ctx *ctx, int nb, const int *ti, const int *tj, const int *bt) { CTX(ctx); RET(E.bonds_upload(nb, ti, tj, bt)); }
 int meso_bond_style_harmonic(meso_ctx *ctx, int nbt) { CTX(ctx); RET(E.bond_style(nbt)); }
 int meso_bond_coeff(meso_ctx *ctx, int type, double k, double r0) { CTX(ctx); RET(E.bond_coeff(type, k, r0)); }
+int meso_bond_style_fene(meso_ctx *ctx, int nbt) { CTX(ctx); RET(E.bond_style(nbt, 1)); }
+int meso_bond_coeff_fene(meso_ctx *ctx, int type, double k, double r0, double eps, double sigma) { CTX(ctx); RET(E.bond_coeff(type, k, r0, eps, sigma)); }
 int meso_bond_compute(meso_ctx *ctx, int eflag) { CTX(ctx); RET(E.bond_compute(eflag)); }
 int meso_compute_ebond(meso_ctx *ctx, double *e) { CTX(ctx); if (!e) return set_err(MESO_ERR_ARG, "null output"); RET(E.compute_ebond(e)); }
 

@@ -41,8 +41,8 @@ public:
     int neighbor(double skin, int every, int delay, int check);
     int bonds_upload(int nbonds, const int *tag_i, const int *tag_j, const int *btype);
     int special_bonds(double w12, double w13, double w14);
-    int bond_style(int nbondtypes);
-    int bond_coeff(int type, double k, double r0);
+    int bond_style(int nbondtypes, int kind = 0);      // kind 0: harmonic/meso, 1: fene/meso
+    int bond_coeff(int type, double k, double r0, double eps = 0.0, double sigma = 0.0);
     int bond_compute(int eflag);
     int compute_ebond(double *e);
     int pair_settings(int style, double cut, int seed);
@@ -224,9 +224,9 @@ private:
     int nsend = 0;
 
     // bonded topology
-    int bpa = 0, msp = 0, nbondtypes = 0, maxtag = 0;
+    int bpa = 0, msp = 0, nbondtypes = 0, maxtag = 0, bond_kind = 0;
     double special_w[3] = {0.0, 0.0, 0.0};
-    std::vector<double> bond_kr0;            // [k(0..nbt)][r0(0..nbt)]
+    std::vector<double> bond_kr0;            // [k(0..nbt)][r0(0..nbt)][epsilon][sigma]
     std::vector<int> h_tags;                 // tags of the atoms kept at upload (topology is attached by tag)
     double *d_bond_kr0 = nullptr, *e_bond = nullptr;
     int *bond_idx = nullptr, *tagmap = nullptr, *tagc = nullptr;

@@ -364,21 +364,27 @@ int Engine::special_bonds(double w12, double w13, double w14)
     return 0;
 }
 
-int Engine::bond_style(int nbt)
+int Engine::bond_style(int nbt, int kind)
 {
     if (nbt < 1) return fail(1, "Illegal bond_style command");
+    if (kind != 0 && kind != 1) return fail(1, "Invalid bond style");
     nbondtypes = nbt;
-    bond_kr0.assign(2 * (size_t)(nbt + 1), 0.0);
+    bond_kind = kind;
+    bond_kr0.assign(4 * (size_t)(nbt + 1), 0.0);
+    dfree(d_bond_kr0);
     return 0;
 }
 
 // BondHarmonic::coeff (src/MOLECULE/bond_harmonic.cpp): bond_coeff type K r0
-int Engine::bond_coeff(int type, double k, double r0)
+// BondFENE::coeff (src/MOLECULE/bond_fene.cpp:143-167, bond_fene_meso.cu:36-50): bond_coeff type K R0 epsilon sigma
+int Engine::bond_coeff(int type, double k, double r0, double eps, double sigma)
 {
     if (nbondtypes == 0) return fail(3, "bond_coeff before bond_style");
     if (type < 1 || type > nbondtypes) return fail(1, "Incorrect args for bond coefficients");
     bond_kr0[type] = k;
     bond_kr0[nbondtypes + 1 + type] = r0;
+    bond_kr0[2 * (nbondtypes + 1) + type] = eps;
+    bond_kr0[3 * (nbondtypes + 1) + type] = sigma;
     dfree(d_bond_kr0);
     return 0;
 }
@@ -461,7 +467,7 @@ int Engine::rebuild_topology()
     return 0;
 }
 
-// BondHarmonic::compute / gpu_bond_harmonic (bond_harmonic_meso.cu:46-117)
+// BondHarmonic::compute / gpu_bond_harmonic (bond_harmonic_meso.cu:46-117), MesoBondFENE::compute (bond_fene_meso.cu:150-214)
 int Engine::bond_compute(int eflag)
 {
     if (!have_bonds || nbondtypes == 0) return 0;
@@ -470,8 +476,8 @@ int Engine::bond_compute(int eflag)
         HIPCHK(hipMemcpy(d_bond_kr0, bond_kr0.data(), bond_kr0.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     tbegin("bond");
-    launch_bond_harmonic(coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, cur.f[0],
-                         cur.f[1], cur.f[2], eflag ? e_bond : nullptr, stream);
+    launch_bond(bond_kind, coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, cur.f[0], cur.f[1],
+                cur.f[2], eflag ? e_bond : nullptr, stream);
     tend("bond");
     return 0;
 }
@@ -480,8 +486,8 @@ int Engine::compute_ebond(double *e)
 {
     if (!have_bonds || nbondtypes == 0 || !is_setup || !d_bond_kr0) { *e = 0.0; return 0; }
     // energy at the coordinates of the last force evaluation (what thermo prints on an eflag step, src/thermo.cpp ebond)
-    launch_bond_harmonic(coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, nullptr, nullptr,
-                         nullptr, e_bond, stream);
+    launch_bond(bond_kind, coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, nullptr, nullptr,
+                nullptr, e_bond, stream);
     std::vector<double> h((size_t)nlocal);
     HIPCHK(hipMemcpyAsync(h.data(), e_bond, nlocal * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -1018,7 +1024,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     if (!cell_ring) p.fuse_nve = 0;              // only the ring kernel has the epilogue
     p.nall = nlocal + nghost;
     p.all_expw_one = 1;
-    p.share = (pair_share && (p.end == nlocal || (p.end & 255) == 0)) ? 1 : 0;
+    p.share = (pair_share && (p.end == nlocal || (p.end & (pair_ring_group() - 1)) == 0)) ? 1 : 0;
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
     const bool cell = layout == 2;
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
@@ -1105,7 +1111,7 @@ int Engine::run(int nsteps)
         if (!merged) TRY(merge_locals(sd));
         // bulk/border split point, rounded down to the force kernel's 256-atom groups (Newton pairing needs whole groups);
         // the few bulk atoms behind it simply wait for the ghosts too
-        const int n_split = n_bulk & ~255;
+        const int n_split = n_bulk & ~(pair_ring_group() - 1);
         const bool split = nranks > 1 && overlap && n_split > 0 && n_split < nlocal;
         if (!ghosts_fresh) TRY(halo_forward_seed(sd, split));
         PairArgs p;

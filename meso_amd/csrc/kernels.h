@@ -137,6 +137,7 @@ void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
 void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s);
 // fp32 style on chunked-8 rows: light cutoff scan per lane, hits compacted into a per-wave LDS ring of 4-byte
 // records, heavy phase on full waves with the partner data re-gathered through buffer loads (pair_ring.hip)
+int pair_ring_group();   // atoms per workgroup of the ring kernel (alignment of paired launches)
 void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s);
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
 void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
@@ -197,9 +198,10 @@ void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, i
 void launch_set_map(const int *tagc, int nall, int maxtag, int *map, hipStream_t s);
 void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int *map, int maxtag, int nlocal,
                       int *bond_idx, int *missing, hipStream_t s);
-void launch_bond_harmonic(const float4 *coord4, const int *nbond, const int *bond_idx, const int *bond_type, int bpa,
-                          const double *kr0, int nbt, const double *prd, int nlocal, double *fx, double *fy,
-                          double *fz, double *e_bond, hipStream_t s);
+// style 0: harmonic, cf = [k][r0]; style 1: FENE, cf = [k][r0][epsilon][sigma] (each nbt + 1 long)
+void launch_bond(int style, const float4 *coord4, const int *nbond, const int *bond_idx, const int *bond_type, int bpa,
+                 const double *cf, int nbt, const double *prd, int nlocal, double *fx, double *fy, double *fz, double *e_bond,
+                 hipStream_t s);
 struct ExclArgs {            // special-partner filter of the list builder (null tagc: no exclusions)
     const int *tagc, *nspecial, *special;
     int msp;

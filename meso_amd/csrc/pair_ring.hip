@@ -33,7 +33,10 @@
 
 namespace meso {
 
+#ifndef RG_WAVES
 #define RG_WAVES 4
+#endif
+#define RG_GROUP (64 * RG_WAVES)      // atoms of a workgroup = Newton-pairing group
 #define RG_RING 256                 // records per wave; a drain check every 2 slots keeps the fill below 64 + 128
 #define RG_OWNER_SHIFT 26
 #define RG_SHARED_BIT 0x02000000u   // record: evaluate once, add to owner and partner
@@ -51,7 +54,7 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 // FAST: dpd/fast/meso (fp32 arithmetic, contracted); otherwise dpd/meso (fp64 arithmetic on the fp32 operands through the
 // uncontracted functions of meso_device.h, 36-fractional-bit fixed-point sums)
 template <bool FAST, bool NT1, bool EW1, bool SHARE>
-__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? 5 : 2) k_pair_dpd_ring(PairArgs a)
+__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
     extern __shared__ double smem[];
@@ -192,10 +195,10 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? 5 : 2) k_pair_dpd_ring(P
             usem[q] = actm;
             if (SHARE) {
                 // (lane masks from the same compares through the icmp builtins: 36 = ULT)
-                usem[q] = actm & ~(__builtin_amdgcn_uicmp((u32)j[q] ^ (u32)i, 256u, 36) & __builtin_amdgcn_uicmp((u32)j[q], (u32)i, 36));
+                usem[q] = actm & ~(__builtin_amdgcn_uicmp((u32)j[q] ^ (u32)i, (u32)RG_GROUP, 36) & __builtin_amdgcn_uicmp((u32)j[q], (u32)i, 36));
                 // same aligned 256-group: lower partner index = mirrored entry, not looked at; higher (and one of this
                 // launch's atoms) = evaluated once for both
-                const bool same = ((u32)j[q] ^ (u32)i) < 256u;
+                const bool same = ((u32)j[q] ^ (u32)i) < (u32)RG_GROUP;
                 use[q] = active & !(same & ((u32)j[q] < (u32)i));
                 shb[q] = same & ((u32)j[q] > (u32)i) & ((u32)j[q] < (u32)a.end);
             }
@@ -260,7 +263,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     if (nt1) ew1 = p.cf1[P_EXPW] == 1.0;
     else ew1 = p.all_expw_one != 0;
     // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom
-    const bool share = p.share != 0 && (p.beg & 255) == 0;
+    const bool share = p.share != 0 && (p.beg & (RG_GROUP - 1)) == 0;
 #define RG_LAUNCH(F, A, B, C) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C>), grid, block, sm, s, p)
 #define RG_PICK(F)                                        \
     if (share) {                                          \
@@ -278,5 +281,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
 #undef RG_PICK
 #undef RG_LAUNCH
 }
+
+int pair_ring_group() { return RG_GROUP; }
 
 } // namespace meso

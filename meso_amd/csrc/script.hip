@@ -66,6 +66,7 @@ struct Deck {
     std::vector<double> x, v, mass;
     std::vector<int> tag, type;
     int nbonds = 0, nbondtypes = 0;
+    bool bond_fene = false;
     std::vector<int> bond_i, bond_j, bond_t;
     bool bonds_sent = false;
     bool have_atoms = false, uploaded = false, is_setup = false;
@@ -337,11 +338,14 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
             if (w.size() != 5 || w[1] != "lj") { E.err = "Illegal special_bonds command"; return 1; }
             if ((rc = E.special_bonds(atof(w[2].c_str()), atof(w[3].c_str()), atof(w[4].c_str())))) return rc;
         } else if (c == "bond_style") {
-            if (w.size() != 2 || w[1] != "harmonic/meso") { E.err = "Invalid bond style"; return 1; }
-            if ((rc = E.bond_style(std::max(D.nbondtypes, 1)))) return rc;
+            if (w.size() != 2 || (w[1] != "harmonic/meso" && w[1] != "fene/meso")) { E.err = "Invalid bond style"; return 1; }
+            D.bond_fene = w[1] == "fene/meso";
+            if ((rc = E.bond_style(std::max(D.nbondtypes, 1), D.bond_fene ? 1 : 0))) return rc;
         } else if (c == "bond_coeff") {
-            if (w.size() != 4) { E.err = "Incorrect args for bond coefficients"; return 1; }
-            if ((rc = E.bond_coeff(atoi(w[1].c_str()), atof(w[2].c_str()), atof(w[3].c_str())))) return rc;
+            if (w.size() != (D.bond_fene ? 6u : 4u)) { E.err = "Incorrect args for bond coefficients"; return 1; }
+            if ((rc = E.bond_coeff(atoi(w[1].c_str()), atof(w[2].c_str()), atof(w[3].c_str()), D.bond_fene ? atof(w[4].c_str()) : 0.0,
+                                   D.bond_fene ? atof(w[5].c_str()) : 0.0)))
+                return rc;
         } else if (c == "compute") {
             if (w.size() < 4 || w[2] != "all") { E.err = "Illegal compute command"; return 1; }
             if (w[3] != "temp/meso" && w[3] != "pe/meso" && w[3] != "pressure/meso") { E.err = "Invalid compute style " + w[3]; return 1; }

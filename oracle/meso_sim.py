@@ -61,10 +61,13 @@ class MesoRefSim:
     def pair_coeff(self, i, j, a0, gamma, sigma, expw=1.0, cut=1.0):
         self.coeffs[(min(i, j), max(i, j))] = (a0, gamma, sigma, expw, cut)
 
-    def set_bonds(self, bonds, coeffs, special=(0.0, 0.0, 0.0)):
-        """bonds (nb,3: tag_i, tag_j, type); coeffs {type: (k, r0)}; special_bonds weights (0 = level excluded
-        from the pair rows, gpu_filter_exclusion neigh_build_meso.cu:497-569).  Bond force: gpu_bond_harmonic
-        bond_harmonic_meso.cu:84-101 == BondHarmonic::compute src/MOLECULE/bond_harmonic.cpp:44-96."""
+    def set_bonds(self, bonds, coeffs, special=(0.0, 0.0, 0.0), style="harmonic"):
+        """bonds (nb,3: tag_i, tag_j, type); coeffs {type: (k, r0)} (harmonic) or {type: (K, R0, epsilon, sigma)}
+        (fene); special_bonds weights (0 = level excluded from the pair rows, gpu_filter_exclusion
+        neigh_build_meso.cu:497-569).  Bond force: gpu_bond_harmonic bond_harmonic_meso.cu:84-101 == BondHarmonic::compute
+        src/MOLECULE/bond_harmonic.cpp:44-96; gpu_bond_fene bond_fene_meso.cu:82-147 (BondFENE::compute
+        src/MOLECULE/bond_fene.cpp:48-124 with the log argument clamped at 0.1)."""
+        self.bond_style = style
         self.bonds = np.asarray(bonds, np.int64).reshape(-1, 3)
         self.bond_coeffs = coeffs
         adj = {}
@@ -111,6 +114,24 @@ class MesoRefSim:
         bt = np.concatenate([self.bonds[:, 2], self.bonds[:, 2]])
         k = np.array([self.bond_coeffs[int(t)][0] for t in bt])
         r0 = np.array([self.bond_coeffs[int(t)][1] for t in bt])
+        if getattr(self, "bond_style", "harmonic") == "fene":
+            eps = np.array([self.bond_coeffs[int(t)][2] for t in bt])
+            sig = np.array([self.bond_coeffs[int(t)][3] for t in bt])
+            d = c[i] - c[j]                                                            # bond_fene_meso.cu:95-98: i - j
+            d = d + np.where(d > -0.5 * prd, np.where(d < 0.5 * prd, 0.0, -prd), prd)
+            rsq = (d * d).sum(1)
+            r0sq = r0 * r0
+            rlogarg = np.maximum(0.1, 1.0 - rsq / r0sq)                                # :103-109
+            fb = -k / rlogarg
+            e = -0.5 * k * r0sq * np.log(rlogarg)
+            wca = rsq < 1.25992104989487316477 * sig * sig                             # :116
+            sr2 = sig * sig / rsq
+            sr6 = sr2 * sr2 * sr2
+            fb = fb + np.where(wca, 48.0 * eps * sr6 * (sr6 - 0.5) / rsq, 0.0)
+            e = e + np.where(wca, 4.0 * eps * sr6 * (sr6 - 1.0) + eps, 0.0)
+            np.add.at(self.f, i, d * fb[:, None])
+            self.e_bond = float(0.5 * e.sum())                                         # each bond stored twice, e * 0.5 (:145)
+            return
         d = c[j] - c[i]
         d = d + np.where(d > -0.5 * prd, np.where(d < 0.5 * prd, 0.0, -prd), prd)     # minimum_image math_meso.h:148-152
         rsq = (d * d).sum(1)

@@ -12,12 +12,18 @@ pytestmark = pytest.mark.gpu
 A = {(1, 1): 15.0, (2, 2): 15.0, (1, 2): 40.0}
 
 
-def _setup(m, x, v, types, bonds, lo, hi, style="dpd/meso", sigma=3.0, special=(0.0, 0.0, 0.0)):
+FENE = (40.0, 1.2, 0.5, 0.4)       # K R0 epsilon sigma: WCA core below 0.45, bonds start near 0.5
+
+
+def _setup(m, x, v, types, bonds, lo, hi, style="dpd/meso", sigma=3.0, special=(0.0, 0.0, 0.0), bond="harmonic"):
     m.read_atoms(x, v, lo, hi, types=types, ntypes=2)
     m.special_bonds(*special)
     m.read_bonds(bonds)
-    m.bond_style("harmonic/meso", 1)
-    m.bond_coeff(1, 50.0, 0.5)
+    m.bond_style(bond + "/meso", 1)
+    if bond == "fene":
+        m.bond_coeff(1, *FENE)
+    else:
+        m.bond_coeff(1, 50.0, 0.5)
     m.neighbor(0.3)
     m.neigh_modify(delay=0, every=5, check=False)
     m.pair_style(style, 1.0, 419084618)
@@ -27,12 +33,12 @@ def _setup(m, x, v, types, bonds, lo, hi, style="dpd/meso", sigma=3.0, special=(
     m.setup()
 
 
-def _oracle(x, v, types, bonds, lo, hi, sigma=3.0, special=(0.0, 0.0, 0.0), fast=False):
+def _oracle(x, v, types, bonds, lo, hi, sigma=3.0, special=(0.0, 0.0, 0.0), fast=False, bond="harmonic"):
     from oracle.meso_sim import MesoRefSim
     s = MesoRefSim(x, v, lo, hi, types=types, ntypes=2, fast=fast)
     for (i, j), a in A.items():
         s.pair_coeff(i, j, a, 4.5, sigma, 1.0, 1.0)
-    s.set_bonds(bonds, {1: (50.0, 0.5)}, special)
+    s.set_bonds(bonds, {1: FENE if bond == "fene" else (50.0, 0.5)}, special, style=bond)
     s.setup()
     return s
 
@@ -53,6 +59,45 @@ def test_forces_rows_and_bond_energy(oracle, special):
         assert m.ebond() == pytest.approx(s.e_bond, rel=1e-10)
     if special == (1.0, 1.0, 1.0):
         assert s.count.sum() > _oracle(x, v, types, bonds, lo, hi).count.sum()
+
+
+@pytest.mark.parametrize("special", [(0.0, 0.0, 0.0), (1.0, 1.0, 1.0)])
+def test_fene_forces_and_bond_energy(oracle, special):
+    """bond_style fene/meso (bond_fene_meso.cu:82-147): forces, rows and bond energy against the oracle; some bonds are
+    pushed into the WCA core and one beyond the clamp of the log argument"""
+    from meso_amd.api import Meso
+    x, v, types, bonds, lo, hi = make_polymer_box(8, frac=0.3)
+    x = x.copy()
+    a, b = int(bonds[0][0]) - 1, int(bonds[0][1]) - 1
+    x[b] = x[a] + np.array([1.17, 0.0, 0.0])          # 1 - r^2/R0^2 = 0.049 < 0.1: clamped
+    a, b = int(bonds[5][0]) - 1, int(bonds[5][1]) - 1
+    x[b] = x[a] + np.array([0.0, 0.41, 0.0])          # inside the WCA core
+    x = lo + np.mod(x - lo, hi - lo)
+    s = _oracle(x, v, types, bonds, lo, hi, special=special, bond="fene")
+    with Meso() as m:
+        _setup(m, x, v, types, bonds, lo, hi, special=special, bond="fene")
+        fg = m.gather()[2]
+        assert np.abs(fg - s.f).max() < 1e-9 * np.abs(s.f).max()
+        assert m.ebond() == pytest.approx(s.e_bond, rel=1e-10)
+        with pytest.raises(Exception):
+            m.bond_coeff(1, 40.0, 1.2)                 # fene needs K R0 epsilon sigma
+
+
+def test_fene_polymer_trajectory(oracle):
+    from meso_amd.api import Meso
+    x, v, types, bonds, lo, hi = make_polymer_box(7, frac=0.3)
+    s = _oracle(x, v, types, bonds, lo, hi, bond="fene")
+    with Meso() as m:
+        _setup(m, x, v, types, bonds, lo, hi, bond="fene")
+        m.run(12)
+        s.run(12)
+        xg, vg = m.gather()[:2]
+        eb = m.ebond()
+    prd = hi - lo
+    d = xg - s.x
+    d -= np.round(d / prd) * prd
+    assert np.abs(d).max() < 1e-9 and np.abs(vg - s.v).max() < 1e-7
+    assert eb == pytest.approx(s.e_bond, rel=1e-7)
 
 
 @pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-9), ("dpd/fast/meso", 5e-5)])

@@ -159,3 +159,36 @@ def test_thermostat_relaxes_temperature(oracle):
     m.run(170)
     t200 = m.temperature
     assert t30 > 1.3 and 0.95 < t200 < 1.15
+
+
+@pytest.mark.parametrize("style,coeff", [("harmonic", (50.0, 0.5)), ("fene", (40.0, 1.2, 0.5, 0.4))])
+def test_bond_forces_are_the_gradient_of_the_bond_energy(oracle, style, coeff):
+    """the bond restatements (bond_harmonic_meso.cu:84-101, bond_fene_meso.cu:82-147) pinned by their own energies:
+    F = -dE/dx by central differences, pair forces switched off"""
+    from meso_amd.datagen import make_polymer_box
+    from oracle.meso_sim import MesoRefSim
+    x, v, types, bonds, lo, hi = make_polymer_box(5, frac=0.3)
+    x = x.copy()
+    if style == "fene":
+        a, b = int(bonds[2][0]) - 1, int(bonds[2][1]) - 1
+        x[b] = x[a] + np.array([0.0, 0.42, 0.0])          # one bond inside the WCA core
+        x = lo + np.mod(x - lo, hi - lo)
+
+    def sim(xx):
+        s = MesoRefSim(xx, v * 0.0, lo, hi, types=types, ntypes=2)
+        for (i, j) in [(1, 1), (2, 2), (1, 2)]:
+            s.pair_coeff(i, j, 0.0, 0.0, 0.0, 1.0, 1.0)
+        s.set_bonds(bonds, {1: coeff}, (0.0, 0.0, 0.0), style=style)
+        s.setup()
+        return s
+
+    s0 = sim(x)
+    bonded = sorted({int(t) - 1 for t in bonds[:4, :2].ravel()})
+    h = 1e-4            # coordinates pass through fp32 (merged float4): the step must stay well above 1e-7
+    for i in bonded[:4]:
+        for d in range(3):
+            xp, xm = x.copy(), x.copy()
+            xp[i, d] += h
+            xm[i, d] -= h
+            num = -(sim(xp).e_bond - sim(xm).e_bond) / (2 * h)
+            assert num == pytest.approx(s0.f[i, d], rel=2e-3, abs=2e-3)
