@@ -95,6 +95,15 @@ int meso_bond_style_fene(meso_ctx *ctx, int nbondtypes);
 int meso_bond_coeff_fene(meso_ctx *ctx, int type, double k, double r0, double epsilon, double sigma);
 int meso_bond_compute(meso_ctx *ctx, int eflag);          /* Bond::compute, adds to f */
 int meso_compute_ebond(meso_ctx *ctx, double *e_total);
+/* AtomStyle(dpd/angle/meso) atom_vec_dpd_angle_meso.h:3, AngleStyle(harmonic/meso) angle_harmonic_meso.h:3 (kernel
+ * angle_harmonic_meso.cu:46-172, tag mapping neighbor_meso.cu:161-182).  The Angles section (tag1, apex tag2, tag3, type)
+ * follows the Bonds section; angle_coeff type K theta0[degrees] as in src/MOLECULE/angle_harmonic.cpp:157-181.
+ * meso_run / meso_setup evaluate bonds and angles themselves; meso_angle_compute is Angle::compute for a host-driven step. */
+int meso_angles_upload(meso_ctx *ctx, int nangles, const int *tag1, const int *tag2, const int *tag3, const int *angle_type);
+int meso_angle_style_harmonic(meso_ctx *ctx, int nangletypes);
+int meso_angle_coeff(meso_ctx *ctx, int type, double k, double theta0_degrees);
+int meso_angle_compute(meso_ctx *ctx, int eflag);
+int meso_compute_eangle(meso_ctx *ctx, double *e_total);
 
 /* ---- timestep, fix nve/meso group */
 int meso_timestep(meso_ctx *ctx, double dt);

@@ -137,6 +137,27 @@ void MesoHipBondFENE::coeff(int narg, char **arg)
   }
 }
 
+/* ---------------------------------------------------------------------- angle_style harmonic/meso */
+
+void MesoHipAngleHarmonic::compute(int eflag, int) { MESO(meso_angle_compute(MesoHipContext::get(lmp), eflag)); }
+
+void MesoHipAngleHarmonic::coeff(int narg, char **arg)
+{
+  if (narg != 3) error->all(FLERR, "Incorrect args for angle coefficients");
+  if (!allocated) {
+    allocated = 1;
+    memory->create(setflag, atom->nangletypes + 1, "angle:setflag");
+    for (int i = 1; i <= atom->nangletypes; i++) setflag[i] = 0;
+    MESO(meso_angle_style_harmonic(MesoHipContext::get(lmp), atom->nangletypes));
+  }
+  int ilo, ihi;
+  force->bounds(arg[0], atom->nangletypes, ilo, ihi);
+  for (int i = ilo; i <= ihi; i++) {
+    MESO(meso_angle_coeff(MesoHipContext::get(lmp), i, atof(arg[1]), atof(arg[2])));
+    setflag[i] = 1;
+  }
+}
+
 /* ---------------------------------------------------------------------- fix nve/meso */
 
 MesoHipFixNVE::MesoHipFixNVE(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg)
@@ -203,6 +224,21 @@ void MesoHipIntegrate::upload()
     MESO(meso_special_bonds(c, force->special_lj[1], force->special_lj[2], force->special_lj[3]));
     MESO(meso_bonds_upload(c, m, ti, tj, bt));
     delete [] ti; delete [] tj; delete [] bt;
+    if (atom->angle_per_atom > 0) {
+      /* each angle once: the copy stored on its apex atom (with newton_bond off all three atoms store it) */
+      int na = 0;
+      for (int i = 0; i < atom->nlocal; i++) na += atom->num_angle[i];
+      int *a1 = new int[na + 1], *a2 = new int[na + 1], *a3 = new int[na + 1], *at = new int[na + 1];
+      int q = 0;
+      for (int i = 0; i < atom->nlocal; i++)
+        for (int a = 0; a < atom->num_angle[i]; a++)
+          if (atom->tag[i] == atom->angle_atom2[i][a]) {
+            a1[q] = atom->angle_atom1[i][a]; a2[q] = atom->angle_atom2[i][a]; a3[q] = atom->angle_atom3[i][a];
+            at[q] = atom->angle_type[i][a]; q++;
+          }
+      MESO(meso_angles_upload(c, q, a1, a2, a3, at));
+      delete [] a1; delete [] a2; delete [] a3; delete [] at;
+    }
   }
 }
 

@@ -20,6 +20,8 @@ PairStyle(dpd/fast/meso,MesoHipPairDPDFast)
 #elif defined(BOND_CLASS)
 BondStyle(harmonic/meso,MesoHipBondHarmonic)
 BondStyle(fene/meso,MesoHipBondFENE)
+#elif defined(ANGLE_CLASS)
+AngleStyle(harmonic/meso,MesoHipAngleHarmonic)
 #elif defined(FIX_CLASS)
 FixStyle(nve/meso,MesoHipFixNVE)
 #elif defined(COMPUTE_CLASS)
@@ -32,6 +34,7 @@ IntegrateStyle(verlet/meso,MesoHipIntegrate)
 #ifndef LMP_MESO_HIP_GLUE_H
 #define LMP_MESO_HIP_GLUE_H
 
+#include "angle.h"
 #include "bond.h"
 #include "compute.h"
 #include "fix.h"
@@ -93,6 +96,19 @@ class MesoHipBondFENE : public Bond {
   void write_restart(FILE *) {}
   void read_restart(FILE *) {}
   double single(int, double, int, int, double &) { return 0.0; }
+};
+
+/* angle_style harmonic/meso (replaces MesoAngleHarmonic, angle_harmonic_meso.h:3); the Angles section is handed over by
+   MesoHipIntegrate::upload through meso_angles_upload, after the bonds */
+class MesoHipAngleHarmonic : public Angle {
+ public:
+  MesoHipAngleHarmonic(class LAMMPS *lmp) : Angle(lmp) {}
+  void compute(int, int);              /* meso_angle_compute */
+  void coeff(int, char **);            /* angle_coeff type K theta0[degrees] -> meso_angle_coeff */
+  double equilibrium_angle(int) { return 0.0; }
+  void write_restart(FILE *) {}
+  void read_restart(FILE *) {}
+  double single(int, int, int, int) { return 0.0; }
 };
 
 class MesoHipFixNVE : public Fix {

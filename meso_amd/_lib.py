@@ -46,6 +46,11 @@ SIGNATURES = {
     "meso_bond_coeff_fene": (_i, [_vp, _i, _d, _d, _d, _d]),
     "meso_bond_compute": (_i, [_vp, _i]),
     "meso_compute_ebond": (_i, [_vp, C.POINTER(_d)]),
+    "meso_angles_upload": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "meso_angle_style_harmonic": (_i, [_vp, _i]),
+    "meso_angle_coeff": (_i, [_vp, _i, _d, _d]),
+    "meso_angle_compute": (_i, [_vp, _i]),
+    "meso_compute_eangle": (_i, [_vp, C.POINTER(_d)]),
     "meso_timestep": (_i, [_vp, _d]),
     "meso_setup": (_i, [_vp]),
     "meso_run": (_i, [_vp, _i]),

@@ -182,6 +182,29 @@ class Meso:
         self._ck(self.lib.meso_compute_ebond(self._h, C.byref(t)))
         return t.value
 
+    def read_angles(self, angles):
+        """angles: (na,4) int array of (tag1, tag2 = apex, tag3, type) - the Angles section of the data file (after read_bonds)."""
+        a = np.ascontiguousarray(angles, np.int32).reshape(-1, 4)
+        c = [np.ascontiguousarray(a[:, k]) for k in range(4)]
+        self._ck(self.lib.meso_angles_upload(self._h, len(a), _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3])))
+        self._setup_done = False
+
+    def angle_style(self, style, nangletypes):
+        if style != "harmonic/meso":
+            raise MesoError("Unknown angle style " + style)
+        self._ck(self.lib.meso_angle_style_harmonic(self._h, nangletypes))
+
+    def angle_coeff(self, atype, k, theta0_degrees):
+        self._ck(self.lib.meso_angle_coeff(self._h, atype, k, theta0_degrees))
+
+    def angle_compute(self, eflag=0):
+        self._ck(self.lib.meso_angle_compute(self._h, eflag))
+
+    def eangle(self):
+        t = C.c_double()
+        self._ck(self.lib.meso_compute_eangle(self._h, C.byref(t)))
+        return t.value
+
     def fix_nve(self):
         pass  # fix nve/meso is the only integrator fix on this path; always active
 

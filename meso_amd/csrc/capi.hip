@@ -148,6 +148,11 @@ int meso_bond_coeff(meso_ctx *ctx, int type, double k, double r0) { CTX(ctx); RE
 int meso_bond_style_fene(meso_ctx *ctx, int nbt) { CTX(ctx); RET(E.bond_style(nbt, 1)); }
 int meso_bond_coeff_fene(meso_ctx *ctx, int type, double k, double r0, double eps, double sigma) { CTX(ctx); RET(E.bond_coeff(type, k, r0, eps, sigma)); }
 int meso_bond_compute(meso_ctx *ctx, int eflag) { CTX(ctx); RET(E.bond_compute(eflag)); }
+int meso_angles_upload(meso_ctx *ctx, int na, const int *t1, const int *t2, const int *t3, const int *ty) { CTX(ctx); RET(E.angles_upload(na, t1, t2, t3, ty)); }
+int meso_angle_style_harmonic(meso_ctx *ctx, int nat) { CTX(ctx); RET(E.angle_style(nat)); }
+int meso_angle_coeff(meso_ctx *ctx, int type, double k, double theta0) { CTX(ctx); RET(E.angle_coeff(type, k, theta0)); }
+int meso_angle_compute(meso_ctx *ctx, int eflag) { CTX(ctx); RET(E.angle_compute(eflag)); }
+int meso_compute_eangle(meso_ctx *ctx, double *e) { CTX(ctx); if (!e) return set_err(MESO_ERR_ARG, "null output"); RET(E.compute_eangle(e)); }
 int meso_compute_ebond(meso_ctx *ctx, double *e) { CTX(ctx); if (!e) return set_err(MESO_ERR_ARG, "null output"); RET(E.compute_ebond(e)); }
 
 int meso_timestep(meso_ctx *ctx, double dt)

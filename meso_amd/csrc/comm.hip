@@ -305,6 +305,11 @@ __global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__re
         t[0] = a.nbond[j]; t[1] = a.nspecial[j];
         for (int b = 0; b < a.bpa; b++) { t[2 + 2 * b] = a.bond_tag[(size_t)j * a.bpa + b]; t[3 + 2 * b] = a.bond_type[(size_t)j * a.bpa + b]; }
         for (int s = 0; s < a.msp; s++) t[2 + 2 * a.bpa + s] = a.special[(size_t)j * a.msp + s];
+        if (a.apa > 0) {
+            int *u = t + 2 + 2 * a.bpa + a.msp;
+            u[0] = a.nangle[j];
+            for (int q = 0; q < 4 * a.apa; q++) u[1 + q] = a.angle_tag[(size_t)j * 4 * a.apa + q];
+        }
     }
 }
 
@@ -327,6 +332,11 @@ __global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double 
         a.nbond[i] = t[0]; a.nspecial[i] = t[1];
         for (int b = 0; b < a.bpa; b++) { a.bond_tag[(size_t)i * a.bpa + b] = t[2 + 2 * b]; a.bond_type[(size_t)i * a.bpa + b] = t[3 + 2 * b]; }
         for (int s = 0; s < a.msp; s++) a.special[(size_t)i * a.msp + s] = t[2 + 2 * a.bpa + s];
+        if (a.apa > 0) {
+            const int *u = t + 2 + 2 * a.bpa + a.msp;
+            a.nangle[i] = u[0];
+            for (int q = 0; q < 4 * a.apa; q++) a.angle_tag[(size_t)i * 4 * a.apa + q] = u[1 + q];
+        }
     }
 }
 

@@ -45,6 +45,12 @@ public:
     int bond_coeff(int type, double k, double r0, double eps = 0.0, double sigma = 0.0);
     int bond_compute(int eflag);
     int compute_ebond(double *e);
+    // Angles section + angle_style harmonic/meso (atom_style dpd/angle/meso, angle_harmonic_meso.cu)
+    int angles_upload(int na, const int *t1, const int *t2, const int *t3, const int *type);
+    int angle_style(int nangletypes);
+    int angle_coeff(int type, double k, double theta0_deg);
+    int angle_compute(int eflag);
+    int compute_eangle(double *e);
     int pair_settings(int style, double cut, int seed);
     int pair_coeff(int i, int j, double a0, double gamma, double sigma, double expw, double cut);
     int set_option(const std::string &key, double val);
@@ -225,6 +231,11 @@ private:
 
     // bonded topology
     int bpa = 0, msp = 0, nbondtypes = 0, maxtag = 0, bond_kind = 0;
+    int apa = 0, nangletypes = 0;
+    bool have_angles = false;
+    std::vector<double> angle_cf;            // [k(0..nat)][theta0 in radians]
+    double *d_angle_cf = nullptr, *e_angle = nullptr;
+    int *angle_idx = nullptr;                // [(i*apa+a)*3] mapped after every rebuild
     double special_w[3] = {0.0, 0.0, 0.0};
     std::vector<double> bond_kr0;            // [k(0..nbt)][r0(0..nbt)][epsilon][sigma]
     std::vector<int> h_tags;                 // tags of the atoms kept at upload (topology is attached by tag)
@@ -233,7 +244,7 @@ private:
     bool have_bonds = false;
     int alloc_topology(AtomSoA &a, int cap, int keep);
     int rebuild_topology();
-    int mig_stride() const { return 8 + (2 + 2 * bpa + msp + 1) / 2; }
+    int mig_stride() const { return 8 + (2 + 2 * bpa + msp + (apa > 0 ? 1 + 4 * apa : 0) + 1) / 2; }
 
     // scalars
     double *d_partial = nullptr, *d_scalar = nullptr;

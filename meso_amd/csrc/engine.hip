@@ -63,6 +63,7 @@ static void free_soa(AtomSoA &a)
     for (int d = 0; d < 3; d++) { dfree(a.x[d]); dfree(a.v[d]); dfree(a.f[d]); }
     dfree(a.tag); dfree(a.type); dfree(a.mask); dfree(a.image); dfree(a.mass);
     dfree(a.nbond); dfree(a.bond_tag); dfree(a.bond_type); dfree(a.nspecial); dfree(a.special);
+    dfree(a.nangle); dfree(a.angle_tag);
 }
 
 void Engine::free_all()
@@ -72,6 +73,7 @@ void Engine::free_all()
     dfree(coord4); dfree(veloc4); dfree(coord4_next); dfree(veloc4_next);
     for (int k = 0; k < 6; k++) dfree(virial[k]);
     dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc);
+    dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32);
     dfree(pair_count); dfree(pair_table);
     dfree(bin_id); dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(bin_start);
@@ -303,6 +305,10 @@ int Engine::alloc_atoms(int cap)
         HIPCHK(regrow(bond_idx, 0, c * (size_t)std::max(bpa, 1), stream));
         HIPCHK(regrow(tagc, 0, c, stream));
         HIPCHK(regrow(e_bond, 0, c, stream));
+        if (apa > 0) {
+            HIPCHK(regrow(angle_idx, 0, c * 3 * (size_t)apa, stream));
+            HIPCHK(regrow(e_angle, 0, c, stream));
+        }
     }
     HIPCHK(regrow(coord4, 0, c, stream)); HIPCHK(regrow(veloc4, 0, c, stream));
     HIPCHK(regrow(coord4_next, 0, c, stream)); HIPCHK(regrow(veloc4_next, 0, c, stream));
@@ -350,6 +356,11 @@ int Engine::alloc_topology(AtomSoA &a, int cap, int keep)
     HIPCHK(regrow(a.bond_type, k * std::max(bpa, 1), c * std::max(bpa, 1), stream));
     HIPCHK(regrow(a.nspecial, k, c, stream));
     HIPCHK(regrow(a.special, k * std::max(msp, 1), c * std::max(msp, 1), stream));
+    a.apa = apa;
+    if (apa > 0) {
+        HIPCHK(regrow(a.nangle, k, c, stream));
+        HIPCHK(regrow(a.angle_tag, k * 4 * apa, c * 4 * apa, stream));
+    }
     return 0;
 }
 
@@ -462,8 +473,10 @@ int Engine::rebuild_topology()
     launch_tag_cell(cur.tag, layout >= 1 ? gslot : nullptr, nlocal, nghost, tagc, stream);
     HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
     launch_set_map(tagc, nall, maxtag, tagmap, stream);
-    HIPCHK(hipMemsetAsync(d_flags + 4, 0, sizeof(int), stream));
+    // (d_flags[4] counts partners that are neither local nor ghost; it stays set until check_overflow reports it)
     launch_map_bonds(cur.nbond, cur.bond_tag, bpa, tagmap, maxtag, nlocal, bond_idx, d_flags + 4, stream);
+    if (have_angles)
+        launch_map_angles(cur.tag, cur.nangle, cur.angle_tag, apa, tagmap, maxtag, nlocal, angle_idx, d_flags + 4, stream);
     return 0;
 }
 
@@ -490,6 +503,94 @@ int Engine::compute_ebond(double *e)
                 nullptr, e_bond, stream);
     std::vector<double> h((size_t)nlocal);
     HIPCHK(hipMemcpyAsync(h.data(), e_bond, nlocal * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    double s = 0.0;
+    for (double v : h) s += v;
+    *e = reduce_global_sum(s);
+    return 0;
+}
+
+// Angles section of the data file: (tag1, tag2, tag3, type), tag2 the apex.  Like the bonds, every rank is handed the whole
+// list and keeps an angle on all three of its atoms (newton off, atom_vec_dpd_angle_meso.cu); needs the Bonds section first
+// (tag map, special lists and message layout are set up there).
+int Engine::angles_upload(int na, const int *t1, const int *t2, const int *t3, const int *ty)
+{
+    if (na < 0 || (na && (!t1 || !t2 || !t3 || !ty))) return fail(1, "Invalid angle arrays");
+    if (!have_bonds) return fail(3, "Angles must follow the Bonds section");
+    std::vector<std::vector<int>> per((size_t)maxtag + 1);
+    for (int a = 0; a < na; a++) {
+        const int t[3] = {t1[a], t2[a], t3[a]};
+        for (int c = 0; c < 3; c++)
+            if (t[c] < 1 || t[c] > maxtag) return fail(1, "Invalid atom ID in Angles section of data file");
+        if (t[0] == t[1] || t[1] == t[2] || t[0] == t[2]) return fail(1, "Invalid atom ID in Angles section of data file");
+        if (nangletypes && (ty[a] < 1 || ty[a] > nangletypes)) return fail(1, "Invalid angle type in Angles section of data file");
+        for (int c = 0; c < 3; c++) per[t[c]].push_back(a);
+    }
+    int new_apa = 0;
+    for (auto &v : per) new_apa = std::max(new_apa, (int)v.size());
+    apa = std::max(new_apa, 1);
+    TRY(alloc_atoms(std::max(nmax, 1024)));
+    const int n = nlocal;
+    std::vector<int> hn((size_t)n, 0), ht((size_t)n * 4 * apa, 0);
+    for (int i = 0; i < n; i++) {
+        auto &v = per[h_tags[i]];
+        hn[i] = (int)v.size();
+        for (size_t q = 0; q < v.size(); q++) {
+            int *o = &ht[((size_t)i * apa + q) * 4];
+            o[0] = t1[v[q]]; o[1] = t2[v[q]]; o[2] = t3[v[q]]; o[3] = ty[v[q]];
+        }
+    }
+    if (n) {
+        HIPCHK(hipMemcpy(cur.nangle, hn.data(), hn.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(cur.angle_tag, ht.data(), ht.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    have_angles = true;
+    is_setup = false;
+    return 0;
+}
+
+int Engine::angle_style(int nat)
+{
+    if (nat < 1) return fail(1, "Illegal angle_style command");
+    nangletypes = nat;
+    angle_cf.assign(2 * (size_t)(nat + 1), 0.0);
+    dfree(d_angle_cf);
+    return 0;
+}
+
+// AngleHarmonic::coeff (src/MOLECULE/angle_harmonic.cpp:157-181): angle_coeff type K theta0[degrees]
+int Engine::angle_coeff(int type, double k, double theta0_deg)
+{
+    if (nangletypes == 0) return fail(3, "angle_coeff before angle_style");
+    if (type < 1 || type > nangletypes) return fail(1, "Incorrect args for angle coefficients");
+    angle_cf[type] = k;
+    angle_cf[nangletypes + 1 + type] = theta0_deg / 180.0 * 3.14159265358979323846;
+    dfree(d_angle_cf);
+    return 0;
+}
+
+// MesoAngleHarmonic::compute (angle_harmonic_meso.cu:174-236)
+int Engine::angle_compute(int eflag)
+{
+    if (!have_angles || nangletypes == 0) return 0;
+    if (!d_angle_cf) {
+        HIPCHK(dalloc(d_angle_cf, angle_cf.size()));
+        HIPCHK(hipMemcpy(d_angle_cf, angle_cf.data(), angle_cf.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    tbegin("angle");
+    launch_angle_harmonic(coord4, cur.nangle, angle_idx, cur.angle_tag, apa, d_angle_cf, nangletypes, prd, nlocal, cur.f[0],
+                          cur.f[1], cur.f[2], eflag ? e_angle : nullptr, stream);
+    tend("angle");
+    return 0;
+}
+
+int Engine::compute_eangle(double *e)
+{
+    if (!have_angles || nangletypes == 0 || !is_setup || !d_angle_cf) { *e = 0.0; return 0; }
+    launch_angle_harmonic(coord4, cur.nangle, angle_idx, cur.angle_tag, apa, d_angle_cf, nangletypes, prd, nlocal, nullptr,
+                          nullptr, nullptr, e_angle, stream);
+    std::vector<double> h((size_t)nlocal);
+    HIPCHK(hipMemcpyAsync(h.data(), e_angle, nlocal * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     double s = 0.0;
     for (double v : h) s += v;
@@ -554,6 +655,7 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
         if (type[i] < 1 || (ntypes && type[i] > ntypes)) return fail(1, "Invalid atom type in atom arrays");
     h_tags.assign(tag, tag + n);
     have_bonds = false;
+    have_angles = false;
     nlocal = n;
     nghost = 0;
     n_bulk = 0;
@@ -941,7 +1043,10 @@ int Engine::check_overflow()
 {
     HIPCHK(hipMemcpyAsync(h_flags, d_flags, 5 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    if (have_bonds && h_flags[4]) return fail(4, "Bond atoms missing: a bonded partner is outside the ghost cutoff");
+    if (have_bonds && h_flags[4]) {
+        HIPCHK(hipMemsetAsync(d_flags + 4, 0, sizeof(int), stream));
+        return fail(4, "Bond atoms missing: a bonded (or angle) partner is outside the ghost cutoff");
+    }
     if (h_flags[0]) {
         char buf[200];
         if (h_flags[0] >= 100000)
@@ -1084,6 +1189,7 @@ int Engine::setup()
     for (int k = 0; k < 6; k++) launch_fill_f64(virial[k], 0.0, nlocal, stream);
     TRY(pair_compute(0, 1, 1));
     TRY(bond_compute(1));
+    TRY(angle_compute(1));
     TRY(check_overflow());
     is_setup = true;
     return 0;
@@ -1154,6 +1260,7 @@ int Engine::run(int nsteps)
             }
         }
         TRY(bond_compute(0));
+        TRY(angle_compute(0));
         if (boundary_in_pair) {
             if (!next_rebuild) { std::swap(coord4, coord4_next); std::swap(veloc4, veloc4_next); }
             initial_done = true;
@@ -1222,6 +1329,7 @@ int Engine::tally_ev()
     TRY(force_clear(0));
     TRY(pair_compute(0, 1, 1));
     TRY(bond_compute(1));
+    TRY(angle_compute(1));
     for (int d = 0; d < 3; d++)
         HIPCHK(hipMemcpyAsync(cur.f[d], alt.f[d], (size_t)nlocal * sizeof(double), hipMemcpyDeviceToDevice, stream));
     return 0;

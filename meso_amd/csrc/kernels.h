@@ -22,6 +22,9 @@ struct AtomSoA {
     // bonded topology, per atom (null / 0 for atom_style dpd/atomic/meso): bond_tag[i*bpa+b], special[i*msp+s]
     int *nbond, *bond_tag, *bond_type, *nspecial, *special;
     int bpa, msp;
+    // angles the atom takes part in (all three atoms store an angle, newton off): angle_tag[(i*apa+a)*4 + {t1,t2,t3,type}]
+    int *nangle, *angle_tag;
+    int apa;
 };
 
 struct HaloShift { double prd[3]; };
@@ -198,6 +201,13 @@ void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, i
 void launch_set_map(const int *tagc, int nall, int maxtag, int *map, hipStream_t s);
 void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int *map, int maxtag, int nlocal,
                       int *bond_idx, int *missing, hipStream_t s);
+// gpu_map_angle (neighbor_meso.cu:161-182): tags -> indices, the atom's own tag -> itself
+void launch_map_angles(const int *tag, const int *nangle, const int *angle_tag, int apa, const int *map, int maxtag, int nlocal,
+                       int *angle_idx, int *missing, hipStream_t s);
+// gpu_angle_harmonic (angle_harmonic_meso.cu:46-172): cf = [k][theta0 (radians)]
+void launch_angle_harmonic(const float4 *coord4, const int *nangle, const int *angle_idx, const int *angle_tag, int apa,
+                           const double *cf, int nat, const double *prd, int nlocal, double *fx, double *fy, double *fz,
+                           double *e_angle, hipStream_t s);
 // style 0: harmonic, cf = [k][r0]; style 1: FENE, cf = [k][r0][epsilon][sigma] (each nbt + 1 long)
 void launch_bond(int style, const float4 *coord4, const int *nbond, const int *bond_idx, const int *bond_type, int bpa,
                  const double *cf, int nbt, const double *prd, int nlocal, double *fx, double *fy, double *fz, double *e_bond,

@@ -385,6 +385,10 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
             dst.bond_type[(size_t)i * src.bpa + b] = src.bond_type[(size_t)j * src.bpa + b];
         }
     }
+    if (src.apa > 0) {
+        dst.nangle[i] = src.nangle[j];
+        for (int a = 0; a < 4 * src.apa; a++) dst.angle_tag[(size_t)i * 4 * src.apa + a] = src.angle_tag[(size_t)j * 4 * src.apa + a];
+    }
     if (src.msp > 0) {
         dst.nspecial[i] = src.nspecial[j];
         for (int s = 0; s < src.msp; s++) dst.special[(size_t)i * src.msp + s] = src.special[(size_t)j * src.msp + s];

@@ -68,6 +68,8 @@ struct Deck {
     int nbonds = 0, nbondtypes = 0;
     bool bond_fene = false;
     std::vector<int> bond_i, bond_j, bond_t;
+    int nangles = 0, nangletypes = 0;
+    std::vector<int> ang_1, ang_2, ang_3, ang_t;
     bool bonds_sent = false;
     bool have_atoms = false, uploaded = false, is_setup = false;
     int thermo_every = 0;
@@ -111,7 +113,9 @@ int read_data(Engine &E, Deck &D, const std::string &path)
         }
         if (w.size() == 2 && w[1] == "bonds") { D.nbonds = atoi(w[0].c_str()); continue; }
         if (w.size() == 3 && w[1] == "bond" && w[2] == "types") { D.nbondtypes = atoi(w[0].c_str()); continue; }
-        if (w.size() >= 2 && (w[1] == "angles" || w[1] == "dihedrals" || w[1] == "impropers")) continue;
+        if (w.size() == 2 && w[1] == "angles") { D.nangles = atoi(w[0].c_str()); continue; }
+        if (w.size() == 3 && w[1] == "angle" && w[2] == "types") { D.nangletypes = atoi(w[0].c_str()); continue; }
+        if (w.size() >= 2 && (w[1] == "dihedrals" || w[1] == "impropers")) continue;
         if (w.size() == 3 && w[2] == "types") continue;
         if (w[0] == "Bonds") {
             D.bond_i.resize(D.nbonds); D.bond_j.resize(D.nbonds); D.bond_t.resize(D.nbonds);
@@ -119,6 +123,15 @@ int read_data(Engine &E, Deck &D, const std::string &path)
                 long id; int t, a1, a2;
                 if (!(f >> id >> t >> a1 >> a2)) { E.err = "Unexpected end of data file"; return 1; }
                 D.bond_t[b] = t; D.bond_i[b] = a1; D.bond_j[b] = a2;
+            }
+            continue;
+        }
+        if (w[0] == "Angles") {
+            D.ang_1.resize(D.nangles); D.ang_2.resize(D.nangles); D.ang_3.resize(D.nangles); D.ang_t.resize(D.nangles);
+            for (int b = 0; b < D.nangles; b++) {
+                long id; int t, a1, a2, a3;
+                if (!(f >> id >> t >> a1 >> a2 >> a3)) { E.err = "Unexpected end of data file"; return 1; }
+                D.ang_t[b] = t; D.ang_1[b] = a1; D.ang_2[b] = a2; D.ang_3[b] = a3;
             }
             continue;
         }
@@ -130,7 +143,8 @@ int read_data(Engine &E, Deck &D, const std::string &path)
                 D.v.assign((size_t)3 * D.natoms, 0.0);
                 D.tag.resize(D.natoms);
                 D.type.resize(D.natoms);
-                const bool molecular = D.atom_style == "dpd/bond/meso" || D.atom_style == "bond";
+                const bool molecular = D.atom_style == "dpd/bond/meso" || D.atom_style == "bond" || D.atom_style == "dpd/angle/meso" ||
+                                       D.atom_style == "angle";
                 for (int i = 0; i < D.natoms; i++) {
                     long id, mol = 0; int t; double a, b, c;
                     if (molecular) { if (!(f >> id >> mol >> t >> a >> b >> c)) { E.err = "Unexpected end of data file"; return 1; } }
@@ -220,6 +234,7 @@ int upload(Engine &E, Deck &D)
     if ((rc = E.set_mass(D.ntypes, D.mass.data()))) return rc;
     if ((rc = E.atoms_upload(D.natoms, D.x.data(), D.v.data(), D.tag.data(), D.type.data(), nullptr, nullptr))) return rc;
     if (D.nbonds > 0 && (rc = E.bonds_upload(D.nbonds, D.bond_i.data(), D.bond_j.data(), D.bond_t.data()))) return rc;
+    if (D.nangles > 0 && (rc = E.angles_upload(D.nangles, D.ang_1.data(), D.ang_2.data(), D.ang_3.data(), D.ang_t.data()))) return rc;
     D.uploaded = true;
     return 0;
 }
@@ -279,7 +294,7 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
                 else { E.err = "Illegal boundary command"; return 1; }
             }
         } else if (c == "atom_style") {
-            if (w.size() < 2 || (w[1] != "dpd/atomic/meso" && w[1] != "atomic" && w[1] != "dpd/bond/meso" && w[1] != "bond")) { E.err = "Invalid atom style " + (w.size() > 1 ? w[1] : ""); return 1; }
+            if (w.size() < 2 || (w[1] != "dpd/atomic/meso" && w[1] != "atomic" && w[1] != "dpd/bond/meso" && w[1] != "bond" && w[1] != "dpd/angle/meso" && w[1] != "angle")) { E.err = "Invalid atom style " + (w.size() > 1 ? w[1] : ""); return 1; }
             D.atom_style = w[1];
         } else if (c == "variable") {
             if (w.size() >= 4 && (w[2] == "index" || w[2] == "equal" || w[2] == "string")) { if (!D.vars.count(w[1])) D.vars[w[1]] = w[3]; }
@@ -346,6 +361,12 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
             if ((rc = E.bond_coeff(atoi(w[1].c_str()), atof(w[2].c_str()), atof(w[3].c_str()), D.bond_fene ? atof(w[4].c_str()) : 0.0,
                                    D.bond_fene ? atof(w[5].c_str()) : 0.0)))
                 return rc;
+        } else if (c == "angle_style") {
+            if (w.size() != 2 || w[1] != "harmonic/meso") { E.err = "Invalid angle style"; return 1; }
+            if ((rc = E.angle_style(std::max(D.nangletypes, 1)))) return rc;
+        } else if (c == "angle_coeff") {
+            if (w.size() != 4) { E.err = "Incorrect args for angle coefficients"; return 1; }
+            if ((rc = E.angle_coeff(atoi(w[1].c_str()), atof(w[2].c_str()), atof(w[3].c_str())))) return rc;
         } else if (c == "compute") {
             if (w.size() < 4 || w[2] != "all") { E.err = "Illegal compute command"; return 1; }
             if (w[3] != "temp/meso" && w[3] != "pe/meso" && w[3] != "pressure/meso") { E.err = "Invalid compute style " + w[3]; return 1; }
@@ -405,9 +426,9 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
                     // of a thermo step; here the forces are left untouched so that the trajectory does not depend on the output)
                     if ((r2 = E.tally_ev())) return r2;
                     if (D.thermo_pe) {
-                        double pe = 0.0, eb = 0.0;
-                        if ((r2 = E.compute_pe(&pe)) || (r2 = E.compute_ebond(&eb))) return r2;
-                        snprintf(buf, sizeof buf, " %14.10g", (pe + eb) / std::max(1, D.natoms));     // thermo_modify norm yes (lj)
+                        double pe = 0.0, eb = 0.0, ea = 0.0;
+                        if ((r2 = E.compute_pe(&pe)) || (r2 = E.compute_ebond(&eb)) || (r2 = E.compute_eangle(&ea))) return r2;
+                        snprintf(buf, sizeof buf, " %14.10g", (pe + eb + ea) / std::max(1, D.natoms));     // thermo_modify norm yes (lj)
                         out += buf;
                     }
                     if (D.thermo_press) {

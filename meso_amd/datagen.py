@@ -39,10 +39,27 @@ def make_box(L: int, seed: int | None = None):
     return x, v, np.zeros(3), np.full(3, float(L))
 
 
+def chain_angles(bonds: np.ndarray, atype: int = 1) -> np.ndarray:
+    """Angles (na,4: tag1, apex, tag3, type) of linear chains: every pair of bonds that share a bead."""
+    adj = {}
+    for i, j, _ in np.asarray(bonds).reshape(-1, 3):
+        adj.setdefault(int(i), []).append(int(j))
+        adj.setdefault(int(j), []).append(int(i))
+    out = []
+    for apex in sorted(adj):
+        nb = sorted(adj[apex])
+        for a in range(len(nb)):
+            for b in range(a + 1, len(nb)):
+                out.append((nb[a], apex, nb[b], atype))
+    return np.array(out, dtype=np.int32).reshape(-1, 4)
+
+
 def write_data(path: str, x: np.ndarray, lo, hi, v: np.ndarray | None = None,
-               types: np.ndarray | None = None, ntypes: int = 1, bonds: np.ndarray | None = None) -> None:
+               types: np.ndarray | None = None, ntypes: int = 1, bonds: np.ndarray | None = None,
+               angles: np.ndarray | None = None) -> None:
     """LAMMPS ``read_data`` file (atom_style atomic / dpd/atomic/meso), optional Velocities.  With ``bonds``
-    (nb,3: tag_i, tag_j, type) the file is in atom_style bond / dpd/bond/meso form (molecule-id column, Bonds)."""
+    (nb,3: tag_i, tag_j, type) the file is in atom_style bond / dpd/bond/meso form (molecule-id column, Bonds); with
+    ``angles`` (na,4: tag1, apex, tag3, type) it also carries the Angles section of atom_style angle / dpd/angle/meso."""
     n = len(x)
     if types is None:
         types = np.ones(n, dtype=np.int64)
@@ -50,9 +67,13 @@ def write_data(path: str, x: np.ndarray, lo, hi, v: np.ndarray | None = None,
         f.write("LAMMPS\n\n%d atoms\n" % n)
         if bonds is not None:
             f.write("%d bonds\n" % len(bonds))
+        if angles is not None:
+            f.write("%d angles\n" % len(angles))
         f.write("\n%d atom types\n" % ntypes)
         if bonds is not None:
             f.write("%d bond types\n" % int(bonds[:, 2].max()))
+        if angles is not None:
+            f.write("%d angle types\n" % int(angles[:, 3].max()))
         f.write("\n")
         for d, a in enumerate("xyz"):
             f.write("%.17g %.17g %slo %shi\n" % (lo[d], hi[d], a, a))
@@ -73,6 +94,10 @@ def write_data(path: str, x: np.ndarray, lo, hi, v: np.ndarray | None = None,
             f.write("\nBonds\n\n")
             for b, (i, j, t) in enumerate(bonds):
                 f.write("%d %d %d %d\n" % (b + 1, t, i, j))
+        if angles is not None:
+            f.write("\nAngles\n\n")
+            for a, (i, j, k, t) in enumerate(angles):
+                f.write("%d %d %d %d %d\n" % (a + 1, t, i, j, k))
 
 
 def read_data(path: str):

@@ -89,6 +89,46 @@ class MesoRefSim:
                 frontier = nxt
             self.special[t] = out
 
+    def set_angles(self, angles, coeffs):
+        """angles (na,4: tag1, apex tag2, tag3, type); coeffs {type: (K, theta0 in degrees)}.  Force and energy:
+        AngleHarmonic::compute src/MOLECULE/angle_harmonic.cpp:50-142 (E = K (theta - theta0)^2), which is what each of the
+        three atoms evaluates for itself in gpu_angle_harmonic angle_harmonic_meso.cu:77-157."""
+        self.angles = np.asarray(angles, np.int64).reshape(-1, 4)
+        self.angle_coeffs = coeffs
+
+    def _angle_forces(self):
+        self.e_angle = 0.0
+        if getattr(self, "angles", None) is None or len(self.angles) == 0:
+            return
+        c = self.c4[:self.n, :3].astype(np.float64)
+        prd = self.hi - self.lo
+        i1, i2, i3 = (self.angles[:, k] - 1 for k in range(3))
+        k = np.array([self.angle_coeffs[int(t)][0] for t in self.angles[:, 3]])
+        th0 = np.array([self.angle_coeffs[int(t)][1] for t in self.angles[:, 3]]) / 180.0 * np.pi
+
+        def mi(d):
+            return d + np.where(d > -0.5 * prd, np.where(d < 0.5 * prd, 0.0, -prd), prd)
+        d1 = mi(c[i1] - c[i2])
+        d2 = mi(c[i3] - c[i2])
+        rsq1 = (d1 * d1).sum(1)
+        rsq2 = (d2 * d2).sum(1)
+        r1 = np.sqrt(rsq1)
+        r2 = np.sqrt(rsq2)
+        cs = np.clip((d1 * d2).sum(1) / (r1 * r2), -1.0, 1.0)
+        sn = 1.0 / np.sqrt(np.maximum(1.0 - cs * cs, 0.001))          # SMALL (angle_harmonic.cpp:31)
+        dth = np.arccos(cs) - th0
+        tk = k * dth
+        a = -2.0 * tk * sn
+        a11 = a * cs / rsq1
+        a12 = -a / (r1 * r2)
+        a22 = a * cs / rsq2
+        f1 = a11[:, None] * d1 + a12[:, None] * d2
+        f3 = a22[:, None] * d2 + a12[:, None] * d1
+        np.add.at(self.f, i1, f1)
+        np.add.at(self.f, i3, f3)
+        np.add.at(self.f, i2, -(f1 + f3))
+        self.e_angle = float((tk * dth).sum())
+
     def _apply_exclusions(self):
         if not getattr(self, "special", None):
             return
@@ -180,6 +220,7 @@ class MesoRefSim:
         self.f = ob.pair_dpd(self.n, self.c4, self.v4, self.count, self.table, self.coeff, self.ntypes,
                              self.dt, fast=self.fast)
         self._bond_forces()
+        self._angle_forces()
 
     def setup(self):
         self.cutmax = max(c[4] for c in self.coeffs.values())

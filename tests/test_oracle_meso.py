@@ -192,3 +192,31 @@ def test_bond_forces_are_the_gradient_of_the_bond_energy(oracle, style, coeff):
             xm[i, d] -= h
             num = -(sim(xp).e_bond - sim(xm).e_bond) / (2 * h)
             assert num == pytest.approx(s0.f[i, d], rel=2e-3, abs=2e-3)
+
+
+def test_angle_forces_are_the_gradient_of_the_angle_energy(oracle):
+    """angle restatement (angle_harmonic.cpp:50-142 / angle_harmonic_meso.cu:77-157) pinned by its own energy"""
+    from meso_amd.datagen import chain_angles, make_polymer_box
+    from oracle.meso_sim import MesoRefSim
+    x, v, types, bonds, lo, hi = make_polymer_box(5, frac=0.3)
+    angles = chain_angles(bonds)
+
+    def sim(xx):
+        s = MesoRefSim(xx, v * 0.0, lo, hi, types=types, ntypes=2)
+        for (i, j) in [(1, 1), (2, 2), (1, 2)]:
+            s.pair_coeff(i, j, 0.0, 0.0, 0.0, 1.0, 1.0)
+        s.set_bonds(bonds, {1: (0.0, 0.5)}, (0.0, 0.0, 0.0))
+        s.set_angles(angles, {1: (8.0, 150.0)})
+        s.setup()
+        return s
+
+    s0 = sim(x)
+    assert s0.e_angle > 0.0 and abs(s0.f.sum(0)).max() < 1e-9 * np.abs(s0.f).max()
+    h = 1e-4
+    for i in sorted({int(t) - 1 for t in angles[:3, :3].ravel()})[:4]:
+        for d in range(3):
+            xp, xm = x.copy(), x.copy()
+            xp[i, d] += h
+            xm[i, d] -= h
+            num = -(sim(xp).e_angle - sim(xm).e_angle) / (2 * h)
+            assert num == pytest.approx(s0.f[i, d], rel=2e-3, abs=2e-3)
