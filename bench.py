@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--box", type=int, default=64, help="cubic box edge L (N = 4 L^3)")
-    ap.add_argument("--style", default="dpd/fast/meso", choices=["dpd/meso", "dpd/fast/meso"])
+    ap.add_argument("--style", default="dpd/fast/meso", choices=["dpd/meso", "dpd/fast/meso", "dpd/mini/meso"])
     ap.add_argument("--every", type=int, default=5, help="neigh_modify every")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0 = auto)")
@@ -165,7 +165,8 @@ def main():
     b_fused = n_rank * (b_in + 48 + 20 + 48 + 32.0 * (a.every - 1) / max(a.every, 1))
     b_pair = b_fused if fused else b_pair_only
     achieved = b_pair / t_pair / 1e9
-    kernel = "k_pair_dpd_ring" + ("" if a.style == "dpd/fast/meso" else "<fp64>")
+    fp32 = a.style in ("dpd/fast/meso", "dpd/mini/meso")
+    kernel = "k_pair_dpd_ring" + ("" if fp32 else "<fp64>")
     kernel += " + step-boundary epilogue (nve final/initial, merge)" if fused else ""
     pair_only = None
     if fused:
@@ -208,7 +209,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32" if a.style == "dpd/fast/meso" else "f64",
+        "dtype": "f32" if fp32 else "f64",
         "data": "synthetic",
         "config": {"workload": "%d^3 box rho=4 (N=%d), pair_style %s, neighbor 0.3 bin, rebuild every %d, dt 0.005, "
                                "%d MI355X, procgrid %dx%dx%d" % ((L, n, a.style, a.every, a.gpus) + tuple(grid)),

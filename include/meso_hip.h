@@ -22,7 +22,9 @@ typedef struct meso_ctx meso_ctx;
 enum { MESO_OK = 0, MESO_ERR_ARG = 1, MESO_ERR_HIP = 2, MESO_ERR_STATE = 3, MESO_ERR_OVERFLOW = 4, MESO_ERR_COMM = 5 };
 
 /* pair styles: PairStyle(dpd/meso,MesoPairDPD) pair_dpd_meso.h:3 ; PairStyle(dpd/fast/meso,...) pair_dpd_fast_meso.h:3 */
-enum { MESO_PAIR_DPD = 0, MESO_PAIR_DPD_FAST = 1 };
+/* MESO_PAIR_DPD_MINI: PairStyle(dpd/mini/meso) pair_dpd_minimal_meso.h:3 - fp32 arithmetic, cutoff 1, one (a0, gamma, sigma)
+ * for all types (pair_coeff * * a0 gamma sigma), pair noise from the logistic map mean0var1<8> (:50-89) instead of TEA */
+enum { MESO_PAIR_DPD = 0, MESO_PAIR_DPD_FAST = 1, MESO_PAIR_DPD_MINI = 2 };
 /* work ranges, AtomAttribute::LOCAL/BULK/BORDER util_meso.h:43-74, resolve_work_range atom_vec_meso.cu:194-218 */
 enum { MESO_RANGE_LOCAL = 0, MESO_RANGE_BULK = 1, MESO_RANGE_BORDER = 2 };
 /* ghost transports */
@@ -143,6 +145,7 @@ int64_t meso_ntimestep(meso_ctx *ctx);
 int meso_test_tea(meso_ctx *ctx, int n, int rounds, const uint32_t *u, const uint32_t *v, uint32_t *out0,
                   uint32_t *out1);
 int meso_test_gaussian(meso_ctx *ctx, int n, const uint32_t *u, const uint32_t *v, double *out_dp, float *out_sp);
+int meso_test_logistic(meso_ctx *ctx, int n, const uint32_t *u, const uint32_t *v, float *out); /* mean0var1<8> pair_dpd_minimal_meso.cu:82-89 */
 uint32_t meso_seed_now(int seed, int64_t ntimestep); /* MesoPairDPD::seed_now pair_dpd_meso.cu:268-270 */
 
 /* ---- mini driver: runs the input-script subset of example/simple/{sp,dp}.run unchanged */

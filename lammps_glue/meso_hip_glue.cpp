@@ -48,6 +48,24 @@ MesoHipPairDPD::MesoHipPairDPD(LAMMPS *lmp) : Pair(lmp)
 
 MesoHipPairDPDFast::MesoHipPairDPDFast(LAMMPS *lmp) : MesoHipPairDPD(lmp) { style_id = MESO_PAIR_DPD_FAST; }
 
+MesoHipPairDPDMini::MesoHipPairDPDMini(LAMMPS *lmp) : MesoHipPairDPD(lmp) { style_id = MESO_PAIR_DPD_MINI; }
+
+void MesoHipPairDPDMini::settings(int narg, char **arg)
+{
+  if (narg != 2) error->all(FLERR, "Illegal pair_style command");
+  cut_global = 1.0;                    /* MesoPairDPDMini::coeff: cutsq = 1 for every pair */
+  seed = atoi(arg[1]);
+  MESO(meso_pair_dpd_settings(MesoHipContext::get(lmp), style_id, cut_global, seed));
+}
+
+void MesoHipPairDPDMini::coeff(int narg, char **arg)
+{
+  if (narg < 5) error->all(FLERR, "Incorrect args for pair coefficients");
+  char one[] = "1.0";
+  char *full[7] = {arg[0], arg[1], arg[2], arg[3], arg[4], one, one};
+  MesoHipPairDPD::coeff(7, full);      /* a0, gamma, sigma are scalars of the style: the library applies them to all pairs */
+}
+
 void MesoHipPairDPD::settings(int narg, char **arg)
 {
   if (narg != 2) error->all(FLERR, "Illegal pair_style command");

@@ -17,6 +17,7 @@
 #ifdef PAIR_CLASS
 PairStyle(dpd/meso,MesoHipPairDPD)
 PairStyle(dpd/fast/meso,MesoHipPairDPDFast)
+PairStyle(dpd/mini/meso,MesoHipPairDPDMini)
 #elif defined(BOND_CLASS)
 BondStyle(harmonic/meso,MesoHipBondHarmonic)
 BondStyle(fene/meso,MesoHipBondFENE)
@@ -71,6 +72,14 @@ class MesoHipPairDPD : public Pair {
 class MesoHipPairDPDFast : public MesoHipPairDPD {
  public:
   MesoHipPairDPDFast(class LAMMPS *);
+};
+
+/* pair_style dpd/mini/meso <unused> seed; pair_coeff * * a0 gamma sigma (replaces MesoPairDPDMini pair_dpd_minimal_meso.h:3) */
+class MesoHipPairDPDMini : public MesoHipPairDPD {
+ public:
+  MesoHipPairDPDMini(class LAMMPS *);
+  void settings(int, char **);
+  void coeff(int, char **);
 };
 
 /* bond_style harmonic/meso (replaces MesoBondHarmonic, bond_harmonic_meso.h:3); the Bonds section is handed over once by

@@ -73,6 +73,7 @@ SIGNATURES = {
     "meso_ntimestep": (_i64, [_vp]),
     "meso_test_tea": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "meso_test_gaussian": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "meso_test_logistic": (_i, [_vp, _i, _vp, _vp, _vp]),
     "meso_seed_now": (_u32, [_i, _i64]),
     "meso_script_run": (_i, [_vp, _cp, _cp, _cp, _cp, _sz]),
 }

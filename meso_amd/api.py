@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib
 
-PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1}
+PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1, "dpd/mini/meso": 2}
 RANGES = {"local": 0, "bulk": 1, "border": 2}
 TRANSPORTS = {"self": 0, "rccl": 1, "host": 2, "local": 3}
 
@@ -140,7 +140,7 @@ class Meso:
             raise MesoError("Unknown pair style " + style)
         self._ck(self.lib.meso_pair_dpd_settings(self._h, PAIR_STYLES[style], cut_global, seed))
 
-    def pair_coeff(self, i, j, a0, gamma, sigma, expw, cut=0.0):
+    def pair_coeff(self, i, j, a0, gamma, sigma, expw=1.0, cut=0.0):
         self._ck(self.lib.meso_pair_dpd_coeff(self._h, i, j, a0, gamma, sigma, expw, cut))
 
     # -- bonded topology: atom_style dpd/bond/meso, bond_style harmonic/meso ---------------------
@@ -329,6 +329,12 @@ class Meso:
         dp = np.empty(len(u), np.float64); sp = np.empty(len(u), np.float32)
         self._ck(self.lib.meso_test_gaussian(self._h, len(u), _p(u), _p(v), _p(dp), _p(sp)))
         return dp, sp
+
+    def logistic(self, u, v):
+        u = np.ascontiguousarray(u, np.uint32); v = np.ascontiguousarray(v, np.uint32)
+        sp = np.empty(len(u), np.float32)
+        self._ck(self.lib.meso_test_logistic(self._h, len(u), _p(u), _p(v), _p(sp)))
+        return sp
 
     def script(self, path, var=None, value=None, log_bytes=1 << 16):
         buf = C.create_string_buffer(log_bytes)

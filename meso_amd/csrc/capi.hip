@@ -226,6 +226,12 @@ int meso_test_gaussian(meso_ctx *ctx, int n, const uint32_t *u, const uint32_t *
     if (n < 0 || !u || !v || !odp || !osp) return set_err(MESO_ERR_ARG, "invalid test buffers");
     RET(E.test_gaussian(n, u, v, odp, osp));
 }
+int meso_test_logistic(meso_ctx *ctx, int n, const uint32_t *u, const uint32_t *v, float *out)
+{
+    CTX(ctx);
+    if (n < 0 || !u || !v || !out) return set_err(MESO_ERR_ARG, "invalid test buffers");
+    RET(E.test_logistic(n, u, v, out));
+}
 uint32_t meso_seed_now(int seed, int64_t ntimestep) { return meso::premix_tea<64>((uint32_t)seed, (uint32_t)ntimestep); }
 
 int meso_script_run(meso_ctx *ctx, const char *path, const char *var_name, const char *var_value, char *log,

@@ -82,6 +82,7 @@ public:
     int timer_get(const std::string &name, double *ms, int64_t *calls);
     int test_tea(int n, int rounds, const uint32_t *u, const uint32_t *v, uint32_t *o0, uint32_t *o1);
     int test_gaussian(int n, const uint32_t *u, const uint32_t *v, double *odp, float *osp);
+    int test_logistic(int n, const uint32_t *u, const uint32_t *v, float *out);
     int sync();
 
     std::string err;
@@ -157,6 +158,7 @@ private:
     int every = 1, delay = 10, dist_check = 1;
     int groupbit = 1;
     int pair_style = 0, seed = 0, ntypes = 0;
+    int pair_rng = 0;       // 1: pair_style dpd/mini/meso (fp32 arithmetic of dpd/fast/meso, logistic-map noise, one coefficient set)
     double cut_global = 0.0, cutmax = 0.0, cutghost = 0.0;
     bool have_pair = false, have_coeff = false, params_ready = false, is_setup = false;
     std::vector<double> coeff;      // ntypes*ntypes*7

@@ -206,9 +206,12 @@ int Engine::neighbor(double s, int ev, int dl, int chk)
 // MesoPairDPD::settings (pair_dpd_meso.cu:272-288): pair_style dpd/meso rc seed
 int Engine::pair_settings(int style, double cut, int sd)
 {
-    if (style != 0 && style != 1) return fail(1, "Illegal pair_style command");
+    if (style != 0 && style != 1 && style != 2) return fail(1, "Illegal pair_style command");
     if (!(cut > 0.0)) return fail(1, "Illegal pair_style command");
-    pair_style = style; cut_global = cut; seed = sd;
+    // MesoPairDPDMini (pair_dpd_minimal_meso.cu:239-265): one global coefficient set, cutoff fixed at 1
+    if (style == 2 && cut != 1.0) return fail(1, "pair_style dpd/mini/meso has a fixed cutoff of 1");
+    pair_rng = style == 2 ? 1 : 0;
+    pair_style = style == 2 ? 1 : style; cut_global = cut; seed = sd;
     have_pair = true;
     params_ready = false;
     return 0;
@@ -221,6 +224,18 @@ int Engine::pair_coeff(int i, int j, double a0, double gamma, double sigma, doub
     if (ntypes == 0) return fail(3, "pair_coeff before atom types are known");
     if (i < 1 || j < 1 || i > ntypes || j > ntypes) return fail(1, "Incorrect args for pair coefficients");
     if (cut <= 0.0) cut = cut_global;
+    if (pair_rng) {
+        // MesoPairDPDMini::coeff: a0, gamma, sigma are scalars of the style - every pair of types gets them, s = 1, rc = 1
+        for (int t = 0; t < ntypes * ntypes; t++) {
+            double *c = &coeff[(size_t)t * N_COEFF];
+            c[P_CUT] = 1.0; c[P_CUTSQ] = 1.0; c[P_CUTINV] = 1.0; c[P_EXPW] = 1.0;
+            c[P_A0] = a0; c[P_GAMMA] = gamma; c[P_SIGMA] = sigma;
+            coeff_set[t] = 1;
+        }
+        have_coeff = true;
+        params_ready = false;
+        return 0;
+    }
     for (int k = 0; k < 2; k++) {
         int a = k ? j - 1 : i - 1, b = k ? i - 1 : j - 1;
         double *c = &coeff[((size_t)a * ntypes + b) * N_COEFF];
@@ -1128,6 +1143,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     const bool cell_ring = !ev && ring_selected();
     if (!cell_ring) p.fuse_nve = 0;              // only the ring kernel has the epilogue
     p.nall = nlocal + nghost;
+    p.rng = pair_rng;
     p.all_expw_one = 1;
     p.share = (pair_share && (p.end == nlocal || (p.end & (pair_ring_group() - 1)) == 0)) ? 1 : 0;
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
@@ -1182,6 +1198,7 @@ int Engine::setup()
 {
     if (nlocal <= 0 && nranks == 1) return fail(3, "No atoms have been uploaded");
     if (have_bonds && layout != 2) return fail(3, "bonded topology needs the cell-ordered layout (layout=2)");
+    if (pair_rng && !ring_selected()) return fail(3, "pair_style dpd/mini/meso runs on the default force kernel only (layout=2, pair_kernel=2)");
     TRY(init_params());
     TRY(reneighbor());
     nbuild = 0;
@@ -1440,6 +1457,21 @@ int Engine::test_gaussian(int n, const uint32_t *u, const uint32_t *v, double *o
     HIPCHK(hipMemcpy(odp, dd, n * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(osp, ds, n * sizeof(float), hipMemcpyDeviceToHost));
     dfree(du); dfree(dv); dfree(dd); dfree(ds);
+    return 0;
+}
+
+int Engine::test_logistic(int n, const uint32_t *u, const uint32_t *v, float *out)
+{
+    if (!stream) TRY(alloc_atoms(1024));
+    uint32_t *du, *dv;
+    float *ds;
+    HIPCHK(dalloc(du, n)); HIPCHK(dalloc(dv, n)); HIPCHK(dalloc(ds, n));
+    HIPCHK(hipMemcpy(du, u, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv, v, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    launch_test_logistic(du, dv, n, ds, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipMemcpy(out, ds, n * sizeof(float), hipMemcpyDeviceToHost));
+    dfree(du); dfree(dv); dfree(ds);
     return 0;
 }
 

@@ -128,6 +128,7 @@ struct PairArgs {
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
     int nall;             // atoms in coord4/veloc4 (locals + ghosts): bound of the buffer-addressed gathers
     int all_expw_one;     // every pair type has weight exponent 1 (no pow() in the kernel)
+    int rng;              // fp32 styles: 0 TEA Gaussian (dpd/fast/meso), 1 logistic map (dpd/mini/meso)
     int share;            // ring kernel: Newton pairing inside a workgroup allowed (end == nlocal or a multiple of 256)
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;
@@ -220,6 +221,7 @@ struct ExclArgs {            // special-partner filter of the list builder (null
 // ---- unit kernels for known-answer tests --------------------------------------------------------------
 void launch_test_tea(const uint32_t *u, const uint32_t *v, int n, int rounds, uint32_t *out0, uint32_t *out1,
                      hipStream_t s);
+void launch_test_logistic(const uint32_t *u, const uint32_t *v, int n, float *out, hipStream_t s);
 void launch_test_gaussian(const uint32_t *u, const uint32_t *v, int n, double *out_dp, float *out_sp,
                           hipStream_t s);
 

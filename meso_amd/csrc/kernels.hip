@@ -913,7 +913,7 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
             const float *cf = cf32 + (t1 * a.ntypes + __float_as_uint(c2.w)) * N_COEFF;
             if (rsq < cf[P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ) {
                 float4 v2 = a.veloc4[j];
-                float rn = gaussian_tea_fast(s1, __float_as_uint(v2.w));
+                float rn = pair_noise_fast(a.rng, s1, __float_as_uint(v2.w));
                 float rinv = __builtin_amdgcn_rsqf(rsq);
                 float r = rsq * rinv;
                 float dvx = v1.x - v2.x, dvy = v1.y - v2.y, dvz = v1.z - v2.z;
@@ -1680,6 +1680,16 @@ __global__ void k_test_gaussian(const u32 *u, const u32 *v, int n, double *odp, 
 void launch_test_gaussian(const uint32_t *u, const uint32_t *v, int n, double *out_dp, float *out_sp, hipStream_t s)
 {
     if (n > 0) hipLaunchKernelGGL(k_test_gaussian, dim3(nblk(n, 256)), dim3(256), 0, s, u, v, n, out_dp, out_sp);
+}
+
+__global__ void k_test_logistic(const u32 *u, const u32 *v, int n, float *o)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = logistic_noise(u[i], v[i]);
+}
+void launch_test_logistic(const uint32_t *u, const uint32_t *v, int n, float *out, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_test_logistic, dim3(nblk(n, 256)), dim3(256), 0, s, u, v, n, out);
 }
 
 } // namespace meso

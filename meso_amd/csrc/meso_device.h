@@ -206,6 +206,33 @@ __device__ inline float gaussian_tea_fast(u32 u, u32 v)
     return fmaxf(-4.0f, fminf(r * f, 4.0f));
 }
 
+// pair_style dpd/mini/meso (pair_dpd_minimal_meso.cu:50-89): mean0var1<8> - the sum of the two signatures mapped to
+// [-1,1), four rounds of the degree-4 Chebyshev map 8x^4 - 8x^2 + 1 (arcsine law on [-1,1], variance 1/2), times sqrt 2.
+// The reference evaluates the map with __fmaf_rz; gfx950 has no per-instruction rounding, so the two FMAs of a round run
+// between two writes of the wave's fp32 rounding mode (MODE[1:0] = 3: toward zero) inside one asm block - the mode never
+// leaks, and the stream equals the oracle's fesetround(FE_TOWARDZERO) + fmaf bit for bit.
+__device__ inline float logistic_round_rz(float x)
+{
+    const float x2 = x * x, c8 = 8.0f, m8 = -8.0f;
+    float r;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_fma_f32 %0, %2, %1, %3\n\t"
+                 "v_fma_f32 %0, %0, %1, 1.0\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(r)
+                 : "v"(x2), "v"(c8), "v"(m8));
+    return r;
+}
+__device__ inline float logistic_noise(u32 u, u32 v)
+{
+    float x = (float)u * (float)MESO_2_TO_MINUS_32 + (float)v * (float)MESO_2_TO_MINUS_32 - 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) x = logistic_round_rz(x);
+    return x * 1.41421356237309514547f;
+}
+// the pair noise of the fp32 styles: rng 0 = TEA-keyed Gaussian (dpd/fast/meso), 1 = logistic map (dpd/mini/meso)
+__device__ inline float pair_noise_fast(int rng, u32 u, u32 v) { return rng ? logistic_noise(u, v) : gaussian_tea_fast(u, v); }
+
 // dpd/meso pair force in the reference's mixed precision (fp32 operands, fp64 arithmetic; gpu_dpd<0>
 // pair_dpd_meso.cu:120-160), one definition for the force kernels; compiled uncontracted (explicit fma only).
 struct PairCoeff64 { double cutinv, expw, a0, gamma, sigma; };

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                     }
                     const float dx = ci.x - pc2.x, dy = ci.y - pc2.y, dz = ci.z - pc2.z;
                     const float rsq = dx * dx + dy * dy + dz * dz;
-                    const float rn = gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w));
+                    const float rn = pair_noise_fast(a.rng, __float_as_uint(vi.w), __float_as_uint(pv2.w));
                     const float rinv = __builtin_amdgcn_rsqf(rsq);
                     const float r = rsq * rinv;
                     const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;

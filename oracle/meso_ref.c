@@ -24,6 +24,7 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
  * ------------------------------------------------------------------------- */
+#include <fenv.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -244,6 +245,23 @@ float meso_gaussian_tea_fast(uint u, uint v)
     return fmaxf(-4.0f, fminf(g, 4.0f));
 }
 
+/* mean0var1<8>  pair_dpd_minimal_meso.cu:50-89: the pair noise of pair_style dpd/mini/meso.  p = u/2^32 + v/2^32 - 1, four
+ * rounds of r = FMA(FMA(8, x^2, -8), x^2, 1) with FMA = __fmaf_rz (round toward zero; x*x rounds to nearest), times sqrt 2.
+ * volatile keeps gcc from moving the arithmetic across the rounding-mode switches. */
+float meso_logistic_noise(uint u, uint v)
+{
+    volatile float x = (float)u / 4294967296.f + (float)v / 4294967296.f - 1.0f;
+    for (int k = 0; k < 4; k++) {
+        volatile float x2 = x * x;
+        fesetround(FE_TOWARDZERO);
+        volatile float t = fmaf(8.0f, x2, -8.0f);
+        volatile float r = fmaf(t, x2, 1.0f);
+        fesetround(FE_TONEAREST);
+        x = r;
+    }
+    return x * 1.41421356237309514547f;
+}
+
 /* ---- gpu_merge_xvt  atom_vec_meso.cu:142-167 ----------------------------- */
 /* coord4/veloc4: n x 4 floats; .w carries (type-1) / signature bit patterns */
 void meso_merge_xvt(int n, const double *x, const double *y, const double *z, const double *vx,
@@ -392,9 +410,10 @@ void meso_pair_dpd(int ibeg, int iend, const float *coord4, const float *veloc4,
 }
 
 /* ---- gpu_dpd_fast<0>  pair_dpd_fast_meso.cu:91-205 ----------------------- */
-void meso_pair_dpd_fast(int ibeg, int iend, const float *coord4, const float *veloc4, const int *count,
-                        const int *table, int stride, const float *coeff, int ntypes, float dt_inv_sqrt,
-                        double *fx, double *fy, double *fz)
+/* rng 0: gaussian_TEA_fast (dpd/fast/meso); rng 1: mean0var1<8> (gpu_dpd_mini pair_dpd_minimal_meso.cu:91-178, same force) */
+void meso_pair_dpd_fast_rng(int ibeg, int iend, const float *coord4, const float *veloc4, const int *count,
+                            const int *table, int stride, const float *coeff, int ntypes, float dt_inv_sqrt,
+                            double *fx, double *fy, double *fz, int rng)
 {
 #pragma omp parallel for schedule(dynamic, 256)
     for (int i = ibeg; i < iend; i++) {
@@ -409,7 +428,7 @@ void meso_pair_dpd_fast(int ibeg, int iend, const float *coord4, const float *ve
             float rsq = dx * dx + dy * dy + dz * dz;
             const float *cf = coeff + (t1 * ntypes + f2u(coord4[4 * j + 3])) * 7;
             if (rsq < cf[1] && (double)rsq >= EPSILON_SQ) {
-                float rn = meso_gaussian_tea_fast(s1, f2u(veloc4[4 * j + 3]));
+                float rn = rng ? meso_logistic_noise(s1, f2u(veloc4[4 * j + 3])) : meso_gaussian_tea_fast(s1, f2u(veloc4[4 * j + 3]));
                 float rinv = 1.0f / sqrtf(rsq);
                 float r = rsq * rinv;
                 float dvx = v1x - veloc4[4 * j], dvy = v1y - veloc4[4 * j + 1], dvz = v1z - veloc4[4 * j + 2];
@@ -423,6 +442,13 @@ void meso_pair_dpd_fast(int ibeg, int iend, const float *coord4, const float *ve
         }
         fx[i] += ax; fy[i] += ay; fz[i] += az;
     }
+}
+
+void meso_pair_dpd_fast(int ibeg, int iend, const float *coord4, const float *veloc4, const int *count,
+                        const int *table, int stride, const float *coeff, int ntypes, float dt_inv_sqrt,
+                        double *fx, double *fy, double *fz)
+{
+    meso_pair_dpd_fast_rng(ibeg, iend, coord4, veloc4, count, table, stride, coeff, ntypes, dt_inv_sqrt, fx, fy, fz, 0);
 }
 
 /* ---- fix nve/meso  fix_nve_meso.cu:62-95, 157-178 ------------------------ */

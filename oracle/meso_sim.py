@@ -39,7 +39,7 @@ def periodic_ghosts(x, lo, hi, cut):
 
 class MesoRefSim:
     def __init__(self, x, v, lo, hi, types=None, ntypes=1, mass=None, skin=0.3, every=5,
-                 dt=0.005, seed=419084618, fast=False, stride=160):
+                 dt=0.005, seed=419084618, fast=False, stride=160, mini=False):
         self.n = len(x)
         self.x = np.array(x, dtype=np.float64)
         self.v = np.array(v, dtype=np.float64)
@@ -51,7 +51,8 @@ class MesoRefSim:
         self.mask = np.ones(self.n, np.int32)
         self.ntypes = ntypes
         self.mass_type = np.ones(ntypes + 1) if mass is None else np.array(mass, dtype=np.float64)
-        self.skin, self.every, self.dt, self.seed, self.fast = skin, every, dt, seed, fast
+        self.skin, self.every, self.dt, self.seed, self.fast = skin, every, dt, seed, fast or mini
+        self.mini = mini            # pair_style dpd/mini/meso: fast arithmetic, logistic-map noise (pair_dpd_minimal_meso.cu)
         self.stride = stride
         self.coeffs = {}
         self.ntimestep = 0
@@ -218,7 +219,7 @@ class MesoRefSim:
         seed = self.M.meso_seed_now(self.seed, self.ntimestep)
         self.c4, self.v4 = self._merge(seed)
         self.f = ob.pair_dpd(self.n, self.c4, self.v4, self.count, self.table, self.coeff, self.ntypes,
-                             self.dt, fast=self.fast)
+                             self.dt, fast=self.fast, rng=1 if self.mini else 0)
         self._bond_forces()
         self._angle_forces()
 

@@ -1,0 +1,118 @@
+"""pair_style dpd/mini/meso (pair_dpd_minimal_meso.cu) - the fp32 force of dpd/fast/meso with one
+global coefficient set, cutoff 1 and the logistic-map pair noise mean0var1<8> instead of TEA."""
+import numpy as np
+import pytest
+
+from meso_amd.datagen import make_box, make_polymer_box
+
+pytestmark = pytest.mark.gpu
+
+
+def test_logistic_noise_is_bit_exact(oracle):
+    """the two FMAs of every round run in round-toward-zero mode like the reference's __fmaf_rz"""
+    from meso_amd.api import Meso
+    M = oracle.meso_lib()
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32)
+    v = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32)
+    u[:4] = [0, 0xFFFFFFFF, 1, 0x80000000]
+    v[:4] = [0, 0xFFFFFFFF, 0, 0x7FFFFFFF]
+    with Meso() as m:
+        a = m.logistic(u, v)
+        b = m.logistic(v, u)
+    ref = np.array([M.meso_logistic_noise(int(p), int(q)) for p, q in zip(u, v)], dtype=np.float32)
+    assert np.array_equal(a.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() <= np.float32(1.41421356) and abs(a[4:].mean()) < 0.03 and abs(a[4:].var() - 1) < 0.03
+
+
+def _mini(m, x, v, lo, hi, sigma=3.0, types=None, ntypes=1):
+    m.read_atoms(x, v, lo, hi, types=types, ntypes=ntypes)
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=5, check=False)
+    m.pair_style("dpd/mini/meso", 1.0, 419084618)
+    m.pair_coeff(1, 1, 15.0, 4.5, sigma)             # pair_coeff * * a0 gamma sigma: scalars of the style
+    m.timestep(0.005)
+    m.setup()
+
+
+@pytest.mark.parametrize("ntypes", [1, 2])
+def test_forces_and_short_trajectory(oracle, ntypes):
+    from meso_amd.api import Meso
+    from oracle.meso_sim import MesoRefSim
+    if ntypes == 1:
+        x, v, lo, hi = make_box(8)
+        types = None
+    else:
+        x, v, types, _, lo, hi = make_polymer_box(8, frac=0.3)
+    def sim(sigma):
+        s = MesoRefSim(x, v, lo, hi, types=types, ntypes=ntypes, mini=True)
+        for i in range(1, ntypes + 1):
+            for j in range(i, ntypes + 1):
+                s.pair_coeff(i, j, 15.0, 4.5, sigma, 1.0, 1.0)
+        s.setup()
+        return s
+    s = sim(3.0)
+    with Meso() as m:
+        _mini(m, x, v, lo, hi, types=types, ntypes=ntypes)
+        f0 = m.gather()[2]
+    # contracted fp32 arithmetic on the GPU, uncontracted in the oracle; the noise itself is bit-identical
+    assert np.abs(f0 - s.f).max() < 5e-5 * np.abs(s.f).max()
+    # trajectories are compared without noise: the signatures are keyed by the low mantissa bits of the fp32 velocities,
+    # so a last-bit difference in v redraws every random number (same reason as for dpd/fast/meso)
+    s = sim(0.0)
+    with Meso() as m:
+        _mini(m, x, v, lo, hi, sigma=0.0, types=types, ntypes=ntypes)
+        m.run(10)
+        s.run(10)
+        xg, vg = m.gather()[:2]
+    prd = hi - lo
+    d = xg - s.x
+    d -= np.round(d / prd) * prd
+    assert np.abs(d).max() < 5e-5 and np.abs(vg - s.v).max() < 5e-3
+
+
+def test_differs_from_the_tea_style_only_in_the_noise():
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(8)
+    out = {}
+    for style in ("dpd/mini/meso", "dpd/fast/meso"):
+        for sigma in (0.0, 3.0):
+            with Meso() as m:
+                m.read_atoms(x, v, lo, hi)
+                m.neighbor(0.3)
+                m.neigh_modify(delay=0, every=5, check=False)
+                m.pair_style(style, 1.0, 419084618)
+                m.pair_coeff(1, 1, 15.0, 4.5, sigma, 1.0, 1.0)
+                m.timestep(0.005)
+                m.setup()
+                out[style, sigma] = m.gather()[2]
+    assert np.array_equal(out["dpd/mini/meso", 0.0], out["dpd/fast/meso", 0.0])
+    assert np.abs(out["dpd/mini/meso", 3.0] - out["dpd/fast/meso", 3.0]).max() > 1.0
+
+
+def test_thermostat_holds_the_temperature():
+    """arcsine-distributed noise of unit variance: fluctuation-dissipation still gives T = sigma^2 / (2 gamma) = 1"""
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(16)
+    with Meso() as m:
+        _mini(m, x, v, lo, hi)
+        m.run(600)
+        t = []
+        for _ in range(10):
+            m.run(20)
+            t.append(m.temperature())
+    assert abs(np.mean(t) - 1.0) < 0.02, t
+
+
+def test_settings_and_kernel_restrictions():
+    from meso_amd.api import Meso, MesoError
+    x, v, lo, hi = make_box(6)
+    with Meso() as m:
+        m.read_atoms(x, v, lo, hi)
+        with pytest.raises(MesoError):
+            m.pair_style("dpd/mini/meso", 1.5, 1)              # fixed cutoff 1
+    with Meso() as m:
+        m.set_option("pair_kernel", 4)
+        with pytest.raises(MesoError):
+            _mini(m, x, v, lo, hi)                             # default force kernel only

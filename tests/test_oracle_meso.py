@@ -220,3 +220,19 @@ def test_angle_forces_are_the_gradient_of_the_angle_energy(oracle):
             xm[i, d] -= h
             num = -(sim(xp).e_angle - sim(xm).e_angle) / (2 * h)
             assert num == pytest.approx(s0.f[i, d], rel=2e-3, abs=2e-3)
+
+
+def test_logistic_noise_properties(oracle):
+    """mean0var1<8> (pair_dpd_minimal_meso.cu:82-89): symmetric in its arguments, bounded by sqrt 2, mean 0, variance 1,
+    and equal to sqrt(2) T_256(p) up to the rounding of four fp32 rounds"""
+    M = oracle.meso_lib()
+    rng = np.random.default_rng(5)
+    u = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64)
+    v = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64)
+    a = np.array([M.meso_logistic_noise(int(p), int(q)) for p, q in zip(u, v)])
+    b = np.array([M.meso_logistic_noise(int(q), int(p)) for p, q in zip(u[:500], v[:500])])
+    assert np.array_equal(a[:500], b)
+    assert np.abs(a).max() <= 1.4142136 and abs(a.mean()) < 0.03 and abs(a.var() - 1.0) < 0.03
+    p = (np.float32(u) / np.float32(4294967296.0) + np.float32(v) / np.float32(4294967296.0) - np.float32(1.0)).astype(np.float64)
+    cheb = np.sqrt(2.0) * np.cos(256.0 * np.arccos(np.clip(p, -1.0, 1.0)))
+    assert np.median(np.abs(a - cheb)) < 2e-4
