@@ -66,6 +66,39 @@ void MesoHipPairDPDMini::coeff(int narg, char **arg)
   MesoHipPairDPD::coeff(7, full);      /* a0, gamma, sigma are scalars of the style: the library applies them to all pairs */
 }
 
+MesoHipPairDPDPolyForce::MesoHipPairDPDPolyForce(LAMMPS *lmp) : MesoHipPairDPD(lmp) { style_id = MESO_PAIR_DPD_POLYFORCE; }
+
+void MesoHipPairDPDPolyForce::coeff(int narg, char **arg)
+{
+  if (narg < 6 || narg != 6 + atoi(arg[4])) error->all(FLERR, "Incorrect args for pair coefficients");
+  int n = atom->ntypes;
+  if (!allocated) {
+    allocated = 1;
+    memory->create(setflag, n + 1, n + 1, "pair:setflag");
+    memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+    memory->create(cut, n + 1, n + 1, "pair:cut");
+    for (int i = 1; i <= n; i++)
+      for (int j = i; j <= n; j++) setflag[i][j] = 0;
+    MESO(meso_set_mass(MesoHipContext::get(lmp), n, atom->mass));
+  }
+  int ilo, ihi, jlo, jhi;
+  force->bounds(arg[0], n, ilo, ihi);
+  force->bounds(arg[1], n, jlo, jhi);
+  int order = atoi(arg[4]);
+  double *c = new double[order + 1];
+  for (int k = 0; k <= order; k++) c[k] = atof(arg[5 + k]);
+  int count = 0;
+  for (int i = ilo; i <= ihi; i++)
+    for (int j = MAX(jlo, i); j <= jhi; j++) {
+      MESO(meso_pair_dpd_polyforce_coeff(MesoHipContext::get(lmp), i, j, atof(arg[2]), atof(arg[3]), order, c));
+      cut[i][j] = cut_global;
+      setflag[i][j] = 1;
+      count++;
+    }
+  delete [] c;
+  if (count == 0) error->all(FLERR, "Incorrect args for pair coefficients");
+}
+
 void MesoHipPairDPD::settings(int narg, char **arg)
 {
   if (narg != 2) error->all(FLERR, "Illegal pair_style command");

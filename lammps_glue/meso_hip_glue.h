@@ -18,6 +18,7 @@
 PairStyle(dpd/meso,MesoHipPairDPD)
 PairStyle(dpd/fast/meso,MesoHipPairDPDFast)
 PairStyle(dpd/mini/meso,MesoHipPairDPDMini)
+PairStyle(dpd/polyforce/meso,MesoHipPairDPDPolyForce)
 #elif defined(BOND_CLASS)
 BondStyle(harmonic/meso,MesoHipBondHarmonic)
 BondStyle(fene/meso,MesoHipBondFENE)
@@ -80,6 +81,14 @@ class MesoHipPairDPDMini : public MesoHipPairDPD {
   MesoHipPairDPDMini(class LAMMPS *);
   void settings(int, char **);
   void coeff(int, char **);
+};
+
+/* pair_style dpd/polyforce/meso rc seed; pair_coeff i j gamma sigma order c_order ... c_0 (replaces MesoPairDPDPolyForce
+   pair_dpd_polyforce_meso.h:3) */
+class MesoHipPairDPDPolyForce : public MesoHipPairDPD {
+ public:
+  MesoHipPairDPDPolyForce(class LAMMPS *);
+  void coeff(int, char **);            /* -> meso_pair_dpd_polyforce_coeff */
 };
 
 /* bond_style harmonic/meso (replaces MesoBondHarmonic, bond_harmonic_meso.h:3); the Bonds section is handed over once by

@@ -38,6 +38,7 @@ SIGNATURES = {
     "meso_neighbor": (_i, [_vp, _d, _i, _i, _i]),
     "meso_pair_dpd_settings": (_i, [_vp, _i, _d, _i]),
     "meso_pair_dpd_coeff": (_i, [_vp, _i, _i, _d, _d, _d, _d, _d]),
+    "meso_pair_dpd_polyforce_coeff": (_i, [_vp, _i, _i, _d, _d, _i, _vp]),
     "meso_special_bonds": (_i, [_vp, _d, _d, _d]),
     "meso_bonds_upload": (_i, [_vp, _i, _vp, _vp, _vp]),
     "meso_bond_style_harmonic": (_i, [_vp, _i]),

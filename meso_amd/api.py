@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib
 
-PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1, "dpd/mini/meso": 2}
+PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1, "dpd/mini/meso": 2, "dpd/polyforce/meso": 3}
 RANGES = {"local": 0, "bulk": 1, "border": 2}
 TRANSPORTS = {"self": 0, "rccl": 1, "host": 2, "local": 3}
 
@@ -142,6 +142,11 @@ class Meso:
 
     def pair_coeff(self, i, j, a0, gamma, sigma, expw=1.0, cut=0.0):
         self._ck(self.lib.meso_pair_dpd_coeff(self._h, i, j, a0, gamma, sigma, expw, cut))
+
+    def pair_coeff_poly(self, i, j, gamma, sigma, coeffs):
+        """dpd/polyforce/meso: pair_coeff i j gamma sigma order c_order ... c_0 (coeffs from the highest order down)"""
+        c = np.ascontiguousarray(coeffs, np.float64)
+        self._ck(self.lib.meso_pair_dpd_polyforce_coeff(self._h, i, j, gamma, sigma, len(c) - 1, _p(c)))
 
     # -- bonded topology: atom_style dpd/bond/meso, bond_style harmonic/meso ---------------------
     def special_bonds(self, w12=0.0, w13=0.0, w14=0.0):

@@ -52,6 +52,7 @@ public:
     int angle_compute(int eflag);
     int compute_eangle(double *e);
     int pair_settings(int style, double cut, int seed);
+    int pair_coeff_poly(int i, int j, double gamma, double sigma, int order, const double *c);
     int pair_coeff(int i, int j, double a0, double gamma, double sigma, double expw, double cut);
     int set_option(const std::string &key, double val);
 
@@ -158,6 +159,9 @@ private:
     int every = 1, delay = 10, dist_check = 1;
     int groupbit = 1;
     int pair_style = 0, seed = 0, ntypes = 0;
+    bool pair_poly = false;  // pair_style dpd/polyforce/meso: fp32 arithmetic, polynomial conservative force
+    std::vector<float> poly; // [ntypes^2][MESO_POLY_PITCH]
+    float *d_poly = nullptr;
     int pair_rng = 0;       // 1: pair_style dpd/mini/meso (fp32 arithmetic of dpd/fast/meso, logistic-map noise, one coefficient set)
     double cut_global = 0.0, cutmax = 0.0, cutghost = 0.0;
     bool have_pair = false, have_coeff = false, params_ready = false, is_setup = false;

@@ -233,6 +233,25 @@ __device__ inline float logistic_noise(u32 u, u32 v)
 // the pair noise of the fp32 styles: rng 0 = TEA-keyed Gaussian (dpd/fast/meso), 1 = logistic map (dpd/mini/meso)
 __device__ inline float pair_noise_fast(int rng, u32 u, u32 v) { return rng ? logistic_noise(u, v) : gaussian_tea_fast(u, v); }
 
+// pair_style dpd/polyforce/meso: the conservative force is a polynomial in w = 1 - r/rc, Horner from the highest order
+// (polyval / polyval_integral, math_meso.h:53-66); table row = [order][c_order .. c_0], MESO_POLY_PITCH floats per type pair
+#define MESO_POLY_MAXLEN 32
+#define MESO_POLY_PITCH (MESO_POLY_MAXLEN + 1)
+__host__ __device__ inline float polyval_f32(float x, const float *row)
+{
+    const int order = (int)row[0];
+    float r = row[1];
+    for (int k = 0; k < order; k++) r = r * x + row[2 + k];
+    return r;
+}
+__host__ __device__ inline float polyval_integral_f32(float x, const float *row)
+{
+    const int order = (int)row[0];
+    float r = row[1] / (float)(order + 1);
+    for (int k = 0; k < order; k++) r = r * x + row[2 + k] / (float)(order - k);
+    return r * x;
+}
+
 // dpd/meso pair force in the reference's mixed precision (fp32 operands, fp64 arithmetic; gpu_dpd<0>
 // pair_dpd_meso.cu:120-160), one definition for the force kernels; compiled uncontracted (explicit fma only).
 struct PairCoeff64 { double cutinv, expw, a0, gamma, sigma; };

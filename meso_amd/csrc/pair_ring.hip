@@ -131,7 +131,10 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                     const float wc = 1.0f - r * c_cutinv;
                     float wr = wc;
                     if (!EW1 && c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
-                    float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
+                    float fcons = c_a0 * wc;
+                    if (a.poly)      // dpd/polyforce/meso (gpu_dpd_polyforce pair_dpd_polyforce_meso.cu:159-162)
+                        fcons = polyval_f32(wc, a.poly + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * MESO_POLY_PITCH));
+                    float fpair = fcons - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
                     fpair *= rinv;
                     qx = to_fixed(dx * fpair); qy = to_fixed(dy * fpair); qz = to_fixed(dz * fpair);
                 } else {

@@ -66,7 +66,7 @@ struct Deck {
     std::vector<double> x, v, mass;
     std::vector<int> tag, type;
     int nbonds = 0, nbondtypes = 0;
-    bool bond_fene = false, pair_mini = false;
+    bool bond_fene = false, pair_mini = false, pair_poly = false;
     std::vector<int> bond_i, bond_j, bond_t;
     int nangles = 0, nangletypes = 0;
     std::vector<int> ang_1, ang_2, ang_3, ang_t;
@@ -325,14 +325,16 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
             if (w.size() != 2 || (w[1] != "mvv/meso" && w[1] != "verlet/meso")) { E.err = "Illegal run_style command"; return 1; }
             D.run_style = w[1];
         } else if (c == "pair_style") {
-            if (w.size() != 4 || (w[1] != "dpd/meso" && w[1] != "dpd/fast/meso" && w[1] != "dpd/mini/meso")) { E.err = "Illegal pair_style command"; return 1; }
+            if (w.size() != 4 || (w[1] != "dpd/meso" && w[1] != "dpd/fast/meso" && w[1] != "dpd/mini/meso" && w[1] != "dpd/polyforce/meso")) { E.err = "Illegal pair_style command"; return 1; }
             D.pair_mini = w[1] == "dpd/mini/meso";
+            D.pair_poly = w[1] == "dpd/polyforce/meso";
             if (D.mass.empty()) { E.err = "pair_style before read_data"; return 1; }
             if ((rc = E.set_mass(D.ntypes, D.mass.data()))) return rc;
-            if ((rc = E.pair_settings(D.pair_mini ? 2 : (w[1] == "dpd/fast/meso" ? 1 : 0), atof(w[2].c_str()), atoi(w[3].c_str())))) return rc;
+            if ((rc = E.pair_settings(D.pair_poly ? 3 : D.pair_mini ? 2 : (w[1] == "dpd/fast/meso" ? 1 : 0), atof(w[2].c_str()), atoi(w[3].c_str())))) return rc;
         } else if (c == "pair_coeff") {
             // dpd/mini/meso: pair_coeff * * a0 gamma sigma (pair_dpd_minimal_meso.cu:248-265); the others: ... s [rc]
-            if (D.pair_mini ? w.size() < 6 : (w.size() < 7 || w.size() > 8)) { E.err = "Incorrect args for pair coefficients"; return 1; }
+            // dpd/polyforce/meso: pair_coeff i j gamma sigma order c_order ... c_0 (pair_dpd_polyforce_meso.cu:290-335)
+            if (D.pair_poly ? (w.size() < 7 || (int)w.size() != 7 + atoi(w[5].c_str())) : D.pair_mini ? w.size() < 6 : (w.size() < 7 || w.size() > 8)) { E.err = "Incorrect args for pair coefficients"; return 1; }
             auto bounds = [&](const std::string &s, int &lo, int &hi) {
                 if (s == "*") { lo = 1; hi = D.ntypes; return; }
                 size_t star = s.find('*');
@@ -346,6 +348,13 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
             int count = 0;
             for (int i = ilo; i <= ihi; i++)
                 for (int j = std::max(jlo, i); j <= jhi; j++) {
+                    if (D.pair_poly) {
+                        std::vector<double> pc;
+                        for (size_t k = 6; k < w.size(); k++) pc.push_back(atof(w[k].c_str()));
+                        if ((rc = E.pair_coeff_poly(i, j, atof(w[3].c_str()), atof(w[4].c_str()), atoi(w[5].c_str()), pc.data()))) return rc;
+                        count++;
+                        continue;
+                    }
                     if ((rc = E.pair_coeff(i, j, atof(w[3].c_str()), atof(w[4].c_str()), atof(w[5].c_str()),
                                            w.size() > 6 ? atof(w[6].c_str()) : 1.0, w.size() == 8 ? atof(w[7].c_str()) : 0.0))) return rc;
                     count++;

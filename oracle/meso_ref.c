@@ -411,9 +411,19 @@ void meso_pair_dpd(int ibeg, int iend, const float *coord4, const float *veloc4,
 
 /* ---- gpu_dpd_fast<0>  pair_dpd_fast_meso.cu:91-205 ----------------------- */
 /* rng 0: gaussian_TEA_fast (dpd/fast/meso); rng 1: mean0var1<8> (gpu_dpd_mini pair_dpd_minimal_meso.cu:91-178, same force) */
+/* polyval  math_meso.h:53-58 (row = [order][c_order .. c_0]) */
+static float polyval_row(float x, const float *row)
+{
+    int order = (int)row[0];
+    float r = row[1];
+    for (int k = 0; k < order; k++) r = r * x + row[2 + k];
+    return r;
+}
+
+/* poly != NULL: gpu_dpd_polyforce pair_dpd_polyforce_meso.cu:91-205 - conservative force polyval(1 - r/rc), rows of 33 floats */
 void meso_pair_dpd_fast_rng(int ibeg, int iend, const float *coord4, const float *veloc4, const int *count,
                             const int *table, int stride, const float *coeff, int ntypes, float dt_inv_sqrt,
-                            double *fx, double *fy, double *fz, int rng)
+                            double *fx, double *fy, double *fz, int rng, const float *poly)
 {
 #pragma omp parallel for schedule(dynamic, 256)
     for (int i = ibeg; i < iend; i++) {
@@ -435,7 +445,8 @@ void meso_pair_dpd_fast_rng(int ibeg, int iend, const float *coord4, const float
                 float dot = dx * dvx + dy * dvy + dz * dvz;
                 float wc = 1.0f - r * cf[2];
                 float wr = powf(wc, cf[3]);
-                float fpair = cf[4] * wc - (cf[5] * wr * wr * dot * rinv) + (cf[6] * wr * rn * dt_inv_sqrt);
+                float fc = poly ? polyval_row(wc, poly + (t1 * ntypes + f2u(coord4[4 * j + 3])) * 33) : cf[4] * wc;
+                float fpair = fc - (cf[5] * wr * wr * dot * rinv) + (cf[6] * wr * rn * dt_inv_sqrt);
                 fpair *= rinv;
                 ax += dx * fpair; ay += dy * fpair; az += dz * fpair;
             }
@@ -448,7 +459,7 @@ void meso_pair_dpd_fast(int ibeg, int iend, const float *coord4, const float *ve
                         const int *table, int stride, const float *coeff, int ntypes, float dt_inv_sqrt,
                         double *fx, double *fy, double *fz)
 {
-    meso_pair_dpd_fast_rng(ibeg, iend, coord4, veloc4, count, table, stride, coeff, ntypes, dt_inv_sqrt, fx, fy, fz, 0);
+    meso_pair_dpd_fast_rng(ibeg, iend, coord4, veloc4, count, table, stride, coeff, ntypes, dt_inv_sqrt, fx, fy, fz, 0, NULL);
 }
 
 /* ---- fix nve/meso  fix_nve_meso.cu:62-95, 157-178 ------------------------ */

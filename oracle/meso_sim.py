@@ -62,6 +62,16 @@ class MesoRefSim:
     def pair_coeff(self, i, j, a0, gamma, sigma, expw=1.0, cut=1.0):
         self.coeffs[(min(i, j), max(i, j))] = (a0, gamma, sigma, expw, cut)
 
+    def pair_coeff_poly(self, i, j, gamma, sigma, coeffs, cut=1.0):
+        """pair_style dpd/polyforce/meso (construct with fast=True): conservative force polyval(1 - r/rc), coefficients from
+        the highest order down (MesoPairDPDPolyForce::coeff pair_dpd_polyforce_meso.cu:290-335)"""
+        self.coeffs[(min(i, j), max(i, j))] = (0.0, gamma, sigma, 1.0, cut)
+        if getattr(self, "poly", None) is None:
+            self.poly = np.zeros((self.ntypes, self.ntypes, 33), np.float32)
+        for a, b in ((i - 1, j - 1), (j - 1, i - 1)):
+            self.poly[a, b, 0] = len(coeffs) - 1
+            self.poly[a, b, 1:1 + len(coeffs)] = coeffs
+
     def set_bonds(self, bonds, coeffs, special=(0.0, 0.0, 0.0), style="harmonic"):
         """bonds (nb,3: tag_i, tag_j, type); coeffs {type: (k, r0)} (harmonic) or {type: (K, R0, epsilon, sigma)}
         (fene); special_bonds weights (0 = level excluded from the pair rows, gpu_filter_exclusion
@@ -219,7 +229,7 @@ class MesoRefSim:
         seed = self.M.meso_seed_now(self.seed, self.ntimestep)
         self.c4, self.v4 = self._merge(seed)
         self.f = ob.pair_dpd(self.n, self.c4, self.v4, self.count, self.table, self.coeff, self.ntypes,
-                             self.dt, fast=self.fast, rng=1 if self.mini else 0)
+                             self.dt, fast=self.fast, rng=1 if self.mini else 0, poly=getattr(self, "poly", None))
         self._bond_forces()
         self._angle_forces()
 
