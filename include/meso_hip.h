@@ -24,7 +24,7 @@ enum { MESO_OK = 0, MESO_ERR_ARG = 1, MESO_ERR_HIP = 2, MESO_ERR_STATE = 3, MESO
 /* pair styles: PairStyle(dpd/meso,MesoPairDPD) pair_dpd_meso.h:3 ; PairStyle(dpd/fast/meso,...) pair_dpd_fast_meso.h:3 */
 /* MESO_PAIR_DPD_MINI: PairStyle(dpd/mini/meso) pair_dpd_minimal_meso.h:3 - fp32 arithmetic, cutoff 1, one (a0, gamma, sigma)
  * for all types (pair_coeff * * a0 gamma sigma), pair noise from the logistic map mean0var1<8> (:50-89) instead of TEA */
-enum { MESO_PAIR_DPD = 0, MESO_PAIR_DPD_FAST = 1, MESO_PAIR_DPD_MINI = 2, MESO_PAIR_DPD_POLYFORCE = 3 };
+enum { MESO_PAIR_DPD = 0, MESO_PAIR_DPD_FAST = 1, MESO_PAIR_DPD_MINI = 2, MESO_PAIR_DPD_POLYFORCE = 3, MESO_PAIR_DPD_TABLEFORCE = 4 };
 /* work ranges, AtomAttribute::LOCAL/BULK/BORDER util_meso.h:43-74, resolve_work_range atom_vec_meso.cu:194-218 */
 enum { MESO_RANGE_LOCAL = 0, MESO_RANGE_BULK = 1, MESO_RANGE_BORDER = 2 };
 /* ghost transports */
@@ -85,6 +85,12 @@ int meso_pair_dpd_settings(meso_ctx *ctx, int style, double cut_global, int seed
  * force polyval(1 - r/rc) (Horner, c_order first; kernel :159-162, energy :176); pair_coeff i j gamma sigma order c_order..c_0
  * (:290-335), cutoff = the style's global cutoff, order < 32 */
 int meso_pair_dpd_polyforce_coeff(meso_ctx *ctx, int itype, int jtype, double gamma, double sigma, int order, const double *c);
+/* MESO_PAIR_DPD_TABLEFORCE: PairStyle(dpd/tableforce/meso) pair_dpd_tableforce_meso.h:3 - the fp32 kernel with the conservative
+ * force read from a table of table_length points uniform in r/rc over [0,1] (linear filter of the texture fetch :181, :291,
+ * weights to 8 fractional bits) and uniform TEA noise (:171); pair_coeff i j gamma sigma <table> (:306-356; the glue reads a
+ * file argument on the host).  No pair energy is booked (as in the reference kernel). */
+int meso_pair_dpd_tableforce_coeff(meso_ctx *ctx, int itype, int jtype, double gamma, double sigma, int table_length,
+                                   const double *table);
 int meso_pair_dpd_coeff(meso_ctx *ctx, int itype, int jtype, double a0, double gamma, double sigma, double expw,
                         double cut /* <=0: cut_global */);
 

@@ -99,6 +99,56 @@ void MesoHipPairDPDPolyForce::coeff(int narg, char **arg)
   if (count == 0) error->all(FLERR, "Incorrect args for pair coefficients");
 }
 
+MesoHipPairDPDTableForce::MesoHipPairDPDTableForce(LAMMPS *lmp) : MesoHipPairDPD(lmp), table_length(0) { style_id = MESO_PAIR_DPD_TABLEFORCE; }
+
+void MesoHipPairDPDTableForce::settings(int narg, char **arg)
+{
+  if (narg != 3) error->all(FLERR, "dpd/tableforce/meso command require: cut_global seed table_length");
+  cut_global = atof(arg[0]);
+  seed = atoi(arg[1]);
+  table_length = atoi(arg[2]);
+  MESO(meso_pair_dpd_settings(MesoHipContext::get(lmp), style_id, cut_global, seed));
+}
+
+void MesoHipPairDPDTableForce::coeff(int narg, char **arg)
+{
+  if (narg != 5 && narg != 4 + table_length)
+    error->all(FLERR, "Incorrect args for pair dpd/tableforce/meso: type1 type2 gamma sigma < fc_file_name | fc_table >");
+  int n = atom->ntypes;
+  if (!allocated) {
+    allocated = 1;
+    memory->create(setflag, n + 1, n + 1, "pair:setflag");
+    memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+    memory->create(cut, n + 1, n + 1, "pair:cut");
+    for (int i = 1; i <= n; i++)
+      for (int j = i; j <= n; j++) setflag[i][j] = 0;
+    MESO(meso_set_mass(MesoHipContext::get(lmp), n, atom->mass));
+  }
+  double *t = new double[table_length];
+  if (narg == 5) {   /* every rank reads the (small) file itself */
+    FILE *fp = fopen(arg[4], "r");
+    if (!fp) error->one(FLERR, "Cannot open force table file for dpd/tableforce/meso");
+    for (int k = 0; k < table_length; k++)
+      if (fscanf(fp, "%lf", &t[k]) != 1) error->one(FLERR, "Insufficient parameters in force table file for dpd/tableforce/meso");
+    fclose(fp);
+  } else {
+    for (int k = 0; k < table_length; k++) t[k] = atof(arg[4 + k]);
+  }
+  int ilo, ihi, jlo, jhi;
+  force->bounds(arg[0], n, ilo, ihi);
+  force->bounds(arg[1], n, jlo, jhi);
+  int count = 0;
+  for (int i = ilo; i <= ihi; i++)
+    for (int j = MAX(jlo, i); j <= jhi; j++) {
+      MESO(meso_pair_dpd_tableforce_coeff(MesoHipContext::get(lmp), i, j, atof(arg[2]), atof(arg[3]), table_length, t));
+      cut[i][j] = cut_global;
+      setflag[i][j] = 1;
+      count++;
+    }
+  delete [] t;
+  if (count == 0) error->all(FLERR, "Incorrect args for pair coefficients");
+}
+
 void MesoHipPairDPD::settings(int narg, char **arg)
 {
   if (narg != 2) error->all(FLERR, "Illegal pair_style command");

@@ -19,6 +19,7 @@ PairStyle(dpd/meso,MesoHipPairDPD)
 PairStyle(dpd/fast/meso,MesoHipPairDPDFast)
 PairStyle(dpd/mini/meso,MesoHipPairDPDMini)
 PairStyle(dpd/polyforce/meso,MesoHipPairDPDPolyForce)
+PairStyle(dpd/tableforce/meso,MesoHipPairDPDTableForce)
 #elif defined(BOND_CLASS)
 BondStyle(harmonic/meso,MesoHipBondHarmonic)
 BondStyle(fene/meso,MesoHipBondFENE)
@@ -89,6 +90,17 @@ class MesoHipPairDPDPolyForce : public MesoHipPairDPD {
  public:
   MesoHipPairDPDPolyForce(class LAMMPS *);
   void coeff(int, char **);            /* -> meso_pair_dpd_polyforce_coeff */
+};
+
+/* pair_style dpd/tableforce/meso rc seed table_length; pair_coeff i j gamma sigma < file | table_length values > (replaces
+   MesoPairDPDTableForce pair_dpd_tableforce_meso.h:3) */
+class MesoHipPairDPDTableForce : public MesoHipPairDPD {
+ public:
+  MesoHipPairDPDTableForce(class LAMMPS *);
+  void settings(int, char **);
+  void coeff(int, char **);            /* -> meso_pair_dpd_tableforce_coeff */
+ protected:
+  int table_length;
 };
 
 /* bond_style harmonic/meso (replaces MesoBondHarmonic, bond_harmonic_meso.h:3); the Bonds section is handed over once by

@@ -39,6 +39,7 @@ SIGNATURES = {
     "meso_pair_dpd_settings": (_i, [_vp, _i, _d, _i]),
     "meso_pair_dpd_coeff": (_i, [_vp, _i, _i, _d, _d, _d, _d, _d]),
     "meso_pair_dpd_polyforce_coeff": (_i, [_vp, _i, _i, _d, _d, _i, _vp]),
+    "meso_pair_dpd_tableforce_coeff": (_i, [_vp, _i, _i, _d, _d, _i, _vp]),
     "meso_special_bonds": (_i, [_vp, _d, _d, _d]),
     "meso_bonds_upload": (_i, [_vp, _i, _vp, _vp, _vp]),
     "meso_bond_style_harmonic": (_i, [_vp, _i]),

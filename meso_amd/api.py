@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib
 
-PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1, "dpd/mini/meso": 2, "dpd/polyforce/meso": 3}
+PAIR_STYLES = {"dpd/meso": 0, "dpd/fast/meso": 1, "dpd/mini/meso": 2, "dpd/polyforce/meso": 3, "dpd/tableforce/meso": 4}
 RANGES = {"local": 0, "bulk": 1, "border": 2}
 TRANSPORTS = {"self": 0, "rccl": 1, "host": 2, "local": 3}
 
@@ -147,6 +147,11 @@ class Meso:
         """dpd/polyforce/meso: pair_coeff i j gamma sigma order c_order ... c_0 (coeffs from the highest order down)"""
         c = np.ascontiguousarray(coeffs, np.float64)
         self._ck(self.lib.meso_pair_dpd_polyforce_coeff(self._h, i, j, gamma, sigma, len(c) - 1, _p(c)))
+
+    def pair_coeff_table(self, i, j, gamma, sigma, table):
+        """dpd/tableforce/meso: pair_coeff i j gamma sigma <table>: conservative force at table_length points uniform in r/rc"""
+        t = np.ascontiguousarray(table, np.float64)
+        self._ck(self.lib.meso_pair_dpd_tableforce_coeff(self._h, i, j, gamma, sigma, len(t), _p(t)))
 
     # -- bonded topology: atom_style dpd/bond/meso, bond_style harmonic/meso ---------------------
     def special_bonds(self, w12=0.0, w13=0.0, w14=0.0):

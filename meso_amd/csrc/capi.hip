@@ -135,6 +135,7 @@ int meso_atoms_download(meso_ctx *ctx, double *x, double *v, double *f, int *tag
 
 int meso_neighbor(meso_ctx *ctx, double skin, int every, int delay, int check) { CTX(ctx); RET(E.neighbor(skin, every, delay, check)); }
 int meso_pair_dpd_settings(meso_ctx *ctx, int style, double cut, int seed) { CTX(ctx); RET(E.pair_settings(style, cut, seed)); }
+int meso_pair_dpd_tableforce_coeff(meso_ctx *ctx, int i, int j, double gamma, double sigma, int len, const double *t) { CTX(ctx); RET(E.pair_coeff_table(i, j, gamma, sigma, len, t)); }
 int meso_pair_dpd_polyforce_coeff(meso_ctx *ctx, int i, int j, double gamma, double sigma, int order, const double *c) { CTX(ctx); RET(E.pair_coeff_poly(i, j, gamma, sigma, order, c)); }
 int meso_pair_dpd_coeff(meso_ctx *ctx, int i, int j, double a0, double gamma, double sigma, double expw, double cut)
 {

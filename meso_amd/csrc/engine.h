@@ -53,6 +53,7 @@ public:
     int compute_eangle(double *e);
     int pair_settings(int style, double cut, int seed);
     int pair_coeff_poly(int i, int j, double gamma, double sigma, int order, const double *c);
+    int pair_coeff_table(int i, int j, double gamma, double sigma, int len, const double *t);
     int pair_coeff(int i, int j, double a0, double gamma, double sigma, double expw, double cut);
     int set_option(const std::string &key, double val);
 
@@ -159,6 +160,10 @@ private:
     int every = 1, delay = 10, dist_check = 1;
     int groupbit = 1;
     int pair_style = 0, seed = 0, ntypes = 0;
+    bool pair_ftab = false;  // pair_style dpd/tableforce/meso: fp32 arithmetic, tabulated conservative force, uniform TEA noise
+    int ftab_len = 0;
+    std::vector<float> ftab; // [ntypes^2][ftab_len]
+    float *d_ftab = nullptr;
     bool pair_poly = false;  // pair_style dpd/polyforce/meso: fp32 arithmetic, polynomial conservative force
     std::vector<float> poly; // [ntypes^2][MESO_POLY_PITCH]
     float *d_poly = nullptr;

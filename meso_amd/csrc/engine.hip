@@ -74,7 +74,7 @@ void Engine::free_all()
     for (int k = 0; k < 6; k++) dfree(virial[k]);
     dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc);
     dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
-    dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly);
+    dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
     dfree(pair_count); dfree(pair_table);
     dfree(bin_id); dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(bin_start);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
@@ -206,11 +206,13 @@ int Engine::neighbor(double s, int ev, int dl, int chk)
 // MesoPairDPD::settings (pair_dpd_meso.cu:272-288): pair_style dpd/meso rc seed
 int Engine::pair_settings(int style, double cut, int sd)
 {
-    if (style < 0 || style > 3) return fail(1, "Illegal pair_style command");
+    if (style < 0 || style > 4) return fail(1, "Illegal pair_style command");
     if (!(cut > 0.0)) return fail(1, "Illegal pair_style command");
     // MesoPairDPDMini (pair_dpd_minimal_meso.cu:239-265): one global coefficient set, cutoff fixed at 1
     if (style == 2 && cut != 1.0) return fail(1, "pair_style dpd/mini/meso has a fixed cutoff of 1");
-    pair_rng = style == 2 ? 1 : 0;
+    pair_rng = style == 2 ? 1 : style == 4 ? 2 : 0;
+    pair_ftab = style == 4;          // MesoPairDPDTableForce: fp32 arithmetic, uniform TEA noise, tabulated conservative force
+    ftab.clear(); ftab_len = 0;
     pair_poly = style == 3;          // MesoPairDPDPolyForce: fp32 arithmetic, TEA noise, polynomial conservative force
     poly.clear();
     pair_style = style >= 2 ? 1 : style; cut_global = cut; seed = sd;
@@ -226,6 +228,7 @@ int Engine::pair_coeff(int i, int j, double a0, double gamma, double sigma, doub
     if (ntypes == 0) return fail(3, "pair_coeff before atom types are known");
     if (i < 1 || j < 1 || i > ntypes || j > ntypes) return fail(1, "Incorrect args for pair coefficients");
     if (pair_poly) return fail(1, "Incorrect args for pair coefficients: dpd/polyforce/meso takes gamma sigma order c_order ... c_0");
+    if (pair_ftab) return fail(1, "Incorrect args for pair dpd/tableforce/meso: type1 type2 gamma sigma < fc_file_name | fc_table >");
     if (cut <= 0.0) cut = cut_global;
     if (pair_rng) {
         // MesoPairDPDMini::coeff: a0, gamma, sigma are scalars of the style - every pair of types gets them, s = 1, rc = 1
@@ -269,6 +272,29 @@ int Engine::pair_coeff_poly(int i, int j, double gamma, double sigma, int order,
         float *row = &poly[((size_t)a * ntypes + b) * MESO_POLY_PITCH];
         row[0] = (float)order;
         for (int t = 0; t <= order; t++) row[1 + t] = (float)c[t];
+    }
+    have_coeff = true;
+    params_ready = false;
+    return 0;
+}
+
+// MesoPairDPDTableForce::coeff (pair_dpd_tableforce_meso.cu:306-356): pair_coeff i j gamma sigma < file | L values >; the
+// table length L is a setting of the style (:290) and therefore the same for every pair of types
+int Engine::pair_coeff_table(int i, int j, double gamma, double sigma, int len, const double *t)
+{
+    if (!have_pair || !pair_ftab) return fail(3, "force tables need pair_style dpd/tableforce/meso");
+    if (ntypes == 0) return fail(3, "pair_coeff before atom types are known");
+    if (i < 1 || j < 1 || i > ntypes || j > ntypes || !t || len < 2) return fail(1, "Incorrect args for pair coefficients");
+    if (ftab_len && len != ftab_len) return fail(1, "Incorrect args for pair dpd/tableforce/meso: every table has table_length entries");
+    ftab_len = len;
+    if (ftab.empty()) ftab.assign((size_t)ntypes * ntypes * len, 0.f);
+    for (int k = 0; k < 2; k++) {
+        int a = k ? j - 1 : i - 1, b = k ? i - 1 : j - 1;
+        double *q = &coeff[((size_t)a * ntypes + b) * N_COEFF];
+        q[P_CUT] = cut_global; q[P_CUTSQ] = cut_global * cut_global; q[P_CUTINV] = 1.0 / cut_global; q[P_EXPW] = 1.0;
+        q[P_A0] = 0.0; q[P_GAMMA] = gamma; q[P_SIGMA] = sigma;
+        coeff_set[(size_t)a * ntypes + b] = 1;
+        for (int e = 0; e < len; e++) ftab[((size_t)a * ntypes + b) * len + e] = (float)t[e];
     }
     have_coeff = true;
     params_ready = false;
@@ -861,6 +887,12 @@ int Engine::init_params()
     std::vector<float> c32(coeff.begin(), coeff.end());
     HIPCHK(hipMemcpy(d_coeff64, coeff.data(), coeff.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_coeff32, c32.data(), c32.size() * sizeof(float), hipMemcpyHostToDevice));
+    dfree(d_ftab);
+    if (pair_ftab) {
+        if (ftab.size() != (size_t)ntypes * ntypes * ftab_len || !ftab_len) return fail(3, "All pair coeffs are not set");
+        HIPCHK(dalloc(d_ftab, ftab.size()));
+        HIPCHK(hipMemcpy(d_ftab, ftab.data(), ftab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     dfree(d_poly);
     if (pair_poly) {
         if (poly.size() != (size_t)ntypes * ntypes * MESO_POLY_PITCH) return fail(3, "All pair coeffs are not set");
@@ -1181,6 +1213,8 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.nall = nlocal + nghost;
     p.rng = pair_rng;
     p.poly = pair_poly ? d_poly : nullptr;
+    p.ftab = pair_ftab ? d_ftab : nullptr;
+    p.ftab_len = ftab_len;
     p.all_expw_one = 1;
     p.share = (pair_share && (p.end == nlocal || (p.end & (pair_ring_group() - 1)) == 0)) ? 1 : 0;
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
@@ -1235,8 +1269,8 @@ int Engine::setup()
 {
     if (nlocal <= 0 && nranks == 1) return fail(3, "No atoms have been uploaded");
     if (have_bonds && layout != 2) return fail(3, "bonded topology needs the cell-ordered layout (layout=2)");
-    if ((pair_rng || pair_poly) && !ring_selected())
-        return fail(3, "pair styles dpd/mini/meso and dpd/polyforce/meso run on the default force kernel only (layout=2, pair_kernel=2)");
+    if ((pair_rng || pair_poly || pair_ftab) && !ring_selected())
+        return fail(3, "pair styles dpd/mini/meso, dpd/polyforce/meso and dpd/tableforce/meso run on the default force kernel only (layout=2, pair_kernel=2)");
     TRY(init_params());
     TRY(reneighbor());
     nbuild = 0;

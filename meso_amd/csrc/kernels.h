@@ -128,8 +128,10 @@ struct PairArgs {
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
     int nall;             // atoms in coord4/veloc4 (locals + ghosts): bound of the buffer-addressed gathers
     int all_expw_one;     // every pair type has weight exponent 1 (no pow() in the kernel)
+    const float *ftab;    // dpd/tableforce/meso: [ntypes^2][ftab_len] conservative-force tables over r/rc in [0,1]; null otherwise
+    int ftab_len;
     const float *poly;    // dpd/polyforce/meso: [ntypes^2][MESO_POLY_PITCH] conservative-force polynomials; null otherwise
-    int rng;              // fp32 styles: 0 TEA Gaussian (dpd/fast/meso), 1 logistic map (dpd/mini/meso)
+    int rng;              // fp32 styles: 0 TEA Gaussian (dpd/fast/meso), 1 logistic map (dpd/mini/meso), 2 TEA uniform (tableforce)
     int share;            // ring kernel: Newton pairing inside a workgroup allowed (end == nlocal or a multiple of 256)
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;

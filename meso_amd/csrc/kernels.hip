@@ -922,13 +922,16 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
                 float ew = cf[P_EXPW];
                 float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
                 const float *prow = a.poly ? a.poly + (t1 * a.ntypes + __float_as_uint(c2.w)) * MESO_POLY_PITCH : nullptr;
-                float fpair = (prow ? polyval_f32(wc, prow) : cf[P_A0] * wc) - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis);
+                float fcons = prow ? polyval_f32(wc, prow) : cf[P_A0] * wc;
+                if (a.ftab) fcons = table_force_f32(r * cf[P_CUTINV], a.ftab + (t1 * a.ntypes + __float_as_uint(c2.w)) * a.ftab_len, a.ftab_len);
+                float fpair = fcons - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis);
                 fpair *= rinv;
                 fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
                 if (EV) {
                     vr[0] += dx * dx * fpair; vr[1] += dy * dy * fpair; vr[2] += dz * dz * fpair;
                     vr[3] += dx * dy * fpair; vr[4] += dx * dz * fpair; vr[5] += dy * dz * fpair;
-                    energy += prow ? polyval_integral_f32(wc, prow) : 0.5f * cf[P_A0] * cf[P_CUT] * wc * wc;   // (:176)
+                    // (polyforce :176; the tableforce kernel books no pair energy, pair_dpd_tableforce_meso.cu:191-198)
+                    energy += a.ftab ? 0.f : prow ? polyval_integral_f32(wc, prow) : 0.5f * cf[P_A0] * cf[P_CUT] * wc * wc;
                 }
             }
         }

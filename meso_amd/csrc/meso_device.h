@@ -230,8 +230,34 @@ __device__ inline float logistic_noise(u32 u, u32 v)
     for (int k = 0; k < 4; k++) x = logistic_round_rz(x);
     return x * 1.41421356237309514547f;
 }
-// the pair noise of the fp32 styles: rng 0 = TEA-keyed Gaussian (dpd/fast/meso), 1 = logistic map (dpd/mini/meso)
-__device__ inline float pair_noise_fast(int rng, u32 u, u32 v) { return rng ? logistic_noise(u, v) : gaussian_tea_fast(u, v); }
+// uniform_TEA_fast<4> (math_meso.h:501-505): uniform on [-sqrt 3, sqrt 3) (variance 1), the noise of dpd/tableforce/meso;
+// called with (min, max) of the two signatures (pair_dpd_tableforce_meso.cu:171)
+__device__ inline float uniform_tea_fast(u32 u, u32 v)
+{
+    u32 v0 = u < v ? u : v, v1 = u < v ? v : u;
+    tea_core<4>(v0, v1);
+    return (float)(v0 ^ v1) * (float)(1.73205080756887729353 * MESO_2_TO_MINUS_31) - (float)1.73205080756887729353;
+}
+// the pair noise of the fp32 styles: rng 0 = TEA-keyed Gaussian (dpd/fast/meso), 1 = logistic map (dpd/mini/meso),
+// 2 = TEA-keyed uniform (dpd/tableforce/meso)
+__device__ inline float pair_noise_fast(int rng, u32 u, u32 v)
+{
+    return rng == 1 ? logistic_noise(u, v) : rng == 2 ? uniform_tea_fast(u, v) : gaussian_tea_fast(u, v);
+}
+// dpd/tableforce/meso: the conservative force is read from a table of L points, uniform in r/rc over [0,1], with the linear
+// filter of the texture unit the reference samples it with (tex1DLayered, clamp addressing, pair_dpd_tableforce_meso.cu:81-84,
+// :181, coordinate transform :291): position x = (r/rc)(L-1), weight frac(x) kept to 8 fractional bits as the CUDA
+// programming guide defines linear filtering
+__host__ __device__ inline float table_force_f32(float rrinv, const float *tab, int len)
+{
+    float x = rrinv * (float)(len - 1);
+    x = x < 0.f ? 0.f : x;
+    int i = (int)x;
+    if (i > len - 1) i = len - 1;
+    const int i1 = i + 1 < len ? i + 1 : len - 1;
+    const float al = floorf((x - (float)i) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    return (1.0f - al) * tab[i] + al * tab[i1];
+}
 
 // pair_style dpd/polyforce/meso: the conservative force is a polynomial in w = 1 - r/rc, Horner from the highest order
 // (polyval / polyval_integral, math_meso.h:53-66); table row = [order][c_order .. c_0], MESO_POLY_PITCH floats per type pair

@@ -134,6 +134,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                     float fcons = c_a0 * wc;
                     if (a.poly)      // dpd/polyforce/meso (gpu_dpd_polyforce pair_dpd_polyforce_meso.cu:159-162)
                         fcons = polyval_f32(wc, a.poly + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * MESO_POLY_PITCH));
+                    if (a.ftab)      // dpd/tableforce/meso (gpu_dpd_tableforce pair_dpd_tableforce_meso.cu:181)
+                        fcons = table_force_f32(r * c_cutinv, a.ftab + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * a.ftab_len), a.ftab_len);
                     float fpair = fcons - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
                     fpair *= rinv;
                     qx = to_fixed(dx * fpair); qy = to_fixed(dy * fpair); qz = to_fixed(dz * fpair);

@@ -67,6 +67,7 @@ struct Deck {
     std::vector<int> tag, type;
     int nbonds = 0, nbondtypes = 0;
     bool bond_fene = false, pair_mini = false, pair_poly = false;
+    int table_len = 0;
     std::vector<int> bond_i, bond_j, bond_t;
     int nangles = 0, nangletypes = 0;
     std::vector<int> ang_1, ang_2, ang_3, ang_t;
@@ -325,7 +326,20 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
             if (w.size() != 2 || (w[1] != "mvv/meso" && w[1] != "verlet/meso")) { E.err = "Illegal run_style command"; return 1; }
             D.run_style = w[1];
         } else if (c == "pair_style") {
-            if (w.size() != 4 || (w[1] != "dpd/meso" && w[1] != "dpd/fast/meso" && w[1] != "dpd/mini/meso" && w[1] != "dpd/polyforce/meso")) { E.err = "Illegal pair_style command"; return 1; }
+            if (w.size() != 4 || (w[1] != "dpd/meso" && w[1] != "dpd/fast/meso" && w[1] != "dpd/mini/meso" && w[1] != "dpd/polyforce/meso")) {
+                // pair_style dpd/tableforce/meso cut_global seed table_length (pair_dpd_tableforce_meso.cu:284-291)
+                if (w.size() == 5 && w[1] == "dpd/tableforce/meso") {
+                    if (D.mass.empty()) { E.err = "pair_style before read_data"; return 1; }
+                    if ((rc = E.set_mass(D.ntypes, D.mass.data()))) return rc;
+                    D.pair_mini = D.pair_poly = false;
+                    D.table_len = atoi(w[4].c_str());
+                    if (D.table_len < 2) { E.err = "dpd/tableforce/meso command require: cut_global seed table_length"; return 1; }
+                    if ((rc = E.pair_settings(4, atof(w[2].c_str()), atoi(w[3].c_str())))) return rc;
+                    continue;
+                }
+                E.err = "Illegal pair_style command"; return 1;
+            }
+            D.table_len = 0;
             D.pair_mini = w[1] == "dpd/mini/meso";
             D.pair_poly = w[1] == "dpd/polyforce/meso";
             if (D.mass.empty()) { E.err = "pair_style before read_data"; return 1; }
@@ -334,7 +348,7 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
         } else if (c == "pair_coeff") {
             // dpd/mini/meso: pair_coeff * * a0 gamma sigma (pair_dpd_minimal_meso.cu:248-265); the others: ... s [rc]
             // dpd/polyforce/meso: pair_coeff i j gamma sigma order c_order ... c_0 (pair_dpd_polyforce_meso.cu:290-335)
-            if (D.pair_poly ? (w.size() < 7 || (int)w.size() != 7 + atoi(w[5].c_str())) : D.pair_mini ? w.size() < 6 : (w.size() < 7 || w.size() > 8)) { E.err = "Incorrect args for pair coefficients"; return 1; }
+            if (D.table_len ? (w.size() != 6 && (int)w.size() != 5 + D.table_len) : D.pair_poly ? (w.size() < 7 || (int)w.size() != 7 + atoi(w[5].c_str())) : D.pair_mini ? w.size() < 6 : (w.size() < 7 || w.size() > 8)) { E.err = "Incorrect args for pair coefficients"; return 1; }
             auto bounds = [&](const std::string &s, int &lo, int &hi) {
                 if (s == "*") { lo = 1; hi = D.ntypes; return; }
                 size_t star = s.find('*');
@@ -348,6 +362,22 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
             int count = 0;
             for (int i = ilo; i <= ihi; i++)
                 for (int j = std::max(jlo, i); j <= jhi; j++) {
+                    if (D.table_len) {
+                        // pair_coeff i j gamma sigma < file | table_length values > (pair_dpd_tableforce_meso.cu:306-356)
+                        std::vector<double> tb;
+                        if (w.size() == 6) {
+                            std::ifstream ft(w[5]);
+                            if (!ft) { E.err = "Cannot open force table file for dpd/tableforce/meso"; return 1; }
+                            double val;
+                            while ((int)tb.size() < D.table_len && (ft >> val)) tb.push_back(val);
+                            if ((int)tb.size() < D.table_len) { E.err = "Insufficient parameters in force table file for dpd/tableforce/meso"; return 1; }
+                        } else {
+                            for (size_t k = 5; k < w.size(); k++) tb.push_back(atof(w[k].c_str()));
+                        }
+                        if ((rc = E.pair_coeff_table(i, j, atof(w[3].c_str()), atof(w[4].c_str()), (int)tb.size(), tb.data()))) return rc;
+                        count++;
+                        continue;
+                    }
                     if (D.pair_poly) {
                         std::vector<double> pc;
                         for (size_t k = 6; k < w.size(); k++) pc.push_back(atof(w[k].c_str()));

@@ -152,10 +152,12 @@ def meso_lib():
         M.meso_neigh_full.argtypes = [_i, _i, _vp, _f, _vp, _vp, _i]
         M.meso_pair_dpd.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp, _i]
         M.meso_pair_dpd_fast.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp]
-        M.meso_pair_dpd_fast_rng.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _vp]
+        M.meso_pair_dpd_fast_rng.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _i]
         M.meso_pair_dpd_fast_rng.restype = None
         M.meso_logistic_noise.restype = _f
         M.meso_logistic_noise.argtypes = [_u, _u]
+        M.meso_uniform_tea_fast.restype = _f
+        M.meso_uniform_tea_fast.argtypes = [_u, _u]
         M.meso_nve_initial.argtypes = [_i] + [_vp] * 11 + [_d, _d, _i]
         M.meso_nve_final.argtypes = [_i] + [_vp] * 8 + [_d, _i]
         M.meso_sum_mv2.restype = _d
@@ -208,7 +210,7 @@ def make_coeff(ntypes, entries, dtype=np.float64):
     return np.ascontiguousarray(cf.reshape(-1), dtype=dtype)
 
 
-def pair_dpd(nlocal, coord4, veloc4, count, table, coeff, ntypes, dt, fast=False, ev=False, rng=0, poly=None):
+def pair_dpd(nlocal, coord4, veloc4, count, table, coeff, ntypes, dt, fast=False, ev=False, rng=0, poly=None, ftab=None):
     """Forces on atoms [0,nlocal) (newton off, full list). Returns f (nlocal,3) [, e_pair, virial]."""
     M = meso_lib()
     fx = np.zeros(nlocal); fy = np.zeros(nlocal); fz = np.zeros(nlocal)
@@ -219,7 +221,9 @@ def pair_dpd(nlocal, coord4, veloc4, count, table, coeff, ntypes, dt, fast=False
         cf = np.ascontiguousarray(coeff, dtype=np.float32)
         M.meso_pair_dpd_fast_rng(0, nlocal, _ptr(coord4), _ptr(veloc4), _ptr(count), _ptr(table), stride,
                                  _ptr(cf), ntypes, np.float32(1.0 / np.sqrt(dt)), _ptr(fx), _ptr(fy), _ptr(fz), int(rng),
-                                 None if poly is None else _ptr(np.ascontiguousarray(poly, dtype=np.float32)))
+                                 None if poly is None else _ptr(np.ascontiguousarray(poly, dtype=np.float32)),
+                                 None if ftab is None else _ptr(np.ascontiguousarray(ftab, dtype=np.float32)),
+                                 0 if ftab is None else int(np.asarray(ftab).shape[-1]))
         return np.stack([fx, fy, fz], axis=1)
     cf = np.ascontiguousarray(coeff, dtype=np.float64)
     e = np.zeros(nlocal) if ev else None

@@ -420,10 +420,31 @@ static float polyval_row(float x, const float *row)
     return r;
 }
 
+/* uniform_TEA_fast<4>  math_meso.h:501-505, arguments (min, max) as at its call site pair_dpd_tableforce_meso.cu:171 */
+float meso_uniform_tea_fast(uint u, uint v)
+{
+    uint v0 = u < v ? u : v, v1 = u < v ? v : u;
+    meso_tea_core(4, &v0, &v1);
+    return (float)(v0 ^ v1) * (float)(1.73205080756887729353 * TWO_TO_MINUS_31) - (float)1.73205080756887729353;
+}
+
+/* the texture fetch of gpu_dpd_tableforce (:181; linear filter, clamp, coordinate transform :291): L points uniform in r/rc,
+ * interpolation weight with 8 fractional bits (CUDA programming guide, linear filtering) */
+static float table_force(float rrinv, const float *tab, int len)
+{
+    float x = rrinv * (float)(len - 1);
+    if (x < 0.f) x = 0.f;
+    int i = (int)x;
+    if (i > len - 1) i = len - 1;
+    int i1 = i + 1 < len ? i + 1 : len - 1;
+    float al = floorf((x - (float)i) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    return (1.0f - al) * tab[i] + al * tab[i1];
+}
+
 /* poly != NULL: gpu_dpd_polyforce pair_dpd_polyforce_meso.cu:91-205 - conservative force polyval(1 - r/rc), rows of 33 floats */
 void meso_pair_dpd_fast_rng(int ibeg, int iend, const float *coord4, const float *veloc4, const int *count,
                             const int *table, int stride, const float *coeff, int ntypes, float dt_inv_sqrt,
-                            double *fx, double *fy, double *fz, int rng, const float *poly)
+                            double *fx, double *fy, double *fz, int rng, const float *poly, const float *ftab, int ftab_len)
 {
 #pragma omp parallel for schedule(dynamic, 256)
     for (int i = ibeg; i < iend; i++) {
@@ -438,7 +459,8 @@ void meso_pair_dpd_fast_rng(int ibeg, int iend, const float *coord4, const float
             float rsq = dx * dx + dy * dy + dz * dz;
             const float *cf = coeff + (t1 * ntypes + f2u(coord4[4 * j + 3])) * 7;
             if (rsq < cf[1] && (double)rsq >= EPSILON_SQ) {
-                float rn = rng ? meso_logistic_noise(s1, f2u(veloc4[4 * j + 3])) : meso_gaussian_tea_fast(s1, f2u(veloc4[4 * j + 3]));
+                uint s2 = f2u(veloc4[4 * j + 3]);
+                float rn = rng == 1 ? meso_logistic_noise(s1, s2) : rng == 2 ? meso_uniform_tea_fast(s1, s2) : meso_gaussian_tea_fast(s1, s2);
                 float rinv = 1.0f / sqrtf(rsq);
                 float r = rsq * rinv;
                 float dvx = v1x - veloc4[4 * j], dvy = v1y - veloc4[4 * j + 1], dvz = v1z - veloc4[4 * j + 2];
@@ -446,6 +468,7 @@ void meso_pair_dpd_fast_rng(int ibeg, int iend, const float *coord4, const float
                 float wc = 1.0f - r * cf[2];
                 float wr = powf(wc, cf[3]);
                 float fc = poly ? polyval_row(wc, poly + (t1 * ntypes + f2u(coord4[4 * j + 3])) * 33) : cf[4] * wc;
+                if (ftab) fc = table_force(r * cf[2], ftab + (t1 * ntypes + f2u(coord4[4 * j + 3])) * ftab_len, ftab_len);
                 float fpair = fc - (cf[5] * wr * wr * dot * rinv) + (cf[6] * wr * rn * dt_inv_sqrt);
                 fpair *= rinv;
                 ax += dx * fpair; ay += dy * fpair; az += dz * fpair;
@@ -459,7 +482,7 @@ void meso_pair_dpd_fast(int ibeg, int iend, const float *coord4, const float *ve
                         const int *table, int stride, const float *coeff, int ntypes, float dt_inv_sqrt,
                         double *fx, double *fy, double *fz)
 {
-    meso_pair_dpd_fast_rng(ibeg, iend, coord4, veloc4, count, table, stride, coeff, ntypes, dt_inv_sqrt, fx, fy, fz, 0, NULL);
+    meso_pair_dpd_fast_rng(ibeg, iend, coord4, veloc4, count, table, stride, coeff, ntypes, dt_inv_sqrt, fx, fy, fz, 0, NULL, NULL, 0);
 }
 
 /* ---- fix nve/meso  fix_nve_meso.cu:62-95, 157-178 ------------------------ */

@@ -72,6 +72,15 @@ class MesoRefSim:
             self.poly[a, b, 0] = len(coeffs) - 1
             self.poly[a, b, 1:1 + len(coeffs)] = coeffs
 
+    def pair_coeff_table(self, i, j, gamma, sigma, table, cut=1.0):
+        """pair_style dpd/tableforce/meso (construct with fast=True): tabulated conservative force over r/rc in [0,1], uniform
+        TEA noise (MesoPairDPDTableForce::coeff pair_dpd_tableforce_meso.cu:306-356, kernel :171-184)"""
+        self.coeffs[(min(i, j), max(i, j))] = (0.0, gamma, sigma, 1.0, cut)
+        if getattr(self, "ftab", None) is None:
+            self.ftab = np.zeros((self.ntypes, self.ntypes, len(table)), np.float32)
+        for a, b in ((i - 1, j - 1), (j - 1, i - 1)):
+            self.ftab[a, b] = table
+
     def set_bonds(self, bonds, coeffs, special=(0.0, 0.0, 0.0), style="harmonic"):
         """bonds (nb,3: tag_i, tag_j, type); coeffs {type: (k, r0)} (harmonic) or {type: (K, R0, epsilon, sigma)}
         (fene); special_bonds weights (0 = level excluded from the pair rows, gpu_filter_exclusion
@@ -229,7 +238,8 @@ class MesoRefSim:
         seed = self.M.meso_seed_now(self.seed, self.ntimestep)
         self.c4, self.v4 = self._merge(seed)
         self.f = ob.pair_dpd(self.n, self.c4, self.v4, self.count, self.table, self.coeff, self.ntypes,
-                             self.dt, fast=self.fast, rng=1 if self.mini else 0, poly=getattr(self, "poly", None))
+                             self.dt, fast=self.fast, rng=1 if self.mini else (2 if getattr(self, "ftab", None) is not None else 0),
+                             poly=getattr(self, "poly", None), ftab=getattr(self, "ftab", None))
         self._bond_forces()
         self._angle_forces()
 
