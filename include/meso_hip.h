@@ -151,6 +151,19 @@ int meso_timer_reset(meso_ctx *ctx);
 int meso_timer_get(meso_ctx *ctx, const char *name, double *ms, int64_t *calls);
 int64_t meso_ntimestep(meso_ctx *ctx);
 
+/* ---- restart files and profiler window.  Inside LAMMPS the restart file is LAMMPS' own (the glue's
+ *      Pair::write_restart keeps MesoPairDPD::write_restart's layout, pair_dpd_meso.cu:363-447).  The stand-alone driver
+ *      writes one file per rank (path, or path.<rank> with several ranks) holding settings, coefficients and the per-atom
+ *      arrays as they live on the device, forces included; meso_read_restart + meso_setup continue a run bit for bit when the
+ *      file was written on a neighbour-rebuild step.
+ *      meso_profile_window: MesoDevice::configure_profiler (engine_meso.cu:155-177); mode 0 off, 1 all, 2 core (the middle
+ *      half of a run), 3 loop (the whole run), 4 interval [start, end) in absolute timesteps - collection of an attached
+ *      rocprofv3 is paused outside the window (roctxProfilerPause/Resume, looked up at run time). */
+enum { MESO_PROFILE_OFF = 0, MESO_PROFILE_ALL = 1, MESO_PROFILE_CORE = 2, MESO_PROFILE_LOOP = 3, MESO_PROFILE_INTERVAL = 4 };
+int meso_write_restart(meso_ctx *ctx, const char *path);
+int meso_read_restart(meso_ctx *ctx, const char *path);
+int meso_profile_window(meso_ctx *ctx, int mode, int64_t start_step, int64_t end_step);
+
 /* ---- known-answer kernels (math_meso.h:444-484) on caller-provided host arrays */
 int meso_test_tea(meso_ctx *ctx, int n, int rounds, const uint32_t *u, const uint32_t *v, uint32_t *out0,
                   uint32_t *out1);

@@ -43,7 +43,7 @@ MesoHipPairDPD::MesoHipPairDPD(LAMMPS *lmp) : Pair(lmp)
 {
   split_flag = 1;
   style_id = MESO_PAIR_DPD;
-  cut = NULL;
+  cut = a0 = gamma = sigma = expw = NULL;
 }
 
 MesoHipPairDPDFast::MesoHipPairDPDFast(LAMMPS *lmp) : MesoHipPairDPD(lmp) { style_id = MESO_PAIR_DPD_FAST; }
@@ -157,19 +157,27 @@ void MesoHipPairDPD::settings(int narg, char **arg)
   MESO(meso_pair_dpd_settings(MesoHipContext::get(lmp), style_id, cut_global, seed));
 }
 
+void MesoHipPairDPD::allocate()
+{
+  allocated = 1;
+  int n = atom->ntypes;
+  memory->create(setflag, n + 1, n + 1, "pair:setflag");
+  memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+  memory->create(cut, n + 1, n + 1, "pair:cut");
+  memory->create(a0, n + 1, n + 1, "pair:a0");
+  memory->create(gamma, n + 1, n + 1, "pair:gamma");
+  memory->create(sigma, n + 1, n + 1, "pair:sigma");
+  memory->create(expw, n + 1, n + 1, "pair:expw");
+  for (int i = 1; i <= n; i++)
+    for (int j = i; j <= n; j++) setflag[i][j] = 0;
+  MESO(meso_set_mass(MesoHipContext::get(lmp), n, atom->mass));
+}
+
 void MesoHipPairDPD::coeff(int narg, char **arg)
 {
   if (narg < 6 || narg > 7) error->all(FLERR, "Incorrect args for pair coefficients");
   int n = atom->ntypes;
-  if (!allocated) {
-    allocated = 1;
-    memory->create(setflag, n + 1, n + 1, "pair:setflag");
-    memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
-    memory->create(cut, n + 1, n + 1, "pair:cut");
-    for (int i = 1; i <= n; i++)
-      for (int j = i; j <= n; j++) setflag[i][j] = 0;
-    MESO(meso_set_mass(MesoHipContext::get(lmp), n, atom->mass));
-  }
+  if (!allocated) allocate();
   int ilo, ihi, jlo, jhi;
   force->bounds(arg[0], n, ilo, ihi);
   force->bounds(arg[1], n, jlo, jhi);
@@ -178,11 +186,70 @@ void MesoHipPairDPD::coeff(int narg, char **arg)
   for (int i = ilo; i <= ihi; i++)
     for (int j = MAX(jlo, i); j <= jhi; j++) {
       MESO(meso_pair_dpd_coeff(MesoHipContext::get(lmp), i, j, atof(arg[2]), atof(arg[3]), atof(arg[4]), atof(arg[5]), cut_one));
+      a0[i][j] = atof(arg[2]); gamma[i][j] = atof(arg[3]); sigma[i][j] = atof(arg[4]); expw[i][j] = atof(arg[5]);
       cut[i][j] = cut_one;
       setflag[i][j] = 1;
       count++;
     }
   if (count == 0) error->all(FLERR, "Incorrect args for pair coefficients");
+}
+
+/* MesoPairDPD::write_restart (pair_dpd_meso.cu:363-380): per i <= j: setflag, then a0 gamma sigma expw cut */
+void MesoHipPairDPD::write_restart(FILE *fp)
+{
+  write_restart_settings(fp);
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = i; j <= atom->ntypes; j++) {
+      fwrite(&setflag[i][j], sizeof(int), 1, fp);
+      if (setflag[i][j]) {
+        fwrite(&a0[i][j], sizeof(double), 1, fp);
+        fwrite(&gamma[i][j], sizeof(double), 1, fp);
+        fwrite(&sigma[i][j], sizeof(double), 1, fp);
+        fwrite(&expw[i][j], sizeof(double), 1, fp);
+        fwrite(&cut[i][j], sizeof(double), 1, fp);
+      }
+    }
+}
+
+/* MesoPairDPD::read_restart (:386-415): proc 0 reads, everybody gets the values and hands them to the library */
+void MesoHipPairDPD::read_restart(FILE *fp)
+{
+  read_restart_settings(fp);
+  if (!allocated) allocate();
+  int me = comm->me;
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = i; j <= atom->ntypes; j++) {
+      if (me == 0) fread(&setflag[i][j], sizeof(int), 1, fp);
+      MPI_Bcast(&setflag[i][j], 1, MPI_INT, 0, world);
+      if (setflag[i][j]) {
+        double v[5];
+        if (me == 0) fread(v, sizeof(double), 5, fp);
+        MPI_Bcast(v, 5, MPI_DOUBLE, 0, world);
+        a0[i][j] = v[0]; gamma[i][j] = v[1]; sigma[i][j] = v[2]; expw[i][j] = v[3]; cut[i][j] = v[4];
+        MESO(meso_pair_dpd_coeff(MesoHipContext::get(lmp), i, j, v[0], v[1], v[2], v[3], v[4]));
+      }
+    }
+}
+
+/* :421-426 / :432-446: cut_global, seed, mix_flag */
+void MesoHipPairDPD::write_restart_settings(FILE *fp)
+{
+  fwrite(&cut_global, sizeof(double), 1, fp);
+  fwrite(&seed, sizeof(int), 1, fp);
+  fwrite(&mix_flag, sizeof(int), 1, fp);
+}
+
+void MesoHipPairDPD::read_restart_settings(FILE *fp)
+{
+  if (comm->me == 0) {
+    fread(&cut_global, sizeof(double), 1, fp);
+    fread(&seed, sizeof(int), 1, fp);
+    fread(&mix_flag, sizeof(int), 1, fp);
+  }
+  MPI_Bcast(&cut_global, 1, MPI_DOUBLE, 0, world);
+  MPI_Bcast(&seed, 1, MPI_INT, 0, world);
+  MPI_Bcast(&mix_flag, 1, MPI_INT, 0, world);
+  MESO(meso_pair_dpd_settings(MesoHipContext::get(lmp), style_id, cut_global, seed));
 }
 
 void MesoHipPairDPD::init_style() {}   /* the neighbour table is built inside the library (meso_reneighbor) */

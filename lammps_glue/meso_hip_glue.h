@@ -64,11 +64,17 @@ class MesoHipPairDPD : public Pair {
   void coeff(int, char **);            /* pair_coeff i j a0 gamma sigma s [rc]  -> meso_pair_dpd_coeff */
   void init_style();
   double init_one(int, int);
+  /* restart file records with the byte layout of MesoPairDPD::write_restart / write_restart_settings (pair_dpd_meso.cu:363-447) */
+  void write_restart(FILE *);
+  void read_restart(FILE *);
+  void write_restart_settings(FILE *);
+  void read_restart_settings(FILE *);
  protected:
+  void allocate();
   int style_id;                        /* MESO_PAIR_DPD or MESO_PAIR_DPD_FAST */
   double cut_global;
   int seed;
-  double **cut;
+  double **cut, **a0, **gamma, **sigma, **expw;     /* host copies for the restart file; the library holds the working tables */
 };
 
 class MesoHipPairDPDFast : public MesoHipPairDPD {

@@ -76,6 +76,9 @@ SIGNATURES = {
     "meso_test_tea": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "meso_test_gaussian": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "meso_test_logistic": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "meso_write_restart": (_i, [_vp, C.c_char_p]),
+    "meso_read_restart": (_i, [_vp, C.c_char_p]),
+    "meso_profile_window": (_i, [_vp, _i, C.c_int64, C.c_int64]),
     "meso_seed_now": (_u32, [_i, _i64]),
     "meso_script_run": (_i, [_vp, _cp, _cp, _cp, _cp, _sz]),
 }

@@ -340,6 +340,17 @@ class Meso:
         self._ck(self.lib.meso_test_gaussian(self._h, len(u), _p(u), _p(v), _p(dp), _p(sp)))
         return dp, sp
 
+    def write_restart(self, path):
+        self._ck(self.lib.meso_write_restart(self._h, str(path).encode()))
+
+    def read_restart(self, path):
+        self._ck(self.lib.meso_read_restart(self._h, str(path).encode()))
+        self._setup_done = False
+
+    def profile_window(self, mode, start=0, end=0):
+        modes = {"off": 0, "all": 1, "core": 2, "loop": 3, "interval": 4}
+        self._ck(self.lib.meso_profile_window(self._h, modes[mode], start, end))
+
     def logistic(self, u, v):
         u = np.ascontiguousarray(u, np.uint32); v = np.ascontiguousarray(v, np.uint32)
         sp = np.empty(len(u), np.float32)

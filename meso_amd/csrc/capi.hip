@@ -228,6 +228,9 @@ int meso_test_gaussian(meso_ctx *ctx, int n, const uint32_t *u, const uint32_t *
     if (n < 0 || !u || !v || !odp || !osp) return set_err(MESO_ERR_ARG, "invalid test buffers");
     RET(E.test_gaussian(n, u, v, odp, osp));
 }
+int meso_write_restart(meso_ctx *ctx, const char *path) { CTX(ctx); if (!path) return set_err(MESO_ERR_ARG, "null path"); RET(E.write_restart(path)); }
+int meso_read_restart(meso_ctx *ctx, const char *path) { CTX(ctx); if (!path) return set_err(MESO_ERR_ARG, "null path"); RET(E.read_restart(path)); }
+int meso_profile_window(meso_ctx *ctx, int mode, int64_t start, int64_t end) { CTX(ctx); RET(E.profile_window(mode, start, end)); }
 int meso_test_logistic(meso_ctx *ctx, int n, const uint32_t *u, const uint32_t *v, float *out)
 {
     CTX(ctx);

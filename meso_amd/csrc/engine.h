@@ -45,6 +45,24 @@ public:
     int bond_coeff(int type, double k, double r0, double eps = 0.0, double sigma = 0.0);
     int bond_compute(int eflag);
     int compute_ebond(double *e);
+    // restart.hip: per-rank restart files of the stand-alone driver, profiler window (-profile all|core|loop|interval)
+    int write_restart(const std::string &path);
+    int read_restart(const std::string &path);
+    // what the script driver needs to know after read_restart
+    int restart_ntypes() const { return ntypes; }
+    const std::vector<double> &restart_masses() const { return mass_type; }
+    void restart_box(double *lo, double *hi, int *per) const
+    {
+        for (int d = 0; d < 3; d++) { lo[d] = boxlo[d]; hi[d] = boxhi[d]; per[d] = periodic[d]; }
+    }
+    int profile_window(int mode, int64_t start, int64_t end);
+    void profile_tick(int it, int nsteps);
+    int prof_mode = 0, prof_windows = 0;
+    int64_t prof_start = 0, prof_end = 0;
+    int (*prof_pause)(uint64_t) = nullptr;
+    int (*prof_resume)(uint64_t) = nullptr;
+    bool restart_forces = false;  // set by read_restart, consumed by setup
+    bool upload_all = false;      // read_restart: atoms_upload keeps every atom it is given
     // Angles section + angle_style harmonic/meso (atom_style dpd/angle/meso, angle_harmonic_meso.cu)
     int angles_upload(int na, const int *t1, const int *t2, const int *t3, const int *type);
     int angle_style(int nangletypes);

@@ -689,7 +689,7 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
     // several ranks: every rank is handed the whole deck and keeps the atoms of its own sub-box
     std::vector<double> fx, fv;
     std::vector<int> ftag, ftype, fmask, fimage;
-    if (nranks > 1) {
+    if (nranks > 1 && !upload_all) {
         for (int i = 0; i < n; i++) {
             if (!owns(x + 3 * (size_t)i)) continue;
             for (int d = 0; d < 3; d++) { fx.push_back(x[3 * (size_t)i + d]); fv.push_back(v[3 * (size_t)i + d]); }
@@ -724,6 +724,7 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
     h_tags.assign(tag, tag + n);
     have_bonds = false;
     have_angles = false;
+    restart_forces = false;
     nlocal = n;
     nghost = 0;
     n_bulk = 0;
@@ -1274,6 +1275,15 @@ int Engine::setup()
     TRY(init_params());
     TRY(reneighbor());
     nbuild = 0;
+    if (restart_forces) {
+        // continuing from a restart file: the forces of the interrupted step came with the atoms (restart.hip) and were
+        // carried through the reorder above; energies and virial are tallied on demand (tally_ev)
+        restart_forces = false;
+        ev_valid = false;
+        TRY(check_overflow());
+        is_setup = true;
+        return 0;
+    }
     TRY(force_clear(0));
     for (int k = 0; k < 6; k++) launch_fill_f64(virial[k], 0.0, nlocal, stream);
     TRY(pair_compute(0, 1, 1));
@@ -1290,6 +1300,7 @@ int Engine::run(int nsteps)
     tbegin("total_steps");
     bool initial_done = false, merged = false;
     for (int it = 0; it < nsteps; it++) {
+        profile_tick(it, nsteps);
         ntimestep++;
         if (!initial_done) TRY(nve_initial());
         int rebuild = 0;
@@ -1371,6 +1382,7 @@ int Engine::run(int nsteps)
         ev_valid = false;
     }
     tend("total_steps");
+    profile_tick(nsteps, nsteps);
     TRY(check_overflow());
     HIPCHK(hipGetLastError());
     return 0;

@@ -316,6 +316,21 @@ int script_run(Engine &E, const char *path, const char *var_name, const char *va
             if ((rc = read_data(E, D, p2))) return rc;
             snprintf(buf, sizeof buf, "  %d atoms\n", D.natoms);
             out += buf;
+        } else if (c == "read_restart") {
+            // the engine's own per-rank file (restart.hip): box, masses, pair / bond / angle coefficients, atoms and topology
+            if (w.size() != 2) { E.err = "Illegal read_restart command"; return 1; }
+            std::string p2 = w[1];
+            { std::ifstream probe(p2); if (!probe) p2 = dir + w[1]; }
+            if ((rc = E.read_restart(p2))) return rc;
+            D.have_atoms = true; D.uploaded = true; D.is_setup = false;
+            D.natoms = E.nlocal; D.ntypes = E.restart_ntypes(); D.mass = E.restart_masses();
+            E.restart_box(D.lo, D.hi, D.periodic);
+            snprintf(buf, sizeof buf, "  %d atoms\n", D.natoms);
+            out += buf;
+        } else if (c == "write_restart") {
+            if (w.size() != 2) { E.err = "Illegal write_restart command"; return 1; }
+            if ((rc = upload(E, D))) return rc;
+            if ((rc = E.write_restart(w[1]))) return rc;
         } else if (c == "mass") {
             if (w.size() != 3) { E.err = "Illegal mass command"; return 1; }
             if (D.mass.empty()) D.mass.assign(D.ntypes + 1, 0.0);

@@ -22,5 +22,7 @@ def test_glue_compiles_against_reference_headers():
 def test_glue_registers_the_reference_style_keys():
     txt = open(os.path.join(ROOT, "lammps_glue", "meso_hip_glue.h")).read()
     for key in ("PairStyle(dpd/meso,", "PairStyle(dpd/fast/meso,", "FixStyle(nve/meso,", "ComputeStyle(temp/meso,",
-                "IntegrateStyle(mvv/meso,", "IntegrateStyle(verlet/meso,"):
+                "IntegrateStyle(mvv/meso,", "IntegrateStyle(verlet/meso,", "PairStyle(dpd/mini/meso,",
+                "PairStyle(dpd/polyforce/meso,", "PairStyle(dpd/tableforce/meso,", "BondStyle(harmonic/meso,",
+                "BondStyle(fene/meso,", "AngleStyle(harmonic/meso,"):
         assert key in txt
