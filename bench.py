@@ -73,10 +73,25 @@ def cpu_baseline(L, x, v, lo, hi, every, steps):
     t0 = time.perf_counter()
     s.run(steps, ev_last=False)
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "timesteps/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of the same %d^3 rho=4 box (N=%d), rebuild every %d, OpenMP %d threads; "
-                      "oracle/lmp_dpd_cpu.c" % (steps, L, len(x), every, cores),
-            "M_particle_steps_per_s": steps * len(x) / dt / 1e6}
+    out = {"value": steps / dt, "unit": "timesteps/s", "cores": cores, "kind": "port",
+           "sample": "%d steps of the same %d^3 rho=4 box (N=%d), rebuild every %d, OpenMP %d threads; "
+                     "oracle/lmp_dpd_cpu.c" % (steps, L, len(x), every, cores),
+           "M_particle_steps_per_s": steps * len(x) / dt / 1e6}
+    if cores > 1:
+        # the same restatement on one thread (SURVEY.md 8d asks for both; the reference binary itself ran 1.335 steps/s at
+        # 64^3 on one core): one rebuild interval of steps
+        s1 = ob.LmpDpd(x, lo, hi, nthreads=1)
+        s1.pair_style(1.0, 1.0, 419084618)
+        s1.pair_coeff(1, 1, 15.0, 4.5)
+        s1.set_velocities(v)
+        s1.neighbor(0.3, every, 0)
+        s1.timestep(0.005)
+        s1.setup()
+        t0 = time.perf_counter()
+        s1.run(every, ev_last=False)
+        out["single_thread"] = {"value": every / (time.perf_counter() - t0), "unit": "timesteps/s", "cores": 1,
+                                "sample": "%d steps" % every}
+    return out
 
 
 def main():
