@@ -22,3 +22,11 @@ PY
 bash tools/pmc_run.sh ${tag}_pmc
 ( echo "# rocprofv3 --pmc <counters> -- python3 bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline   (64^3 rho=4, dpd/fast/meso; one pass per counter group; mean per dispatch)"; cat gpurun_out/${tag}_pmc.summary.txt ) > gpurun_out/${tag}_pmc_64_fast.txt
 echo "pmc done"
+# the other configurations of BASELINE.json (parity-test cases; timed for the record)
+cd $R
+timeout -k 10 300 python3 bench.py --box 25 --no-cpu-baseline > gpurun_out/${tag}_bench25_fast.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --box 48 --no-cpu-baseline > gpurun_out/${tag}_bench48_fast.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --box 64 --style dpd/meso --no-cpu-baseline > gpurun_out/${tag}_bench64_dp.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --box 25 --style dpd/meso --every 1 --no-cpu-baseline > gpurun_out/${tag}_bench25_dp_every1.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --box 128 --steps 300 --warmup 50 --no-cpu-baseline > gpurun_out/${tag}_bench128_fast.json 2>/dev/null
+echo "other configs done"

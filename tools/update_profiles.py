@@ -3,8 +3,13 @@
 (HBM bytes of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes).   usage: tools/update_profiles.py r01"""
 import json, re, shutil, sys
 tag = sys.argv[1]
+import os
 for f in ("bench64_fast.json", "kernel_stats_64_fast.txt", "pmc_64_fast.txt"):
     shutil.copy("gpurun_out/%s_%s" % (tag, f), "profiles/%s_%s" % (tag, f))
+for f in ("bench25_fast.json", "bench48_fast.json", "bench64_dp.json", "bench25_dp_every1.json", "bench128_fast.json"):
+    src = "gpurun_out/%s_%s" % (tag, f)
+    if os.path.exists(src) and os.path.getsize(src) > 100:
+        shutil.copy(src, "profiles/%s_%s" % (tag, f))
 d = json.loads(open("profiles/%s_bench64_fast.json" % tag).read().strip().splitlines()[-1])
 vals = {}
 for ln in open("profiles/%s_pmc_64_fast.txt" % tag):
