@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0 = auto)")
     ap.add_argument("--profile-steps", type=int, default=200)
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="multi-rank transport: rccl (production) or host (gloo point-to-point through host buffers: lets several "
+                         "ranks share one GPU, for rehearsing the multi-process flow on a one-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     return ap.parse_args()
 
@@ -110,7 +113,11 @@ def main():
     L = a.box
     x, v, lo, hi = make_box(L)
     n = len(x)
-    m = Meso(local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    if a.transport == "rccl" and world > ndev:
+        raise SystemExit("bench: %d ranks but %d GPU(s) - RCCL needs one GPU per rank (use --transport host to rehearse)" % (world, ndev))
+    dev = local_rank % ndev
+    m = Meso(dev)
     for kv in a.opt:
         k, val = kv.split("=")
         m.set_option(k, float(val))
@@ -120,15 +127,21 @@ def main():
         # barriers and the max-over-ranks timing; the ghost traffic itself is RCCL send/recv inside the engine
         import torch.distributed as dist
         from meso_amd.api import nccl_unique_id, procgrid
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
         grid = procgrid(world, hi - lo)
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.from_numpy(nccl_unique_id().copy())
-        uid = uid.cuda()
-        dist.broadcast(uid, 0)
-        m.comm_init(world, rank, grid, "rccl", uid.cpu().numpy())
+        if a.transport == "rccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.from_numpy(nccl_unique_id().copy())
+            uid = uid.cuda()
+            dist.broadcast(uid, 0)
+            m.comm_init(world, rank, grid, "rccl", uid.cpu().numpy())
+        else:
+            from meso_amd.hostxchg import make_exchange
+            dist.init_process_group("gloo")
+            m.set_host_exchange(make_exchange(dist, rank))
+            m.comm_init(world, rank, grid, "host")
     m.read_atoms(x, v, lo, hi)
     m.neighbor(0.3)
     m.neigh_modify(delay=0, every=a.every, check=False)
@@ -150,7 +163,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device="cuda" if a.transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     steps_per_s = a.steps / elapsed
@@ -165,9 +178,11 @@ def main():
     phases = {}
     for name in ("pair", "neigh", "nve", "merge", "halo", "reorder", "bin", "total_steps"):
         ms, calls = m.timer(name)
-        phases[name] = {"ms_per_call": ms / calls if calls else None, "calls": calls}
+        phases[name] = {"ms_per_call": ms / calls if calls else None, "calls": calls, "ms": ms}
     m.set_option("profile", 0)
-    t_pair = phases["pair"]["ms_per_call"] * 1e-3
+    # per launch on one rank; with several ranks the force kernel runs twice per step (bulk, then border range after the
+    # ghost refresh): the two launches together cover the rank's atoms once, so they are timed together
+    t_pair = phases["pair"]["ms"] / max(a.profile_steps, 1) * 1e-3 if world > 1 else phases["pair"]["ms_per_call"] * 1e-3
     n_rank = m.counts()[0]                                          # atoms this rank's pair kernel covers
     # ALGORITHMIC bytes per launch: own coord4 + veloc4, count, the stored row entries, and either
     # the fp64 force store (pair kernel alone) or - when the step boundary runs in the kernel's epilogue (fp32 ring

@@ -96,6 +96,11 @@ class Meso:
         self._ck(self.lib.meso_comm_init(self._h, nranks, rank, _p(g), TRANSPORTS[transport], _p(u),
                                          0 if u is None else len(u)))
 
+    def set_host_exchange(self, fn):
+        """transport "host": fn is a _lib.HOST_EXCHANGE_FN (e.g. hostxchg.make_exchange); a reference is kept here"""
+        self._host_fn = fn
+        self._ck(self.lib.meso_comm_set_host_exchange(self._h, fn, None))
+
     # -- read_data / create atoms -----------------------------------------------------------
     def read_atoms(self, x, v, box_lo, box_hi, types=None, tags=None, masses=None, ntypes=None,
                    periodicity=(1, 1, 1)):

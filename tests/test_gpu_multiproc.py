@@ -1,0 +1,28 @@
+"""The multi-process flow of bench.py (one process per rank, torch.distributed rendezvous, decomposition, timed run, profiled
+pass, global reductions, one JSON line from rank 0) rehearsed on one GPU: two processes share the card through the HOST
+transport (gloo point-to-point through host buffers, meso_amd/hostxchg.py) - RCCL itself refuses two ranks on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_processes_host_transport():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "20",
+           "--profile-steps", "20", "--box", "16", "--transport", "host"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "strong" and d["value"] > 0
+    assert "procgrid" in d["config"]["workload"] and 0.5 < d["config"]["temperature_end"] < 2.0
+    assert d["roofline"]["us_per_launch"] > 0 and "cpu_baseline" not in d
