@@ -185,6 +185,7 @@ private:
     bool pair_poly = false;  // pair_style dpd/polyforce/meso: fp32 arithmetic, polynomial conservative force
     std::vector<float> poly; // [ntypes^2][MESO_POLY_PITCH]
     float *d_poly = nullptr;
+    int pair_npart = 0;      // option pair_npart: lanes per atom in the ring kernel (0 = by launch size)
     int pair_rng = 0;       // 1: pair_style dpd/mini/meso (fp32 arithmetic of dpd/fast/meso, logistic-map noise, one coefficient set)
     double cut_global = 0.0, cutmax = 0.0, cutghost = 0.0;
     bool have_pair = false, have_coeff = false, params_ready = false, is_setup = false;

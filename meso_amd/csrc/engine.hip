@@ -312,6 +312,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "fuse_pair") { fuse_pair = (int)val; return 0; }
     if (key == "brick_margin") { if (val < 1.0) return fail(1, "brick_margin must be >= 1"); brick_margin = val; params_ready = false; return 0; }
     if (key == "pair_share") { pair_share = (int)val; return 0; }
+    if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
@@ -1213,6 +1214,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     if (!cell_ring) p.fuse_nve = 0;              // only the ring kernel has the epilogue
     p.nall = nlocal + nghost;
     p.rng = pair_rng;
+    p.npart = pair_npart;
     p.poly = pair_poly ? d_poly : nullptr;
     p.ftab = pair_ftab ? d_ftab : nullptr;
     p.ftab_len = ftab_len;

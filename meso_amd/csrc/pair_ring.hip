@@ -53,7 +53,7 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 // EW1: every pair type has weight exponent s = 1 (the usual DPD choice): w_R = w_C, no pow()
 // FAST: dpd/fast/meso (fp32 arithmetic, contracted); otherwise dpd/meso (fp64 arithmetic on the fp32 operands through the
 // uncontracted functions of meso_device.h, 36-fractional-bit fixed-point sums)
-template <bool FAST, bool NT1, bool EW1, bool SHARE>
+template <bool FAST, bool NT1, bool EW1, bool SHARE, int NPART>
 __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
@@ -69,32 +69,39 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t per_wave = 64 * 16 * 2 + RG_RING * 16;
     u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
-    char *wb = (char *)smem + off + 3 * 64 * RG_WAVES * 8 + (size_t)w * per_wave;
+    char *wb = (char *)smem + off + 3 * 64 * RG_WAVES * 8 + (size_t)w * per_wave;      // (accumulator area sized for NPART = 1)
     float4 *own_c = (float4 *)wb;
     float4 *own_v = own_c + 64;
     float4 *ring = own_v + 64;          // (partner x, y, z, record word): the coordinate is not gathered twice
 
     const int nbk = gridDim.x;
     const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
-    const int blockbase = a.beg + blk * (int)blockDim.x;     // SHARE: beg is a multiple of 256 (launcher)
-    const int i = blockbase + (int)threadIdx.x;
+    // NPART lanes share one atom (small launches: more waves for the same atoms): lane = part * APW + slot, the parts of an
+    // atom walk its row chunks part, part + NPART, ...; sums meet in the LDS accumulators like those of the other waves
+    constexpr int APW = 64 / NPART;                          // atoms per wave
+    constexpr int NB = APW * RG_WAVES;                       // atoms per workgroup = Newton-pairing group of this launch
+    const int slot = lane % APW, part = lane / APW;
+    const int blockbase = a.beg + blk * NB;                  // SHARE: beg is a multiple of 256 (launcher)
+    const int i = blockbase + w * APW + slot;
     const bool mine = i < a.end;
     float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
     int n = 0;
     if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
-    own_c[lane] = c1;
-    own_v[lane] = v1;
-    constexpr int NB = 64 * RG_WAVES;
-    const int ob = w * 64 + lane;                            // my slot in the workgroup's accumulators
-    facc[ob] = 0; facc[NB + ob] = 0; facc[2 * NB + ob] = 0;
+    const int ob = w * APW + slot;                           // my atom's slot in the workgroup's accumulators
+    if (part == 0) {
+        own_c[slot] = c1;
+        own_v[slot] = v1;
+        facc[ob] = 0; facc[NB + ob] = 0; facc[2 * NB + ob] = 0;
+    }
     __syncthreads();   // coefficient table (multi-type), accumulators, this wave's own_c/own_v
 
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.coord4, 0, a.nall * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, a.nall * 16, 0x00020000);
     const u32 t1 = __float_as_uint(c1.w);
     const float dtis = (float)a.dt_inv_sqrt;
-    const u32 lanehi = (u32)lane << RG_OWNER_SHIFT;
-    const int nch = (n + 7) >> 3;
+    const u32 lanehi = (u32)slot << RG_OWNER_SHIFT;
+    const int nch_row = (n + 7) >> 3;
+    const int nch = (nch_row - part + NPART - 1) / NPART;      // chunks part, part + NPART, ... of the row
     int nchmax = nch;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nchmax = max(nchmax, __shfl_xor(nchmax, o, 64));
@@ -151,7 +158,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                     pair_dpd_f64<EW1>(ci, pc2, vi, pv2, pc, a.dt_inv_sqrt, fx, fy, fz);
                     qx = to_fixed36(fx); qy = to_fixed36(fy); qz = to_fixed36(fz);
                 }
-                const u32 oo = (u32)(w * 64) + owner;
+                const u32 oo = (u32)(w * APW) + owner;
                 __hip_atomic_fetch_add(&facc[oo], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[NB + oo], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[2 * NB + oo], qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -183,13 +190,13 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
 
     const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);
     int4 w0 = make_int4(0, 0, 0, 0), w1 = w0;
-    if (nch > 0) { w0 = rows[0]; w1 = rows[1]; }
+    if (nch > 0) { w0 = rows[(size_t)part * 128]; w1 = rows[(size_t)part * 128 + 1]; }
 #pragma unroll 1
     for (int c = 0; c < nchmax; c++) {
         const bool active = c < nch;
         const u64 actm = __builtin_amdgcn_ballot_w64(active);
         const int j[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        if (c + 1 < nch) { w0 = rows[(size_t)(c + 1) * 128]; w1 = rows[(size_t)(c + 1) * 128 + 1]; }
+        if (c + 1 < nch) { w0 = rows[(size_t)((c + 1) * NPART + part) * 128]; w1 = rows[(size_t)((c + 1) * NPART + part) * 128 + 1]; }
         float4 c2[8];
         bool use[8], shb[8];
         u64 usem[8];
@@ -200,10 +207,10 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
             usem[q] = actm;
             if (SHARE) {
                 // (lane masks from the same compares through the icmp builtins: 36 = ULT)
-                usem[q] = actm & ~(__builtin_amdgcn_uicmp((u32)j[q] ^ (u32)i, (u32)RG_GROUP, 36) & __builtin_amdgcn_uicmp((u32)j[q], (u32)i, 36));
+                usem[q] = actm & ~(__builtin_amdgcn_uicmp((u32)j[q] ^ (u32)i, (u32)NB, 36) & __builtin_amdgcn_uicmp((u32)j[q], (u32)i, 36));
                 // same aligned 256-group: lower partner index = mirrored entry, not looked at; higher (and one of this
                 // launch's atoms) = evaluated once for both
-                const bool same = ((u32)j[q] ^ (u32)i) < (u32)RG_GROUP;
+                const bool same = ((u32)j[q] ^ (u32)i) < (u32)NB;
                 use[q] = active & !(same & ((u32)j[q] < (u32)i));
                 shb[q] = same & ((u32)j[q] > (u32)i) & ((u32)j[q] < (u32)a.end);
             }
@@ -239,7 +246,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
     while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
-    if (mine) {
+    if (mine && part == 0) {
         double fx, fy, fz;
         if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
         else { fx = from_fixed36(facc[ob]); fy = from_fixed36(facc[NB + ob]); fz = from_fixed36(facc[2 * NB + ob]); }
@@ -260,7 +267,14 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? 4 : 8);
     size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
-    dim3 grid(((n + 64 * RG_WAVES - 1) / (64 * RG_WAVES) + 7) / 8 * 8), block(64 * RG_WAVES);
+    // small launches: 2 lanes per atom, so that the same atoms fill twice as many waves (a 32^3 box is 2048 waves for 1024
+    // SIMDs otherwise, and each wave walks 7 row chunks and ~11 hit batches one after the other)
+    // (measured, fused launch: 25^3 21.6 -> 17.3 us, 32^3 25.7 -> 23.5; 40^3 34.4 -> 37.1: one lane per atom from there on;
+    // four lanes per atom never beat two)
+    int npart = p.npart > 0 ? p.npart : (n <= 163840 ? 2 : 1);
+    if (npart != 1 && npart != 2 && npart != 4) npart = 1;
+    const int awg = 64 / npart * RG_WAVES;
+    dim3 grid(((n + awg - 1) / awg + 7) / 8 * 8), block(64 * RG_WAVES);
     // p.debug 3/4: occupancy ablation - pad the LDS request so that only 3 / 4 workgroups fit a CU (default: 5)
     if (p.debug == 3) sm = 53 * 1024;
     if (p.debug == 4) sm = 40 * 1024;
@@ -269,7 +283,12 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     else ew1 = p.all_expw_one != 0;
     // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom
     const bool share = p.share != 0 && (p.beg & (RG_GROUP - 1)) == 0;
-#define RG_LAUNCH(F, A, B, C) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C>), grid, block, sm, s, p)
+#define RG_LAUNCH(F, A, B, C)                                                                                   \
+    do {                                                                                                        \
+        if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4>), grid, block, sm, s, p);            \
+        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2>), grid, block, sm, s, p);       \
+        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1>), grid, block, sm, s, p);                       \
+    } while (0)
 #define RG_PICK(F)                                        \
     if (share) {                                          \
         if (nt1 && ew1) RG_LAUNCH(F, true, true, true);   \

@@ -576,3 +576,29 @@ def test_option_matrix_sigma0_trajectories(Meso, style, tol):
         d = out[0] - ref[0]
         d -= np.round(d / prd) * prd
         assert np.abs(d).max() < tol and np.abs(out[1] - ref[1]).max() < 50 * tol, (layout, pk, nk, fs, fp, sh)
+    # lanes per atom of the ring kernel (1, 2, 4; the default picks by launch size), with and without pairing / epilogue
+    for npart, fp, sh in itertools.product((1, 2, 4), (0, 1), (0, 1)):
+        out = run({"pair_npart": npart, "fuse_pair": fp, "pair_share": sh})
+        d = out[0] - ref[0]
+        d -= np.round(d / prd) * prd
+        assert np.abs(d).max() < tol and np.abs(out[1] - ref[1]).max() < 50 * tol, ("npart", npart, fp, sh)
+
+
+@pytest.mark.parametrize("style", ["dpd/fast/meso", "dpd/meso"])
+def test_lanes_per_atom_give_identical_forces(Meso, style):
+    """the parts of an atom add into the same fixed-point sums: forces with the thermostat on are bit-identical for 1, 2 and
+    4 lanes per atom (two atom types, non-cubic box)"""
+    from meso_amd.datagen import make_polymer_box
+    x, v, types, _, lo, hi = make_polymer_box(9, frac=0.3)
+    res = []
+    for npart in (1, 2, 4):
+        m = Meso()
+        m.set_option("pair_npart", npart)
+        m.read_atoms(x, v, lo, hi, types=types, ntypes=2); m.neighbor(0.3); m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style(style, 1.0, DP_RUN["seed"])
+        for (i, j), a0 in {(1, 1): 15.0, (2, 2): 15.0, (1, 2): 40.0}.items():
+            m.pair_coeff(i, j, a0, 4.5, 3.0, 1.0, 1.0)
+        m.timestep(0.005); m.setup()
+        res.append(m.gather()[2])
+        m.close()
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
