@@ -185,6 +185,8 @@ private:
     bool pair_poly = false;  // pair_style dpd/polyforce/meso: fp32 arithmetic, polynomial conservative force
     std::vector<float> poly; // [ntypes^2][MESO_POLY_PITCH]
     float *d_poly = nullptr;
+    int ghost_sort = 0;      // option: 1 = bin the ghosts with the radix/merge sort (the former path), 0 = by counting
+    int *gcount = nullptr;   // [M+1] ghosts per Morton code
     int pair_npart = 0;      // option pair_npart: lanes per atom in the ring kernel (0 = by launch size)
     int pair_rng = 0;       // 1: pair_style dpd/mini/meso (fp32 arithmetic of dpd/fast/meso, logistic-map noise, one coefficient set)
     double cut_global = 0.0, cutmax = 0.0, cutghost = 0.0;

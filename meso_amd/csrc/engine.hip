@@ -80,7 +80,7 @@ void Engine::free_all()
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
-    dfree(estart); dfree(gstart); dfree(gslot); dfree(table16);
+    dfree(estart); dfree(gstart); dfree(gcount); dfree(gslot); dfree(table16);
     dfree(brick_flag); dfree(brick_pos); dfree(brick_active); dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
@@ -312,6 +312,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "fuse_pair") { fuse_pair = (int)val; return 0; }
     if (key == "brick_margin") { if (val < 1.0) return fail(1, "brick_margin must be >= 1"); brick_margin = val; params_ready = false; return 0; }
     if (key == "pair_share") { pair_share = (int)val; return 0; }
+    if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
@@ -837,12 +838,14 @@ int Engine::init_params()
             estart_cap = 2 * M + 1;
             HIPCHK(dalloc(estart, estart_cap));
             HIPCHK(dalloc(gstart, M + 1));
+            dfree(gcount);
+            HIPCHK(dalloc(gcount, M + 1));
             dfree(binrange);
             HIPCHK(dalloc(binrange, 2 * M));
             HIPCHK(dalloc(brick_flag, M / 16 + 1));
             HIPCHK(dalloc(brick_pos, M / 16 + 1));
             HIPCHK(dalloc(brick_active, M / 16 + 1));
-            size_t tb = scan_temp_bytes((int)(M / 16 + 1));
+            size_t tb = scan_temp_bytes((int)(M + 2));      // ghost counts per Morton code (M + 1) is the longest scan
             if (tb > sort_temp_bytes) {
                 if (sort_temp) (void)hipFree(sort_temp);
                 sort_temp = nullptr;
@@ -1044,12 +1047,20 @@ int Engine::build_cells_and_table()
             bargs.nactive = bargs.nbricks;
             bargs.nactive_dev = nullptr;
         }
-        launch_ghost_morton(cur, geom, nlocal, nghost, bin_key, bin_val, stream);
-        if (nghost > 0)
-            HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nghost,
-                                  std::max(1, 3 * l1bits), stream));
-        launch_code_starts_u32(bin_key, nghost, bargs.M, gstart, stream);
-        launch_invert_perm(bin_val, gslot, nghost, stream);
+        if (ghost_sort) {
+            launch_ghost_morton(cur, geom, nlocal, nghost, bin_key, bin_val, stream);
+            if (nghost > 0)
+                HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nghost,
+                                      std::max(1, 3 * l1bits), stream));
+            launch_code_starts_u32(bin_key, nghost, bargs.M, gstart, stream);
+            launch_invert_perm(bin_val, gslot, nghost, stream);
+        } else {
+            // counting instead of sorting: 6 launches instead of ~18 (the ghosts' comparison sort was launch-bound)
+            HIPCHK(hipMemsetAsync(gcount, 0, ((size_t)bargs.M + 1) * sizeof(int), stream));
+            launch_ghost_count(cur, geom, nlocal, nghost, bin_key, bin_val, gcount, stream);
+            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, gcount, gstart, bargs.M + 1, stream));
+            launch_ghost_place(bin_key, bin_val, gstart, nghost, bargs.M, bin_val_alt, gslot, stream);
+        }
         bargs.ghost_base = nlocal;
         tend("bin");
         // merged arrays with the signatures of the CURRENT step: the force kernel of this step uses them as they are

@@ -183,6 +183,10 @@ int tile_build_maxh_limit(int n_col);
 size_t brick_hoff_pitch();
 size_t brick_hdr_pitch();
 void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s);
+// ghost binning by counting (no sort): cnt[M+1] zeroed by the caller, scanned into gstart between the two calls
+void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt, hipStream_t s);
+void launch_ghost_place(const uint32_t *code, const int *rank, const int *gstart, int nghost, int M, int *slotval, int *gslot,
+                        hipStream_t s);
 struct ExclArgs;
 // cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
