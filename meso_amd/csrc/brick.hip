@@ -650,37 +650,21 @@ __global__ void __launch_bounds__(256) k_ghost_count(const double *__restrict__ 
                                                      u32 *__restrict__ code, int *__restrict__ rank, int *__restrict__ cnt)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nghost) return;
-    const double c[3] = {x[nlocal + k], y[nlocal + k], z[nlocal + k]};
-    int b[3];
+    const bool valid = k < nghost;
+    u32 m = 0;
+    if (valid) {
+        const double c[3] = {x[nlocal + k], y[nlocal + k], z[nlocal + k]};
+        int b[3];
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        b[d] = clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1.0), 0, g.mbin[d]);
-        b[d] = (c[d] >= g.lo[d]) ? (c[d] <= g.hi[d] ? b[d] : g.mbin[d] - 1) : 0;
+        for (int d = 0; d < 3; d++) {
+            b[d] = clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1.0), 0, g.mbin[d]);
+            b[d] = (c[d] >= g.lo[d]) ? (c[d] <= g.hi[d] ? b[d] : g.mbin[d] - 1) : 0;
+        }
+        m = interleave3((u32)b[0], (u32)b[1], (u32)b[2]);
+        code[k] = m;
     }
-    const u32 m = interleave3((u32)b[0], (u32)b[1], (u32)b[2]);
-    code[k] = m;
-    rank[k] = atomicAdd(cnt + m, 1);
-}
-__global__ void __launch_bounds__(256) k_ghost_place(const u32 *__restrict__ code, const int *__restrict__ rank,
-                                                     const int *__restrict__ gstart, int nghost, int *__restrict__ slotval)
-{
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nghost) slotval[gstart[code[k]] + rank[k]] = k;
-}
-__global__ void __launch_bounds__(256) k_ghost_order(const int *__restrict__ gstart, int M, int *__restrict__ slotval,
-                                                     int *__restrict__ gslot)
-{
-    int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int b = gstart[m], e = gstart[m + 1];
-    for (int a = b + 1; a < e; a++) {
-        const int v = slotval[a];
-        int q = a - 1;
-        while (q >= b && slotval[q] > v) { slotval[q + 1] = slotval[q]; q--; }
-        slotval[q + 1] = v;
-    }
-    for (int a = b; a < e; a++) gslot[slotval[a]] = a;
+    const int r = run_rank(m, valid, cnt);
+    if (valid) rank[k] = r;
 }
 void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt, hipStream_t s)
 {
@@ -688,14 +672,6 @@ void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int ngho
         hipLaunchKernelGGL(k_ghost_count, dim3((nghost + 255) / 256), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, nlocal, nghost, code,
                            rank, cnt);
 }
-void launch_ghost_place(const uint32_t *code, const int *rank, const int *gstart, int nghost, int M, int *slotval, int *gslot,
-                        hipStream_t s)
-{
-    if (nghost <= 0) return;
-    hipLaunchKernelGGL(k_ghost_place, dim3((nghost + 255) / 256), dim3(256), 0, s, code, rank, gstart, nghost, slotval);
-    hipLaunchKernelGGL(k_ghost_order, dim3((M + 255) / 256), dim3(256), 0, s, gstart, M, slotval, gslot);
-}
-
 static inline int brick_grid(const BrickArgs &g) { return (g.nactive + 7) / 8 * 8; }
 
 // flag[b] = 1 if brick b owns atoms (bulk or border section); the engine scans the flags and compacts the ids

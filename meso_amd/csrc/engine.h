@@ -185,6 +185,9 @@ private:
     bool pair_poly = false;  // pair_style dpd/polyforce/meso: fp32 arithmetic, polynomial conservative force
     std::vector<float> poly; // [ntypes^2][MESO_POLY_PITCH]
     float *d_poly = nullptr;
+    int reorder_sort = 0;    // option: 1 = reorder the locals with the radix/merge sort (the former path), 0 = by counting
+    int *rcount = nullptr;   // [2M+1] atoms per extended code
+    int reorder_cap = 2048;  // LDS stage of k_reorder_order (pairs per 128 codes), from the density
     int ghost_sort = 0;      // option: 1 = bin the ghosts with the radix/merge sort (the former path), 0 = by counting
     int *gcount = nullptr;   // [M+1] ghosts per Morton code
     int pair_npart = 0;      // option pair_npart: lanes per atom in the ring kernel (0 = by launch size)

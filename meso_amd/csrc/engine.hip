@@ -80,7 +80,7 @@ void Engine::free_all()
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
-    dfree(estart); dfree(gstart); dfree(gcount); dfree(gslot); dfree(table16);
+    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(table16);
     dfree(brick_flag); dfree(brick_pos); dfree(brick_active); dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
@@ -313,6 +313,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "brick_margin") { if (val < 1.0) return fail(1, "brick_margin must be >= 1"); brick_margin = val; params_ready = false; return 0; }
     if (key == "pair_share") { pair_share = (int)val; return 0; }
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
+    if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
@@ -838,14 +839,19 @@ int Engine::init_params()
             estart_cap = 2 * M + 1;
             HIPCHK(dalloc(estart, estart_cap));
             HIPCHK(dalloc(gstart, M + 1));
+            // counts per code: zeroed once here, the ordering passes leave them clean for the next rebuild
             dfree(gcount);
             HIPCHK(dalloc(gcount, M + 1));
+            HIPCHK(hipMemsetAsync(gcount, 0, (M + 1) * sizeof(int), stream));
+            dfree(rcount);
+            HIPCHK(dalloc(rcount, 2 * M + 1));
+            HIPCHK(hipMemsetAsync(rcount, 0, (2 * M + 1) * sizeof(int), stream));
             dfree(binrange);
             HIPCHK(dalloc(binrange, 2 * M));
             HIPCHK(dalloc(brick_flag, M / 16 + 1));
             HIPCHK(dalloc(brick_pos, M / 16 + 1));
             HIPCHK(dalloc(brick_active, M / 16 + 1));
-            size_t tb = scan_temp_bytes((int)(M + 2));      // ghost counts per Morton code (M + 1) is the longest scan
+            size_t tb = scan_temp_bytes((int)(2 * M + 2));  // atoms per extended code (2M + 1) is the longest scan
             if (tb > sort_temp_bytes) {
                 if (sort_temp) (void)hipFree(sort_temp);
                 sort_temp = nullptr;
@@ -865,6 +871,9 @@ int Engine::init_params()
             else if (want < brick_static_maxh()) want = brick_static_maxh();
             tile_fits = want <= tile_build_maxh_limit(n_col);
             bargs.maxh = want;
+            // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
+            const double m128 = density * 128.0 * binvol * brick_margin;
+            reorder_cap = std::min(7680, std::max(2048, ((int)std::ceil(m128 + 6.5 * std::sqrt(m128)) + 63) / 64 * 64));
             bargs.maxown = layout == 1 ? brick_static_maxown() : 0;
         }
         if (layout >= 1 && (M / brick_codes() + 8 > brick_cap || bargs.maxh != brick_maxh_alloc)) {
@@ -934,13 +943,24 @@ int Engine::reorder_locals()
     }
     tbegin("reorder");
     int bits = reorder_key_bits(geom);
-    launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
-    HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
-    if (layout >= 1) {
-        // first index of every extended code ([border][Morton(bin)]); the border section starts at estart[M] = n_bulk
+    if (layout >= 1 && !reorder_sort) {
+        // counting per extended code instead of a comparison sort (kernels.hip): ~8 launches instead of ~28; estart - first
+        // index of every extended code ([border][Morton(bin)]), the border section starts at estart[M] = n_bulk - is the scan
+        const int ncodes = 2 * bargs.M;
+        launch_reorder_count(cur, geom, slab_lo, slab_hi, rkey, rval_alt, rcount, nlocal, stream);
+        HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, rcount, estart, ncodes + 1, stream));
+        launch_reorder_place(rkey, rval_alt, estart, geom, ncodes, nlocal, reorder_cap, (int *)rkey_alt, rval, (uint32_t *)bin_key_alt, rcount,
+                             stream);
+        std::swap(rkey, bin_key_alt);            // sorted keys (the lane-per-atom list builder reads them)
+        HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    } else if (layout >= 1) {
+        launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
+        HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
         launch_estart(rkey, nlocal, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);
         HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
     } else {
+        launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
+        HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
         HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
         launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
     }
@@ -1056,10 +1076,10 @@ int Engine::build_cells_and_table()
             launch_invert_perm(bin_val, gslot, nghost, stream);
         } else {
             // counting instead of sorting: 6 launches instead of ~18 (the ghosts' comparison sort was launch-bound)
-            HIPCHK(hipMemsetAsync(gcount, 0, ((size_t)bargs.M + 1) * sizeof(int), stream));
             launch_ghost_count(cur, geom, nlocal, nghost, bin_key, bin_val, gcount, stream);
             HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, gcount, gstart, bargs.M + 1, stream));
-            launch_ghost_place(bin_key, bin_val, gstart, nghost, bargs.M, bin_val_alt, gslot, stream);
+            launch_ghost_order(bin_key, bin_val, gstart, bargs.M, nghost, reorder_cap, (int *)bin_key_alt, bin_val_alt, (uint32_t *)rkey_alt, gslot,
+                               gcount, stream);
         }
         bargs.ghost_base = nlocal;
         tend("bin");

@@ -55,6 +55,13 @@ int reorder_key_bits(const BinGeom &g);
 int reorder_sub_bits(const BinGeom &g);
 void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi,
                          const int *dim_active, uint32_t *key, int *val, int n, hipStream_t s);
+// reorder by counting per extended code (no comparison sort): count -> scan (caller) -> place + order
+void launch_reorder_count(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi, uint32_t *key,
+                          int *rank, int *cnt, int n, hipStream_t s);
+void launch_reorder_place(const uint32_t *key, const int *rank, const int *estart, const BinGeom &g, int ncodes, int n, int cap,
+                          int *placed, int *val_sorted, uint32_t *key_sorted, int *cnt, hipStream_t s);
+void launch_ghost_order(const uint32_t *code, const int *rank, const int *gstart, int M, int nghost, int cap, int *placed,
+                        int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, hipStream_t s);
 void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s);
 void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s);
@@ -185,8 +192,7 @@ size_t brick_hdr_pitch();
 void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s);
 // ghost binning by counting (no sort): cnt[M+1] zeroed by the caller, scanned into gstart between the two calls
 void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt, hipStream_t s);
-void launch_ghost_place(const uint32_t *code, const int *rank, const int *gstart, int nghost, int M, int *slotval, int *gslot,
-                        hipStream_t s);
+
 struct ExclArgs;
 // cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,

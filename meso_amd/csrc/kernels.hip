@@ -336,6 +336,134 @@ __global__ void __launch_bounds__(256) k_reorder_keys(const double *__restrict__
     val[i] = i;
 }
 
+// ---- reorder without a comparison sort (rocPRIM sends <= 2^20 pairs through ~26 merge-sort launches, 134 us at 64^3):
+// the key's upper part - [border][Morton(bin)], the "extended code" - has only 2M values, so the atoms are COUNTED per code
+// (the atomic's return value is the atom's rank inside its code), the counts are scanned into estart (which the list
+// builder needs anyway), every atom is placed at estart[code] + rank, and one pass per group of 128 codes puts the few
+// atoms of each code in (sub-cell key, old index) order in LDS - the order the sort gave, so storage stays deterministic.
+__global__ void __launch_bounds__(256) k_reorder_keys_count(const double *__restrict__ x, const double *__restrict__ y,
+                                                            const double *__restrict__ z, BinGeom g, double slx, double sly,
+                                                            double slz, double shx, double shy, double shz, int border_bit,
+                                                            int sub_bits, u32 *__restrict__ key, int *__restrict__ rank,
+                                                            int *__restrict__ cnt, int n)
+{
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    const bool valid = i < n;
+    u32 k = 0;
+    if (valid) {
+        const double c[3] = {x[i], y[i], z[i]};
+        const int res = 1 << (sub_bits / 3);
+        u32 b[3], sc[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            b[d] = (u32)clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1), 0, g.mbin[d]);
+            sc[d] = (u32)clampi((int)((c[d] - g.lo[d] - ((double)b[d] - 1) * g.binsize[d]) * (res * g.bininv[d])), 0, res);
+        }
+        k = (interleave3(b[0], b[1], b[2]) << sub_bits) | interleave3(sc[0], sc[1], sc[2]);
+        bool border = c[0] <= slx || c[0] >= shx || c[1] <= sly || c[1] >= shy || c[2] <= slz || c[2] >= shz;
+        if (border) k |= (1u << border_bit);
+        key[i] = k;
+    }
+    const int r = run_rank(k >> sub_bits, valid, cnt);
+    if (valid) rank[i] = r;
+}
+__global__ void __launch_bounds__(256) k_reorder_place(const u32 *__restrict__ key, const int *__restrict__ rank,
+                                                       const int *__restrict__ estart, int sub_bits, int n,
+                                                       int *__restrict__ placed)
+{
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i < n) placed[estart[key[i] >> sub_bits] + rank[i]] = i;
+}
+#define REORDER_CODES 128
+__global__ void __launch_bounds__(REORDER_CODES) k_reorder_order(const int *__restrict__ estart, int ncodes,
+                                                                 const u32 *__restrict__ key, const int *__restrict__ placed,
+                                                                 int cap, int *__restrict__ val_sorted,
+                                                                 u32 *__restrict__ key_sorted, int *__restrict__ inverse,
+                                                                 int *__restrict__ cnt)
+{
+    extern __shared__ unsigned long long pairs[];      // (key << 32) | old index: one compare orders by key, then index
+    const int c0 = blockIdx.x * REORDER_CODES, c = c0 + (int)threadIdx.x;
+    const int c1 = min(c0 + REORDER_CODES, ncodes);
+    const int s0 = estart[c0], s1 = estart[c1];
+    const int ns = s1 - s0;
+    if (cnt && c <= ncodes && (c < c1 || c == ncodes)) cnt[c] = 0;      // the counts are clean again for the next rebuild
+    if (ns <= 0) return;
+    const bool staged = ns <= cap;
+    if (staged) {
+        for (int p = threadIdx.x; p < ns; p += REORDER_CODES) {
+            const int idx = placed[s0 + p];
+            pairs[p] = ((unsigned long long)key[idx] << 32) | (u32)idx;
+        }
+    }
+    __syncthreads();
+    if (c < ncodes) {
+        const int b = estart[c] - s0, e = estart[c + 1] - s0;
+        if (staged) {
+            for (int a = b + 1; a < e; a++) {
+                const unsigned long long v = pairs[a];
+                int q = a - 1;
+                while (q >= b && pairs[q] > v) { pairs[q + 1] = pairs[q]; q--; }
+                pairs[q + 1] = v;
+            }
+        } else {
+            // a neighbourhood too dense for the LDS stage: selection into the output, straight from global memory
+            for (int a = b; a < e; a++) {
+                unsigned long long best = ~0ull;
+                // the a-th smallest pair of the segment: smallest pair greater than the previous pick
+                const unsigned long long prev = a == b ? 0ull : (((unsigned long long)key_sorted[s0 + a - 1] << 32) | (u32)val_sorted[s0 + a - 1]);
+                for (int q = b; q < e; q++) {
+                    const int idx = placed[s0 + q];
+                    const unsigned long long v = ((unsigned long long)key[idx] << 32) | (u32)idx;
+                    if ((a == b || v > prev) && v < best) best = v;
+                }
+                val_sorted[s0 + a] = (int)(u32)best;
+                key_sorted[s0 + a] = (u32)(best >> 32);
+                if (inverse) inverse[(u32)best] = s0 + a;
+            }
+        }
+    }
+    __syncthreads();
+    if (staged) {
+        for (int p = threadIdx.x; p < ns; p += REORDER_CODES) {
+            const unsigned long long v = pairs[p];
+            val_sorted[s0 + p] = (int)(u32)v;
+            key_sorted[s0 + p] = (u32)(v >> 32);
+            if (inverse) inverse[(u32)v] = s0 + p;
+        }
+    }
+}
+void launch_reorder_count(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi, uint32_t *key,
+                          int *rank, int *cnt, int n, hipStream_t s)
+{
+    if (n <= 0) return;
+    int bits = reorder_key_bits(g);
+    hipLaunchKernelGGL(k_reorder_keys_count, dim3(nblk(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, slab_lo[0],
+                       slab_lo[1], slab_lo[2], slab_hi[0], slab_hi[1], slab_hi[2], bits - 1, reorder_sub_bits(g), key, rank,
+                       cnt, n);
+}
+void launch_reorder_place(const uint32_t *key, const int *rank, const int *estart, const BinGeom &g, int ncodes, int n, int cap,
+                          int *placed, int *val_sorted, uint32_t *key_sorted, int *cnt, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_reorder_place, dim3(nblk(n, 256)), dim3(256), 0, s, key, rank, estart, reorder_sub_bits(g), n, placed);
+    const size_t dyn = (size_t)cap * 8;
+    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_reorder_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(k_reorder_order, dim3((ncodes + REORDER_CODES) / REORDER_CODES), dim3(REORDER_CODES), dyn, s, estart,
+                       ncodes, key, placed, cap, val_sorted, key_sorted, (int *)nullptr, cnt);
+}
+
+// ghosts: same scheme on the plain Morton code (rank from k_ghost_count, brick.hip); the ordering pass sorts the ghosts of a
+// code by ghost index and writes gslot (ghost -> slot) as the inverse
+void launch_ghost_order(const uint32_t *code, const int *rank, const int *gstart, int M, int nghost, int cap, int *placed,
+                        int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, hipStream_t s)
+{
+    if (nghost > 0) hipLaunchKernelGGL(k_reorder_place, dim3(nblk(nghost, 256)), dim3(256), 0, s, code, rank, gstart, 0, nghost, placed);
+    const size_t dyn = (size_t)cap * 8;
+    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_reorder_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(k_reorder_order, dim3((M + REORDER_CODES) / REORDER_CODES), dim3(REORDER_CODES), dyn, s, gstart, M, code,
+                       placed, cap, slotval, code_sorted, gslot, cnt);
+}
+
 void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi, const int *,
                          uint32_t *key, int *val, int n, hipStream_t s)
 {

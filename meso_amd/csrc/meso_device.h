@@ -353,6 +353,28 @@ __host__ __device__ inline int clampi(int i, int nmin, int nmax)
 // word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63).  A lane writes/reads whole 32-B sectors (no partial-sector
 // writes: the 4-byte scattered stores of the transposed layout cost 8x the bytes at HBM, profiles/r01_pmc_*),
 // and a wave's access to chunk c of its 64 atoms is one contiguous 2 KiB.
+// rank of every lane inside its code, with ONE atomic per run of equal codes in the wave: the atoms arrive nearly sorted, so a
+// wave holds ~7 runs of ~9 equal codes, and same-address atomics serialise in L2 (61 us for 1 M single atomics, 64^3)
+__device__ inline int run_rank(u32 code, bool valid, int *__restrict__ cnt)
+{
+    const int lane = __lane_id();
+    const u32 prev = __shfl_up(code, 1, 64);
+    const bool head = valid && (lane == 0 || code != prev || !__shfl_up((int)valid, 1, 64));
+    const unsigned long long heads = __ballot(head), live = __ballot(valid);
+    int rank = 0;
+    if (valid) {
+        const unsigned long long below = heads & ((2ull << lane) - 1ull);         // heads at or below my lane (never empty)
+        const int start = 63 - __builtin_clzll(below);
+        const unsigned long long after = (heads & ~((2ull << start) - 1ull)) | ~live;   // next head, or the first dead lane
+        const int end = after ? __builtin_ctzll(after) : 64;
+        int base = 0;
+        if (lane == start) base = atomicAdd(cnt + code, end - start);
+        base = __shfl(base, start, 64);
+        rank = base + (lane - start);
+    }
+    return rank;
+}
+
 __device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
 
 // x -> two's-complement 64-bit fixed point with 32 fractional bits: floor(x) in the high word, fract(x) * 2^32 in the low
