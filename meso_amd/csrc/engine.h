@@ -187,6 +187,7 @@ private:
     float *d_poly = nullptr;
     int reorder_sort = 0;    // option: 1 = reorder the locals with the radix/merge sort (the former path), 0 = by counting
     int *rcount = nullptr;   // [2M+1] atoms per extended code
+    int reorder_cap_user = 0;
     int reorder_cap = 2048;  // LDS stage of k_reorder_order (pairs per 128 codes), from the density
     int ghost_sort = 0;      // option: 1 = bin the ghosts with the radix/merge sort (the former path), 0 = by counting
     int *gcount = nullptr;   // [M+1] ghosts per Morton code

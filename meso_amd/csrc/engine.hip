@@ -314,6 +314,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "pair_share") { pair_share = (int)val; return 0; }
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
+    if (key == "reorder_cap") { reorder_cap_user = (int)val; return 0; }      // tests: force the ordering pass off its LDS stage
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
@@ -874,6 +875,7 @@ int Engine::init_params()
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
             const double m128 = density * 128.0 * binvol * brick_margin;
             reorder_cap = std::min(7680, std::max(2048, ((int)std::ceil(m128 + 6.5 * std::sqrt(m128)) + 63) / 64 * 64));
+            if (reorder_cap_user > 0) reorder_cap = reorder_cap_user;
             bargs.maxown = layout == 1 ? brick_static_maxown() : 0;
         }
         if (layout >= 1 && (M / brick_codes() + 8 > brick_cap || bargs.maxh != brick_maxh_alloc)) {

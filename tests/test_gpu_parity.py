@@ -602,3 +602,27 @@ def test_lanes_per_atom_give_identical_forces(Meso, style):
         res.append(m.gather()[2])
         m.close()
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+
+
+@pytest.mark.parametrize("style", ["dpd/meso"])
+def test_reorder_by_counting_equals_reorder_by_sorting(Meso, style):
+    """storage order, neighbour rows and the trajectory (thermostat on) are identical whether the atoms are reordered by
+    counting per cell code or by the sort - also when the ordering pass cannot stage its 128 codes in LDS (reorder_cap 64:
+    the selection fallback) - and for the ghosts likewise"""
+    x, v, lo, hi = make_box(10)
+    res = []
+    for opts in ({"reorder_sort": 1, "ghost_sort": 1}, {}, {"reorder_cap": 64}, {"reorder_sort": 1}, {"ghost_sort": 1}):
+        m = Meso()
+        for k, val in opts.items():
+            m.set_option(k, val)
+        m.read_atoms(x, v, lo, hi); m.neighbor(0.3); m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style(style, 1.0, DP_RUN["seed"]); m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0); m.timestep(0.005)
+        m.setup(); m.run(23)
+        xs, vs, fs, tag, _ = m.gather(by_tag=False)
+        c4, v4 = m.merged()
+        count, table = m.neigh_table()
+        res.append((xs, vs, fs, tag, c4.view(np.uint32), v4.view(np.uint32), count, table))      # (signatures are bit patterns)
+        m.close()
+    for k, other in enumerate(res[1:]):
+        for q, (a, b) in enumerate(zip(res[0], other)):
+            assert np.array_equal(a, b), (k, q)
