@@ -61,6 +61,7 @@ public:
     int64_t prof_start = 0, prof_end = 0;
     int (*prof_pause)(uint64_t) = nullptr;
     int (*prof_resume)(uint64_t) = nullptr;
+    bool merged_in_reorder = false;   // coord4/veloc4 of the locals were written by the reorder gather of this rebuild
     bool restart_forces = false;  // set by read_restart, consumed by setup
     bool upload_all = false;      // read_restart: atoms_upload keeps every atom it is given
     // Angles section + angle_style harmonic/meso (atom_style dpd/angle/meso, angle_harmonic_meso.cu)

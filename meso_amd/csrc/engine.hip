@@ -383,6 +383,7 @@ int Engine::alloc_atoms(int cap)
         }
     }
     HIPCHK(regrow(coord4, 0, c, stream)); HIPCHK(regrow(veloc4, 0, c, stream));
+    merged_in_reorder = false;
     HIPCHK(regrow(coord4_next, 0, c, stream)); HIPCHK(regrow(veloc4_next, 0, c, stream));
     for (int k = 0; k < 6; k++) HIPCHK(regrow(virial[k], 0, c, stream));
     HIPCHK(regrow(e_pair, 0, c, stream));
@@ -938,6 +939,7 @@ void Engine::range(int r, int &beg, int &end) const
 // MesoAtom::sort_local (atom_meso.cu:343-384) + transfer_post_sort, all device resident
 int Engine::reorder_locals()
 {
+    merged_in_reorder = false;
     if (nlocal == 0) {
         n_bulk = 0;
         if (layout >= 1) launch_estart(rkey, 0, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);   // an empty rank: all zero
@@ -966,7 +968,14 @@ int Engine::reorder_locals()
         HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
         launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
     }
-    launch_permute_atoms(cur, alt, rval, nlocal, permute_forces ? 1 : 0, stream);
+    if (layout >= 1) {
+        // the gather also writes the merged float4 pair of the new order, with the signatures of the current step
+        launch_permute_merge(cur, alt, rval, nlocal, permute_forces ? 1 : 0, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
+                             0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), stream);
+        merged_in_reorder = true;      // (alloc_atoms clears it: a regrown coord4 has lost the values)
+    } else {
+        launch_permute_atoms(cur, alt, rval, nlocal, permute_forces ? 1 : 0, stream);
+    }
     std::swap(cur, alt);
     HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
@@ -1087,7 +1096,8 @@ int Engine::build_cells_and_table()
         tend("bin");
         // merged arrays with the signatures of the CURRENT step: the force kernel of this step uses them as they are
         const u32 sd_now = premix_tea<64>((u32)seed, (u32)ntimestep);
-        TRY(merge_locals(sd_now));
+        if (!merged_in_reorder) TRY(merge_locals(sd_now));
+        merged_in_reorder = false;
         TRY(halo_forward_seed(sd_now));
         TRY(rebuild_topology());
         if (layout == 1) {

@@ -64,6 +64,9 @@ void launch_ghost_order(const uint32_t *code, const int *rank, const int *gstart
                         int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, hipStream_t s);
 void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s);
+// ... and the merged float4 pair of the new order in the same pass (k_merge_xvt folded in)
+void launch_permute_merge(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, float4 *coord4,
+                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, hipStream_t s);
 void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s);
 
 // ---- halo: border lists + pack (comm_meso.cu:41-186, atom_vec_dpd_atomic_meso.cu:61-244) --------------

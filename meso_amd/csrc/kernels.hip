@@ -490,19 +490,36 @@ void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int 
 }
 
 // gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
-__global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n, int with_f)
+// mg.coord4 != null: the merged float4 pair of the atom's new place is written as well (gpu_merge_xvt folded into the gather:
+// the reorder has x, v, tag and type in registers anyway; 17 us of re-reading them at 64^3)
+struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; };
+__global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n, int with_f,
+                                                       MergeOut mg)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
     if (i >= n) return;
     int j = from[i];
+    double xx[3], vv[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        dst.x[d][i] = src.x[d][j];
-        dst.v[d][i] = src.v[d][j];
+        xx[d] = src.x[d][j];
+        vv[d] = src.v[d][j];
+        dst.x[d][i] = xx[d];
+        dst.v[d][i] = vv[d];
         if (with_f) dst.f[d][i] = src.f[d][j];      // inside run() the forces are recomputed before anyone reads them
     }
-    dst.tag[i] = src.tag[j];
-    dst.type[i] = src.type[j];
+    const int tg = src.tag[j], ty = src.type[j];
+    if (mg.coord4) {
+        float4 c, v;
+        c.x = (float)(xx[0] - mg.cx); c.y = (float)(xx[1] - mg.cy); c.z = (float)(xx[2] - mg.cz);
+        c.w = __uint_as_float((u32)(ty - 1));
+        v.x = (float)vv[0]; v.y = (float)vv[1]; v.z = (float)vv[2];
+        v.w = __uint_as_float(signature(mg.seed, tg, v.x, v.y, v.z));
+        mg.coord4[i] = c;
+        mg.veloc4[i] = v;
+    }
+    dst.tag[i] = tg;
+    dst.type[i] = ty;
     dst.mask[i] = src.mask[j];
     dst.image[i] = src.image[j];
     dst.mass[i] = src.mass[j];
@@ -524,7 +541,14 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
 }
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s)
 {
-    if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f);
+    MergeOut mg = {nullptr, nullptr, 0.0, 0.0, 0.0, 0u};
+    if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f, mg);
+}
+void launch_permute_merge(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, float4 *coord4,
+                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, hipStream_t s)
+{
+    MergeOut mg = {coord4, veloc4, cx, cy, cz, seed};
+    if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f, mg);
 }
 
 // gpu_permute_from2to (atom_meso.cu:310-314)
