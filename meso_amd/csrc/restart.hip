@@ -46,6 +46,11 @@ static void dfree(T *&p)
 }
 
 namespace {
+struct FileCloser {      // closes on every return path (the HIPCHK / TRY macros return early)
+    FILE *f;
+    ~FileCloser() { if (f) fclose(f); }
+    int close() { int rc = f ? fclose(f) : 0; f = nullptr; return rc; }
+};
 const char MAGIC[8] = {'M', 'E', 'S', 'O', 'H', 'I', 'P', '1'};
 
 struct Writer {
@@ -90,6 +95,7 @@ int Engine::write_restart(const std::string &path)
     HIPCHK(hipStreamSynchronize(stream));
     FILE *f = fopen(rank_path(path, nranks, rank).c_str(), "wb");
     if (!f) return fail(2, "Cannot open restart file " + path);
+    FileCloser fc{f};
     Writer w{f};
     fwrite(MAGIC, 1, 8, f);
     w.pod(nranks); w.pod(rank);
@@ -130,7 +136,7 @@ int Engine::write_restart(const std::string &path)
         HIPCHK(d2h(hi, cur.nangle, n)); w.vec(hi);
         HIPCHK(d2h(hi, cur.angle_tag, n * 4 * apa)); w.vec(hi);
     }
-    const bool ok = w.ok && fclose(f) == 0;
+    const bool ok = w.ok && fc.close() == 0;
     return ok ? 0 : fail(2, "Error while writing restart file " + path);
 }
 
@@ -138,14 +144,14 @@ int Engine::read_restart(const std::string &path)
 {
     FILE *f = fopen(rank_path(path, nranks, rank).c_str(), "rb");
     if (!f) return fail(2, "Cannot open restart file " + path);
+    FileCloser fc{f};
     Reader r{f};
     char magic[8];
-    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, MAGIC, 8)) { fclose(f); return fail(2, "Not a meso-hip restart file: " + path); }
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, MAGIC, 8)) { return fail(2, "Not a meso-hip restart file: " + path); }
     int nr = 0, rk = 0, pg[3] = {1, 1, 1};
     r.pod(nr); r.pod(rk);
     for (int d = 0; d < 3; d++) r.pod(pg[d]);
     if (!r.ok || nr != nranks || rk != rank || pg[0] != procgrid[0] || pg[1] != procgrid[1] || pg[2] != procgrid[2]) {
-        fclose(f);
         return fail(2, "Restart file was written by a different decomposition (the files are per rank)");
     }
     int64_t step = 0;
@@ -156,7 +162,7 @@ int Engine::read_restart(const std::string &path)
     int nt = 0;
     std::vector<double> mt;
     r.pod(nt); r.vec(mt);
-    if (!r.ok || nt < 1 || (int)mt.size() != nt + 1) { fclose(f); return fail(2, "Restart file is damaged: " + path); }
+    if (!r.ok || nt < 1 || (int)mt.size() != nt + 1) { return fail(2, "Restart file is damaged: " + path); }
     TRY(set_box(lo, hi, per));
     ntypes = 0;
     TRY(set_mass(nt, mt.data()));
@@ -172,14 +178,14 @@ int Engine::read_restart(const std::string &path)
     r.vec(bond_kr0); r.pod(nangletypes); r.vec(angle_cf);
     int n = 0;
     r.pod(n);
-    if (!r.ok || n < 0 || (int)coeff.size() != nt * nt * N_COEFF) { fclose(f); return fail(2, "Restart file is damaged: " + path); }
+    if (!r.ok || n < 0 || (int)coeff.size() != nt * nt * N_COEFF) { return fail(2, "Restart file is damaged: " + path); }
     std::vector<double> x[3], v[3], fr[3];
     std::vector<int> tag, type, mask, image;
     for (int d = 0; d < 3; d++) r.vec(x[d]);
     for (int d = 0; d < 3; d++) r.vec(v[d]);
     for (int d = 0; d < 3; d++) r.vec(fr[d]);
     r.vec(tag); r.vec(type); r.vec(mask); r.vec(image);
-    if (!r.ok || (int)tag.size() != n || (int)x[2].size() != n || (int)image.size() != n) { fclose(f); return fail(2, "Restart file is damaged: " + path); }
+    if (!r.ok || (int)tag.size() != n || (int)x[2].size() != n || (int)image.size() != n) { return fail(2, "Restart file is damaged: " + path); }
     std::vector<double> xa((size_t)3 * n), va((size_t)3 * n);
     for (int i = 0; i < n; i++)
         for (int d = 0; d < 3; d++) { xa[3 * (size_t)i + d] = x[d][i]; va[3 * (size_t)i + d] = v[d][i]; }
@@ -188,7 +194,7 @@ int Engine::read_restart(const std::string &path)
     bpa = msp = apa = 0;
     int rc = atoms_upload(n, xa.data(), va.data(), tag.data(), type.data(), mask.data(), image.data());
     upload_all = false;
-    if (rc) { fclose(f); return rc; }
+    if (rc) return rc;
     for (int d = 0; d < 3; d++)
         if ((int)fr[d].size() == n && n) HIPCHK(hipMemcpy(cur.f[d], fr[d].data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     dfree(d_bond_kr0); dfree(d_angle_cf);
@@ -218,7 +224,7 @@ int Engine::read_restart(const std::string &path)
         have_bonds = true;
         have_angles = topo[6] != 0;
     }
-    fclose(f);
+    fc.close();
     if (rc) return rc;
     if (!r.ok) return fail(2, "Restart file is damaged: " + path);
     ntimestep = step;
