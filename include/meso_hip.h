@@ -46,6 +46,7 @@ int meso_device_sync(meso_ctx *ctx);
  *   fuse_step     1  final(s) + initial(s+1) + merge(s+1) in one pass between the steps of one run
  *   fuse_pair     1  ... inside the ring kernel's epilogue (forces are then not stored on those steps)
  *   pair_share    1  ring kernel: pairs inside one aligned 256-atom group are evaluated once (Newton pairing)
+ *   tile_plan     0  the tile builder computes each brick's plan (halo runs, slot map) itself | 1 separate k_brick_plan launch
  *   reorder_sort  0  locals reordered by counting per [border][Morton(bin)] code | 1 by rocPRIM's sort (former path, same order)
  *   ghost_sort    0  ghosts binned by counting per Morton code | 1 by sorting them (former path, same storage order)
  *   pair_npart    0  ring kernel: lanes per atom; 0 = by launch size (2 up to 163 840 atoms, else 1) | 1 | 2 | 4

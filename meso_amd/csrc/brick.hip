@@ -256,16 +256,76 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     const int part = (int)blockIdx.x % split;
     const int slot = (int)blockIdx.x / split;
     if (slot >= g.nactive) return;
-    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
-    const int nh = hdr[0];
-    if (hdr[2] + hdr[4] == 0) return;
-    for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
-    for (int t = tid; t < BRK_NHB; t += BRK_THREADS) hloc[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + t];
-    for (int h = tid; h < nh; h += BRK_THREADS) {
-        const u32 src = g.hmap[(size_t)slot * g.maxh + h];
-        hgi[h] = src;
-        const float4 c = coord4[src];
-        hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+    int nh;
+    if (g.plan_inline) {
+        // the brick's plan (k_brick_plan) computed here, in LDS: the halo-bin runs from estart / gstart, their prefix, and
+        // the halo slot -> global index map by binary search - no plan launch, no round trip of the map through HBM
+        __shared__ int wtot[4];
+        int *hs0 = (int *)rowbuf, *hl0 = hs0 + BRK_NHB, *hs1 = hl0 + BRK_NHB, *hl1 = hs1 + BRK_NHB, *hs2 = hl1 + BRK_NHB;   // rows are not staged yet
+        const int B = slot;                  // identity brick list (cell-ordered layout)
+        const size_t e0 = (size_t)BRK_CODES * B;
+        if (g.estart[e0 + BRK_CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + BRK_CODES] - g.estart[(size_t)g.M + e0] == 0) return;
+        const u32 code0 = (u32)e0;
+        const int bx0 = (int)compact3(code0), by0 = (int)compact3(code0 >> 1), bz0 = (int)compact3(code0 >> 2);
+        int tot = 0;
+        if (tid < BRK_NHB) {
+            const int qx = bx0 - 1 + tid % BRK_H, qy = by0 - 1 + (tid / BRK_H) % BRK_H, qz = bz0 - 1 + tid / (BRK_H * BRK_H);
+            int s0 = 0, l0 = 0, s1 = 0, l1 = 0, s2 = 0, l2 = 0;
+            if (qx >= 0 && qx < g.mbin[0] && qy >= 0 && qy < g.mbin[1] && qz >= 0 && qz < g.mbin[2]) {
+                const u32 m = interleave3((u32)qx, (u32)qy, (u32)qz);
+                s0 = g.estart[m]; l0 = g.estart[m + 1] - s0;
+                s1 = g.estart[(size_t)g.M + m]; l1 = g.estart[(size_t)g.M + m + 1] - s1;
+                s2 = g.ghost_base + g.gstart[m]; l2 = g.gstart[m + 1] - g.gstart[m];
+            }
+            hs0[tid] = s0; hl0[tid] = l0; hs1[tid] = s1; hl1[tid] = l1; hs2[tid] = s2;
+            hloc[tid] = l0 + l1;
+            tot = l0 + l1 + l2;
+        }
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63 && w < 4) wtot[w] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < w && k < 4; k++) base += wtot[k];
+        if (tid < BRK_NHB) hoff[tid] = base + incl - tot;
+        if (tid == BRK_NHB - 1) hoff[BRK_NHB] = base + incl;
+        __syncthreads();
+        nh = hoff[BRK_NHB];
+        if (nh > g.maxh) {
+            if (tid == 0) atomicMax(overflow, 100000 + nh);
+            return;
+        }
+        for (int h = tid; h < nh; h += BRK_THREADS) {
+            int lo = 0, hi = BRK_NHB;            // largest halo bin with hoff[bin] <= h
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (hoff[mid] <= h) lo = mid; else hi = mid;
+            }
+            int off = h - hoff[lo];
+            u32 src;
+            if (off < hl0[lo]) src = (u32)(hs0[lo] + off);
+            else if ((off -= hl0[lo]) < hl1[lo]) src = (u32)(hs1[lo] + off);
+            else src = (u32)(hs2[lo] + (off - hl1[lo]));
+            hgi[h] = src;
+            const float4 c = coord4[src];
+            hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+        }
+    } else {
+        const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
+        nh = hdr[0];
+        if (hdr[2] + hdr[4] == 0) return;
+        for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
+        for (int t = tid; t < BRK_NHB; t += BRK_THREADS) hloc[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + t];
+        for (int h = tid; h < nh; h += BRK_THREADS) {
+            const u32 src = g.hmap[(size_t)slot * g.maxh + h];
+            hgi[h] = src;
+            const float4 c = coord4[src];
+            hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+        }
     }
     __syncthreads();
     unsigned short *myrow0 = rowbuf + (size_t)w * TB_G * n_col;

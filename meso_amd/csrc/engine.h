@@ -186,6 +186,7 @@ private:
     bool pair_poly = false;  // pair_style dpd/polyforce/meso: fp32 arithmetic, polynomial conservative force
     std::vector<float> poly; // [ntypes^2][MESO_POLY_PITCH]
     float *d_poly = nullptr;
+    int tile_plan = 0;       // option: 1 = separate k_brick_plan launch before the tile builder (former path), 0 = plan inside it
     int reorder_sort = 0;    // option: 1 = reorder the locals with the radix/merge sort (the former path), 0 = by counting
     int *rcount = nullptr;   // [2M+1] atoms per extended code
     int reorder_cap_user = 0;

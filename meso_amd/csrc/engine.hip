@@ -314,6 +314,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "pair_share") { pair_share = (int)val; return 0; }
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
+    if (key == "tile_plan") { tile_plan = (int)val; return 0; }
     if (key == "reorder_cap") { reorder_cap_user = (int)val; return 0; }      // tests: force the ordering pass off its LDS stage
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
@@ -1114,7 +1115,9 @@ int Engine::build_cells_and_table()
             if (neigh_kernel == 1 && n_col <= tile_build_rowcap() && tile_fits) {
                 // wave-per-bin ballot builder on LDS-staged neighbourhoods (every brick: empty ones exit at once)
                 bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
-                launch_brick_plan(bargs, d_flags, stream);
+                // (the inline plan borrows the row stage for its run tables: 5 x 216 ints)
+                bargs.plan_inline = (tile_plan == 0 && bargs.active == nullptr && n_col >= 64) ? 1 : 0;
+                if (!bargs.plan_inline) launch_brick_plan(bargs, d_flags, stream);
                 launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr,
                                   pair_debug >= 10 ? pair_debug - 10 : 0, stream);
                 tend("neigh");

@@ -185,6 +185,7 @@ struct BrickArgs {
     uint32_t *hmap;      // [slot][nh]  halo slot -> global atom index
     int *hdr;            // [slot]{nh, o0, n0, o1, n1}: halo size, own runs of the bulk and border sections
     uint32_t *own_info;  // [nlocal]    own atom -> halo slot | halo bin << 16
+    int plan_inline;     // tile builder computes the brick's plan itself (no k_brick_plan launch; identity brick list only)
 };
 int brick_codes();
 int brick_static_maxh();
