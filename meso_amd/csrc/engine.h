@@ -61,6 +61,7 @@ public:
     int64_t prof_start = 0, prof_end = 0;
     int (*prof_pause)(uint64_t) = nullptr;
     int (*prof_resume)(uint64_t) = nullptr;
+    bool wrap_in_reorder = false;     // this rebuild's periodic wrap is done by the reorder's key kernel
     bool merged_in_reorder = false;   // coord4/veloc4 of the locals were written by the reorder gather of this rebuild
     bool restart_forces = false;  // set by read_restart, consumed by setup
     bool upload_all = false;      // read_restart: atoms_upload keeps every atom it is given

@@ -952,7 +952,8 @@ int Engine::reorder_locals()
         // counting per extended code instead of a comparison sort (kernels.hip): ~8 launches instead of ~28; estart - first
         // index of every extended code ([border][Morton(bin)]), the border section starts at estart[M] = n_bulk - is the scan
         const int ncodes = 2 * bargs.M;
-        launch_reorder_count(cur, geom, slab_lo, slab_hi, rkey, rval_alt, rcount, nlocal, stream);
+        launch_reorder_count(cur, geom, slab_lo, slab_hi, rkey, rval_alt, rcount, nlocal, wrap_in_reorder ? boxlo : nullptr, boxhi, periodic,
+                             stream);
         HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, rcount, estart, ncodes + 1, stream));
         launch_reorder_place(rkey, rval_alt, estart, geom, ncodes, nlocal, reorder_cap, (int *)rkey_alt, rval, (uint32_t *)bin_key_alt, rcount,
                              stream);
@@ -1190,7 +1191,9 @@ int Engine::check_overflow()
 int Engine::reneighbor()
 {
     TRY(init_params());
-    launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
+    // one rank: nothing happens between the wrap and the reorder, which reads the coordinates anyway - wrapped there
+    wrap_in_reorder = nranks == 1 && layout >= 1 && !reorder_sort && nlocal > 0;
+    if (!wrap_in_reorder) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
     TRY(migrate());
     TRY(reorder_locals());
     TRY(halo_borders());

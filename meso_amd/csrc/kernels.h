@@ -57,7 +57,8 @@ void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_
                          const int *dim_active, uint32_t *key, int *val, int n, hipStream_t s);
 // reorder by counting per extended code (no comparison sort): count -> scan (caller) -> place + order
 void launch_reorder_count(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi, uint32_t *key,
-                          int *rank, int *cnt, int n, hipStream_t s);
+                          int *rank, int *cnt, int n, const double *wrap_lo, const double *wrap_hi, const int *wrap_per,
+                          hipStream_t s);      // wrap_lo != null: the periodic wrap (k_pbc) happens here
 void launch_reorder_place(const uint32_t *key, const int *rank, const int *estart, const BinGeom &g, int ncodes, int n, int cap,
                           int *placed, int *val_sorted, uint32_t *key_sorted, int *cnt, hipStream_t s);
 void launch_ghost_order(const uint32_t *code, const int *rank, const int *gstart, int M, int nghost, int cap, int *placed,

@@ -341,17 +341,36 @@ __global__ void __launch_bounds__(256) k_reorder_keys(const double *__restrict__
 // (the atomic's return value is the atom's rank inside its code), the counts are scanned into estart (which the list
 // builder needs anyway), every atom is placed at estart[code] + rank, and one pass per group of 128 codes puts the few
 // atoms of each code in (sub-cell key, old index) order in LDS - the order the sort gave, so storage stays deterministic.
+// wrap != null: MesoDomain::pbc (k_pbc) folded in - one rank has no migration between the wrap and the reorder, so the
+// coordinates are wrapped here, on their way to the key (written back only where they changed)
+struct WrapArgs { double *x, *y, *z; int *image; double lo[3], hi[3]; int per[3]; };
 __global__ void __launch_bounds__(256) k_reorder_keys_count(const double *__restrict__ x, const double *__restrict__ y,
                                                             const double *__restrict__ z, BinGeom g, double slx, double sly,
                                                             double slz, double shx, double shy, double shz, int border_bit,
                                                             int sub_bits, u32 *__restrict__ key, int *__restrict__ rank,
-                                                            int *__restrict__ cnt, int n)
+                                                            int *__restrict__ cnt, int n, WrapArgs wr)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
     const bool valid = i < n;
     u32 k = 0;
     if (valid) {
-        const double c[3] = {x[i], y[i], z[i]};
+        double c[3] = {x[i], y[i], z[i]};
+        if (wr.image) {
+            const int img = wr.image[i];
+            int im[3] = {img & 1023, (img >> 10) & 1023, img >> 20};
+            bool moved = false;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                if (!wr.per[d]) continue;
+                const double p = wr.hi[d] - wr.lo[d];
+                if (c[d] < wr.lo[d]) { c[d] += p; im[d] = (im[d] - 1) & 1023; moved = true; }
+                if (c[d] >= wr.hi[d]) { c[d] -= p; c[d] = fmax(c[d], wr.lo[d]); im[d] = (im[d] + 1) & 1023; moved = true; }
+            }
+            if (moved) {
+                wr.x[i] = c[0]; wr.y[i] = c[1]; wr.z[i] = c[2];
+                wr.image[i] = im[0] | (im[1] << 10) | (im[2] << 20);
+            }
+        }
         const int res = 1 << (sub_bits / 3);
         u32 b[3], sc[3];
 #pragma unroll
@@ -433,13 +452,19 @@ __global__ void __launch_bounds__(REORDER_CODES) k_reorder_order(const int *__re
     }
 }
 void launch_reorder_count(const AtomSoA &a, const BinGeom &g, const double *slab_lo, const double *slab_hi, uint32_t *key,
-                          int *rank, int *cnt, int n, hipStream_t s)
+                          int *rank, int *cnt, int n, const double *wrap_lo, const double *wrap_hi, const int *wrap_per,
+                          hipStream_t s)
 {
     if (n <= 0) return;
     int bits = reorder_key_bits(g);
+    WrapArgs wr = {nullptr, nullptr, nullptr, nullptr, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    if (wrap_lo) {
+        wr.x = a.x[0]; wr.y = a.x[1]; wr.z = a.x[2]; wr.image = a.image;
+        for (int d = 0; d < 3; d++) { wr.lo[d] = wrap_lo[d]; wr.hi[d] = wrap_hi[d]; wr.per[d] = wrap_per[d]; }
+    }
     hipLaunchKernelGGL(k_reorder_keys_count, dim3(nblk(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, slab_lo[0],
                        slab_lo[1], slab_lo[2], slab_hi[0], slab_hi[1], slab_hi[2], bits - 1, reorder_sub_bits(g), key, rank,
-                       cnt, n);
+                       cnt, n, wr);
 }
 void launch_reorder_place(const uint32_t *key, const int *rank, const int *estart, const BinGeom &g, int ncodes, int n, int cap,
                           int *placed, int *val_sorted, uint32_t *key_sorted, int *cnt, hipStream_t s)
