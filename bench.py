@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0 = auto)")
     ap.add_argument("--profile-steps", type=int, default=200)
+    ap.add_argument("--polymer", type=float, default=0.0,
+                    help="fraction of the beads in A2B4 chains with harmonic bonds (configs[4]: 0.1); 0 = plain fluid")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="multi-rank transport: rccl (production) or host (gloo point-to-point through host buffers: lets several "
                          "ranks share one GPU, for rehearsing the multi-process flow on a one-GPU box)")
@@ -111,7 +113,12 @@ def main():
 
     dist = None
     L = a.box
-    x, v, lo, hi = make_box(L)
+    types = bonds = None
+    if a.polymer > 0:
+        from meso_amd.datagen import make_polymer_box
+        x, v, types, bonds, lo, hi = make_polymer_box(L, frac=a.polymer)
+    else:
+        x, v, lo, hi = make_box(L)
     n = len(x)
     ndev = max(1, torch.cuda.device_count())
     if a.transport == "rccl" and world > ndev:
@@ -142,11 +149,23 @@ def main():
             dist.init_process_group("gloo")
             m.set_host_exchange(make_exchange(dist, rank))
             m.comm_init(world, rank, grid, "host")
-    m.read_atoms(x, v, lo, hi)
+    if bonds is None:
+        m.read_atoms(x, v, lo, hi)
+    else:
+        # configs[4] (build-defined deck): amphiphilic A2B4 chains, harmonic bonds k = 50, r0 = 0.5, a_AB = 40
+        m.read_atoms(x, v, lo, hi, types=types, ntypes=2)
+        m.special_bonds(0.0, 1.0, 1.0)
+        m.read_bonds(bonds)
+        m.bond_style("harmonic/meso", 1)
+        m.bond_coeff(1, 50.0, 0.5)
     m.neighbor(0.3)
     m.neigh_modify(delay=0, every=a.every, check=False)
     m.pair_style(a.style, 1.0, 419084618)
-    m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    if bonds is None:
+        m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    else:
+        for (ti, tj), a0 in {(1, 1): 15.0, (2, 2): 15.0, (1, 2): 40.0}.items():
+            m.pair_coeff(ti, tj, a0, 4.5, 3.0, 1.0, 1.0)
     m.timestep(0.005)
     m.setup()
 
@@ -241,8 +260,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if fp32 else "f64",
         "data": "synthetic",
-        "config": {"workload": "%d^3 box rho=4 (N=%d), pair_style %s, neighbor 0.3 bin, rebuild every %d, dt 0.005, "
-                               "%d MI355X, procgrid %dx%dx%d" % ((L, n, a.style, a.every, a.gpus) + tuple(grid)),
+        "config": {"workload": "%d^3 box rho=4 (N=%d)%s, pair_style %s, neighbor 0.3 bin, rebuild every %d, dt 0.005, "
+                               "%d MI355X, procgrid %dx%dx%d" % ((L, n, ", %.0f %% of the beads in bonded A2B4 chains" % (100 * a.polymer)
+                                                                  if a.polymer > 0 else "", a.style, a.every, a.gpus) + tuple(grid)),
                    "M_particle_steps_per_s": steps_per_s * n / 1e6,
                    "avg_neighbors": info["avg_count"], "temperature_end": T},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -251,7 +271,7 @@ def main():
                      "pair_only": pair_only},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
     }
-    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and bonds is None:
         line["cpu_baseline"] = cpu_baseline(L, x, v, lo, hi, a.every, a.cpu_steps)
         line["config"]["gpu_over_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
     m.close()

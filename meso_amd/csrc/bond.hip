@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) k_bond(const float4 *__restrict__ coord4,
                                               const int *__restrict__ bond_idx, const int *__restrict__ bond_type, int bpa,
                                               const double *__restrict__ cf, int nbt, double px, double py, double pz,
                                               int nlocal, double *__restrict__ fx_, double *__restrict__ fy_,
-                                              double *__restrict__ fz_, double *__restrict__ e_bond)
+                                              double *__restrict__ fz_, double *__restrict__ e_bond, int store)
 {
     extern __shared__ double sh[];
     const int ncf = (STYLE == 1 ? 4 : 2) * (nbt + 1);
@@ -72,7 +72,11 @@ __global__ void __launch_bounds__(256) k_bond(const float4 *__restrict__ coord4,
     const double *k = sh, *r0 = sh + nbt + 1, *eps = sh + 2 * (nbt + 1), *sig = sh + 3 * (nbt + 1);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nlocal; i += gridDim.x * blockDim.x) {
         const int n = nbond[i];
-        if (n == 0) { if (EV) e_bond[i] = 0.0; continue; }
+        if (n == 0) {
+            if (EV) e_bond[i] = 0.0;
+            if (store && fx_) { fx_[i] = 0.0; fy_[i] = 0.0; fz_[i] = 0.0; }      // store mode: this kernel opens the step's forces
+            continue;
+        }
         const float4 c1 = coord4[i];
         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
         for (int b = 0; b < n; b++) {
@@ -107,7 +111,10 @@ __global__ void __launch_bounds__(256) k_bond(const float4 *__restrict__ coord4,
                 fx += dx * fbond; fy += dy * fbond; fz += dz * fbond;
             }
         }
-        if (fx_) { fx_[i] += fx; fy_[i] += fy; fz_[i] += fz; }   // null: energy-only pass (compute_ebond)
+        if (fx_) {   // null: energy-only pass (compute_ebond)
+            if (store) { fx_[i] = fx; fy_[i] = fy; fz_[i] = fz; }
+            else { fx_[i] += fx; fy_[i] += fy; fz_[i] += fz; }
+        }
         if (EV) e_bond[i] = e * 0.5;
     }
 }
@@ -219,7 +226,7 @@ void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int 
 }
 void launch_bond(int style, const float4 *coord4, const int *nbond, const int *bond_idx, const int *bond_type, int bpa,
                  const double *cf, int nbt, const double *prd, int nlocal, double *fx, double *fy, double *fz, double *e_bond,
-                 hipStream_t s)
+                 int store, hipStream_t s)
 {
     if (nlocal <= 0) return;
     int g = nblk(nlocal, 256);
@@ -227,7 +234,7 @@ void launch_bond(int style, const float4 *coord4, const int *nbond, const int *b
     size_t sm = (style == 1 ? 4 : 2) * (size_t)(nbt + 1) * sizeof(double);
 #define BOND_LAUNCH(S, E)                                                                                                  \
     hipLaunchKernelGGL((k_bond<S, E>), dim3(g), dim3(256), sm, s, coord4, nbond, bond_idx, bond_type, bpa, cf, nbt, prd[0],   \
-                       prd[1], prd[2], nlocal, fx, fy, fz, e_bond)
+                       prd[1], prd[2], nlocal, fx, fy, fz, e_bond, store)
     if (style == 1) { if (e_bond) BOND_LAUNCH(1, true); else BOND_LAUNCH(1, false); }
     else { if (e_bond) BOND_LAUNCH(0, true); else BOND_LAUNCH(0, false); }
 #undef BOND_LAUNCH

@@ -43,7 +43,7 @@ public:
     int special_bonds(double w12, double w13, double w14);
     int bond_style(int nbondtypes, int kind = 0);      // kind 0: harmonic/meso, 1: fene/meso
     int bond_coeff(int type, double k, double r0, double eps = 0.0, double sigma = 0.0);
-    int bond_compute(int eflag);
+    int bond_compute(int eflag, int store = 0);
     int compute_ebond(double *e);
     // restart.hip: per-rank restart files of the stand-alone driver, profiler window (-profile all|core|loop|interval)
     int write_restart(const std::string &path);

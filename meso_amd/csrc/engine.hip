@@ -555,7 +555,7 @@ int Engine::rebuild_topology()
 }
 
 // BondHarmonic::compute / gpu_bond_harmonic (bond_harmonic_meso.cu:46-117), MesoBondFENE::compute (bond_fene_meso.cu:150-214)
-int Engine::bond_compute(int eflag)
+int Engine::bond_compute(int eflag, int store)
 {
     if (!have_bonds || nbondtypes == 0) return 0;
     if (!d_bond_kr0) {
@@ -564,7 +564,7 @@ int Engine::bond_compute(int eflag)
     }
     tbegin("bond");
     launch_bond(bond_kind, coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, cur.f[0], cur.f[1],
-                cur.f[2], eflag ? e_bond : nullptr, stream);
+                cur.f[2], eflag ? e_bond : nullptr, store, stream);
     tend("bond");
     return 0;
 }
@@ -574,7 +574,7 @@ int Engine::compute_ebond(double *e)
     if (!have_bonds || nbondtypes == 0 || !is_setup || !d_bond_kr0) { *e = 0.0; return 0; }
     // energy at the coordinates of the last force evaluation (what thermo prints on an eflag step, src/thermo.cpp ebond)
     launch_bond(bond_kind, coord4, cur.nbond, bond_idx, cur.bond_type, bpa, d_bond_kr0, nbondtypes, prd, nlocal, nullptr, nullptr,
-                nullptr, e_bond, stream);
+                nullptr, e_bond, 0, stream);
     std::vector<double> h((size_t)nlocal);
     HIPCHK(hipMemcpyAsync(h.data(), e_bond, nlocal * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -1387,8 +1387,17 @@ int Engine::run(int nsteps)
         // the merged arrays of step s+1 go to the second buffer (this step's are still being gathered from)
         const int a1 = ago + 1;
         const bool next_rebuild = dist_check || (a1 >= delay && a1 % every == 0);
-        const bool boundary_in_pair = fuse_pair && fuse_step && it + 1 < nsteps && !have_bonds && ring_selected();
+        // bonded systems: bond and angle forces depend on this step's merged coordinates only, so they are computed FIRST (the
+        // bond kernel opens the force arrays) and the force kernel's epilogue adds them to its sums before the step boundary.
+        // Not with the bulk/border overlap of several ranks: bonds across a face need the ghosts the bulk launch does not wait for.
+        const bool bonded_first = have_bonds && nbondtypes > 0 && !split;
+        const bool boundary_in_pair = fuse_pair && fuse_step && it + 1 < nsteps && (!have_bonds || bonded_first) && ring_selected();
         p.fuse_nve = boundary_in_pair ? 1 : 0;
+        if (boundary_in_pair && bonded_first) {
+            TRY(bond_compute(0, 1));
+            TRY(angle_compute(0));
+            p.accumulate = 1;
+        }
         if (boundary_in_pair)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
                                   0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
@@ -1410,8 +1419,10 @@ int Engine::run(int nsteps)
                 tend("pair");
             }
         }
-        TRY(bond_compute(0));
-        TRY(angle_compute(0));
+        if (!(boundary_in_pair && bonded_first)) {
+            TRY(bond_compute(0));
+            TRY(angle_compute(0));
+        }
         if (boundary_in_pair) {
             if (!next_rebuild) { std::swap(coord4, coord4_next); std::swap(veloc4, veloc4_next); }
             initial_done = true;

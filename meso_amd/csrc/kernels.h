@@ -231,7 +231,7 @@ void launch_angle_harmonic(const float4 *coord4, const int *nangle, const int *a
 // style 0: harmonic, cf = [k][r0]; style 1: FENE, cf = [k][r0][epsilon][sigma] (each nbt + 1 long)
 void launch_bond(int style, const float4 *coord4, const int *nbond, const int *bond_idx, const int *bond_type, int bpa,
                  const double *cf, int nbt, const double *prd, int nlocal, double *fx, double *fy, double *fz, double *e_bond,
-                 hipStream_t s);
+                 int store, hipStream_t s);      // store: f = bond force (opens the step's forces) instead of f += bond force
 struct ExclArgs {            // special-partner filter of the list builder (null tagc: no exclusions)
     const int *tagc, *nspecial, *special;
     int msp;
