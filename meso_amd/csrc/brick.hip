@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     extern __shared__ float tb_dyn[];
     float *hx = tb_dyn, *hy = hx + g.maxh, *hz = hy + g.maxh;
     u32 *hgi = (u32 *)(hz + g.maxh);
-    unsigned short *rowbuf = (unsigned short *)(hgi + g.maxh);          // [wave][TB_G][n_col]
+    int *htag = (int *)(hgi + g.maxh);                                   // EXCL only: tags of the staged atoms
+    unsigned short *rowbuf = (unsigned short *)(EXCL ? (u32 *)(htag + g.maxh) : hgi + g.maxh);          // [wave][TB_G][n_col]
     __shared__ int hoff[BRK_NHB + 1];
     __shared__ int hloc[BRK_NHB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -311,6 +312,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             else if ((off -= hl0[lo]) < hl1[lo]) src = (u32)(hs1[lo] + off);
             else src = (u32)(hs2[lo] + (off - hl1[lo]));
             hgi[h] = src;
+            if (EXCL) htag[h] = ex.tagc[src];
             const float4 c = coord4[src];
             hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
         }
@@ -323,6 +325,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
         for (int h = tid; h < nh; h += BRK_THREADS) {
             const u32 src = g.hmap[(size_t)slot * g.maxh + h];
             hgi[h] = src;
+            if (EXCL) htag[h] = ex.tagc[src];
             const float4 c = coord4[src];
             hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
         }
@@ -363,7 +366,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             cx = valid ? hx[cs] : 1.0e18f;       // never inside the cutoff
             cy = hy[cs]; cz = hz[cs];
             ctag = 0;
-            if (EXCL) ctag = ex.tagc[hgi[cs]];
+            if (EXCL) ctag = htag[cs];          // (staged with the neighbourhood: a gather from global memory per candidate before)
         };
         int cs4[4], ct4[4];
         float cx4[4], cy4[4], cz4[4];
@@ -754,7 +757,7 @@ int brick_codes() { return BRK_CODES; }
 int brick_static_maxh() { return BRK_MAXH; }        // capacity of the brick-layout kernels (static LDS arrays)
 int brick_static_maxown() { return BRK_MAXOWN; }
 // largest halo the tile builder can stage: 160 KB of LDS minus its static part (row staging, bin offsets), 16 B per atom
-int tile_build_maxh_limit(int n_col) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / 16); }
+int tile_build_maxh_limit(int n_col, int with_tags) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / (with_tags ? 20 : 16)); }
 size_t brick_hoff_pitch() { return BRK_HOFF_PITCH; }
 size_t brick_hdr_pitch() { return BRK_HDR_PITCH; }
 
@@ -803,7 +806,8 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     while (split < 4 && g.nactive * split < 2 * 3 * 256) split *= 2;
     const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
     ExclArgs ex = {nullptr, nullptr, nullptr, 0};
-    const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2;
+    const bool with_tags = excl && excl->tagc;
+    const size_t dyn = (size_t)g.maxh * (with_tags ? 20 : 16) + (size_t)BRK_WAVES * TB_G * n_col * 2;
     if (dyn > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)k_tile_build<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         (void)hipFuncSetAttribute((const void *)k_tile_build<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);

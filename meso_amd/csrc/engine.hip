@@ -872,7 +872,7 @@ int Engine::init_params()
             int want = ((int)std::ceil(mean + 6.5 * std::sqrt(mean)) + 63) / 64 * 64;
             if (layout == 1) want = brick_static_maxh();
             else if (want < brick_static_maxh()) want = brick_static_maxh();
-            tile_fits = want <= tile_build_maxh_limit(n_col);
+            tile_fits = want <= tile_build_maxh_limit(n_col, have_bonds && msp > 0 ? 1 : 0);
             bargs.maxh = want;
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
             const double m128 = density * 128.0 * binvol * brick_margin;

@@ -191,7 +191,7 @@ struct BrickArgs {
 int brick_codes();
 int brick_static_maxh();
 int brick_static_maxown();
-int tile_build_maxh_limit(int n_col);
+int tile_build_maxh_limit(int n_col, int with_tags);   // with_tags: special-bond filter active (tags staged too)
 size_t brick_hoff_pitch();
 size_t brick_hdr_pitch();
 void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s);
