@@ -47,6 +47,10 @@ def lmp_lib():
         L.lmp_set_mass.argtypes = [_vp, _i, _d]
         L.lmp_set_timestep.argtypes = [_vp, _d]
         L.lmp_set_neighbor.argtypes = [_vp, _d, _i, _i]
+        L.lmp_set_sortfreq.argtypes = [_vp, _i]
+        L.lmp_get_ev.argtypes = [_vp, _vp]
+        L.lmp_ranmars_stream.argtypes = [_i, _i, _vp, _vp]
+        L.lmp_ranpark_stream.argtypes = [_i, _i, _vp, _vp]
         L.lmp_pair_style_dpd.argtypes = [_vp, _d, _d, _i]
         L.lmp_pair_coeff.argtypes = [_vp, _i, _i, _d, _d, _d]
         L.lmp_velocity_create.argtypes = [_vp, _d, _i]
@@ -102,6 +106,18 @@ class LmpDpd:
     def timestep(self, dt):
         self.L.lmp_set_timestep(self.h, dt)
 
+    def set_mass(self, t, m):
+        self.L.lmp_set_mass(self.h, t, m)
+
+    def atom_modify_sort(self, freq):
+        self.L.lmp_set_sortfreq(self.h, freq)
+
+    def ev(self):
+        """(eng_vdwl, virial[6]) of the last energy/virial step."""
+        out = np.empty(7)
+        self.L.lmp_get_ev(self.h, _ptr(out))
+        return out[0], out[1:].copy()
+
     def setup(self):
         self.L.lmp_setup(self.h)
 
@@ -118,6 +134,16 @@ class LmpDpd:
         x = np.empty((self.n, 3)); v = np.empty((self.n, 3)); f = np.empty((self.n, 3))
         self.L.lmp_get_state(self.h, _ptr(x), _ptr(v), _ptr(f))
         return x, v, f
+
+
+def rng_stream(kind, seed, n):
+    """n uniform() then n gaussian() draws of the restated RanMars ("mars") / RanPark ("park")."""
+    L = lmp_lib()
+    u, g = np.empty(n), np.empty(n)
+    fn = L.lmp_ranmars_stream if kind == "mars" else L.lmp_ranpark_stream
+    if fn(int(seed), int(n), _ptr(u), _ptr(g)):
+        raise ValueError("invalid seed")
+    return u, g
 
 
 def meso_lib():

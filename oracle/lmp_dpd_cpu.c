@@ -135,6 +135,44 @@ static double park_uniform(int *seed)
     return AM * (*seed);
 }
 
+/* the two generators as plain streams (n uniform() draws, then n gaussian() draws): what tests/test_oracle_ref.py
+ * compares bit for bit with the reference's own random_mars.cpp / random_park.cpp built into oracle/_ref */
+int lmp_ranmars_stream(int seed, int n, double *uni, double *gau)
+{
+    RanMars r;
+    if (mars_init(&r, seed)) return -1;
+    for (int i = 0; i < n; i++) uni[i] = mars_uniform(&r);
+    for (int i = 0; i < n; i++) gau[i] = mars_gaussian(&r);
+    return 0;
+}
+
+/* RanPark::gaussian (random_park.cpp:53-76): the same polar method on the Park-Miller stream */
+int lmp_ranpark_stream(int seed, int n, double *uni, double *gau)
+{
+    if (seed <= 0) return -1;
+    int s = seed, save = 0;
+    double second = 0.0;
+    for (int i = 0; i < n; i++) uni[i] = park_uniform(&s);
+    for (int i = 0; i < n; i++) {
+        if (!save) {
+            double v1, v2, rsq;
+            do {
+                v1 = 2.0 * park_uniform(&s) - 1.0;
+                v2 = 2.0 * park_uniform(&s) - 1.0;
+                rsq = v1 * v1 + v2 * v2;
+            } while (rsq >= 1.0 || rsq == 0.0);
+            double fac = sqrt(-2.0 * log(rsq) / rsq);
+            second = v1 * fac;
+            gau[i] = v2 * fac;
+            save = 1;
+        } else {
+            gau[i] = second;
+            save = 0;
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------ system ----------------------------------- */
 typedef struct {
     /* atoms */
@@ -258,6 +296,9 @@ void lmp_set_velocities(LmpSys *s, const double *v)
 
 void lmp_set_mass(LmpSys *s, int type, double m) { s->mass[type] = m; }
 void lmp_set_timestep(LmpSys *s, double dt) { s->dt = dt; }
+/* atom_modify sort N binsize (atom.cpp:62: default 1000; 0 switches Atom::sort off - the setting under which
+ * oracle/_ref, which cannot contain atom.cpp, is compared with this file) */
+void lmp_set_sortfreq(LmpSys *s, int freq) { s->sortfreq = freq; }
 void lmp_set_neighbor(LmpSys *s, double skin, int every, int delay)
 {
     s->skin = skin; s->every = every; s->delay = delay;
@@ -861,6 +902,13 @@ double lmp_pressure(const LmpSys *s)
     double dof = 3.0 * s->nlocal - 3.0;
     double vol = s->prd[0] * s->prd[1] * s->prd[2];
     return (dof * lmp_temperature(s) + s->virial[0] + s->virial[1] + s->virial[2]) / 3.0 / vol;
+}
+
+/* eng_vdwl and the six virial components of the last ev step (Pair::eng_vdwl, Pair::virial) */
+void lmp_get_ev(const LmpSys *s, double *out7)
+{
+    out7[0] = s->eng_vdwl;
+    for (int k = 0; k < 6; k++) out7[1 + k] = s->virial[k];
 }
 
 int lmp_nlocal(const LmpSys *s) { return s->nlocal; }
