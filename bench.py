@@ -2,7 +2,8 @@
 """DPD timesteps/s on the rho=4 cubic box (BASELINE.json metric), one process per GPU.
 
     python bench.py --gpus 1 --steps 1000 --warmup 200            # 64^3, dpd/fast/meso (configs[2])
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                                  # starts its own N ranks (torch.distributed.run)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or is started as one of them
 
 A "step" is one full run_style mvv/meso timestep (NVE initial, ghost refresh, pair force, NVE final, and a
 neighbour rebuild every 5th step) over the whole box; inputs are resident in HBM before the timed region.
@@ -22,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4 copy: 6290 GB/s
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E nominal (MI355X_MICROARCH.md); the measured float4 copy rate is reported beside it
 
 
 def parse():
@@ -78,7 +79,7 @@ def cpu_baseline(L, x, v, lo, hi, every, steps):
     t0 = time.perf_counter()
     s.run(steps, ev_last=False)
     dt = time.perf_counter() - t0
-    out = {"value": steps / dt, "unit": "timesteps/s", "cores": cores, "kind": "port",
+    out = {"value": steps / dt, "unit": "timesteps/s", "cores": cores, "node_cores": os.cpu_count(), "kind": "port",
            "sample": "%d steps of the same %d^3 rho=4 box (N=%d), rebuild every %d, OpenMP %d threads; "
                      "oracle/lmp_dpd_cpu.c" % (steps, L, len(x), every, cores),
            "M_particle_steps_per_s": steps * len(x) / dt / 1e6}
@@ -99,13 +100,33 @@ def cpu_baseline(L, x, v, lo, hi, every, steps):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` typed as is: this process has not touched the GPU (no torch import, no HIP call yet), so
+    it starts the N ranks as a child `python -m torch.distributed.run` (one process per GPU, the reference's
+    `mpirun -np N lmp_meso`, src/main.cpp:31-47), relays the child's output - rank 0's JSON line - and exits with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, a.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, a.gpus))
 
     import torch
     from meso_amd.api import Meso
@@ -201,49 +222,56 @@ def main():
     m.set_option("profile", 0)
     # per launch on one rank; with several ranks the force kernel runs twice per step (bulk, then border range after the
     # ghost refresh): the two launches together cover the rank's atoms once, so they are timed together
-    t_pair = phases["pair"]["ms"] / max(a.profile_steps, 1) * 1e-3 if world > 1 else phases["pair"]["ms_per_call"] * 1e-3
+    pp = phases["pair"]
+    if not pp["calls"]:
+        raise SystemExit("bench: the profiled pass recorded no force-kernel launch (--profile-steps must be > 0)")
+    t_pair = pp["ms"] / max(a.profile_steps, 1) * 1e-3 if world > 1 else pp["ms_per_call"] * 1e-3
     n_rank = m.counts()[0]                                          # atoms this rank's pair kernel covers
-    # ALGORITHMIC bytes per launch: own coord4 + veloc4, count, the stored row entries, and either
-    # the fp64 force store (pair kernel alone) or - when the step boundary runs in the kernel's epilogue (fp32 ring
-    # kernel) - what that boundary must move instead: x, v in (48 B) and out (48 B), mass/mask/tag/type (20 B) and the
-    # merged float4 pair of the next step (32 B, on the steps that keep the neighbour table).  The force itself then
-    # never leaves the registers.
-    fused = (phases["nve"]["calls"] or 0) <= 2 and (phases["pair"]["calls"] or 0) > 2
+    # ALGORITHMIC bytes per launch: B_pair = M (16 own coord4 + 16 own veloc4 + 4 count + 4 n_list row
+    # entries actually stored + 3 x 8 fp64 force store).  The kernel of the timed region carries the step boundary in its
+    # epilogue (fp32 ring kernel): the force then never leaves the registers and the 24 B are replaced by what the boundary
+    # must move - x, v in (48 B) and out (48 B), mass/mask/tag/type (20 B) and the merged float4 pair of the next step (32 B,
+    # on the steps that keep the neighbour table).  The graded figure (`frac`) is the force kernel ALONE on B_pair, timed in
+    # a short extra pass with the boundary back in its own kernel; the fused launch of the timed region is under "fused".
+    fused = (phases["nve"]["calls"] or 0) <= 2 and (pp["calls"] or 0) > 2
     b_in = 16 + 16 + 4 + 4.0 * info["avg_count"]
     b_pair_only = n_rank * (b_in + 3 * 8)
     b_fused = n_rank * (b_in + 48 + 20 + 48 + 32.0 * (a.every - 1) / max(a.every, 1))
-    b_pair = b_fused if fused else b_pair_only
-    achieved = b_pair / t_pair / 1e9
     fp32 = a.style in ("dpd/fast/meso", "dpd/mini/meso")
     kernel = "k_pair_dpd_ring" + ("" if fp32 else "<fp64>")
-    kernel += " + step-boundary epilogue (nve final/initial, merge)" if fused else ""
-    pair_only = None
+    fused_rec = None
+    t_alone = t_pair
     if fused:
-        # the force kernel on its own (boundary back in its separate kernel), for comparison with earlier rounds
+        fused_rec = {"kernel": kernel + " + step-boundary epilogue (nve final/initial, merge)", "us_per_launch": t_pair * 1e6,
+                     "bytes_per_launch": b_fused, "achieved": b_fused / t_pair / 1e9, "frac": b_fused / t_pair / 1e9 / HBM_PEAK_GBS}
         m.set_option("fuse_pair", 0)
         m.timer_reset()
         m.set_option("profile", 1)
-        m.run(max(a.every, min(a.profile_steps, 50)))
+        m.run(max(a.every, min(a.profile_steps, 100)))
         ms, calls = m.timer("pair")
         m.set_option("profile", 0)
         m.set_option("fuse_pair", 1)
-        if calls:
-            t1 = ms / calls * 1e-3
-            pair_only = {"kernel": kernel.split(" + ")[0], "us_per_launch": t1 * 1e6, "bytes_per_launch": b_pair_only,
-                         "achieved": b_pair_only / t1 / 1e9, "frac": b_pair_only / t1 / 1e9 / HBM_PEAK_GBS}
+        if not calls:
+            raise SystemExit("bench: the force-only pass recorded no launch")
+        t_alone = (ms / max(a.every, min(a.profile_steps, 100)) if world > 1 else ms / calls) * 1e-3
+    achieved = b_pair_only / t_alone / 1e9
+    # measured peak beside the nominal one: a 1 GiB float4 copy on the same device (read + write bytes)
+    copy_gbs = m.membw_probe(1 << 30, 5)
     T = m.temperature()
     # the thermostat overshoots to ~1.5 in the first ~100 steps of a cold start and has relaxed to 1 by ~300
     settled = a.warmup + a.steps + a.profile_steps >= 500
     ablation = any(kv.startswith("pair_debug=") and kv != "pair_debug=0" for kv in a.opt)   # timing ablations skip work
     if not ablation and not (abs(T - 1.0) < 0.25 if settled else 0.5 < T < 2.0):
         raise SystemExit("bench: temperature %r after the run - the trajectory is not physical" % T)
-    # HBM traffic of the dominant kernel from the PMC passes of the same workload (profiles/, collected separately:
-    # counters cannot be read inside this process); null for workloads that were not profiled
-    traffic = None
+    # HBM traffic of the force kernel: PMC counters cannot be read inside this process; the figure of the separate
+    # `rocprofv3 --pmc` passes over this same command is kept in profiles/ (traffic_source names the file) and attached only
+    # while kernel and workload match
+    traffic = traffic_source = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if L == 64 and a.style == "dpd/fast/meso" and a.gpus == 1 and tj.get("kernel") == kernel:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if L == tj.get("box") and a.style == tj.get("style") and a.gpus == 1 and tj.get("kernel") == kernel:
             traffic = tj["traffic_bytes_per_launch"]
+            traffic_source = "profiles/r02_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc")
     except (OSError, ValueError, KeyError):
         pass
 
@@ -266,14 +294,33 @@ def main():
                    "M_particle_steps_per_s": steps_per_s * n / 1e6,
                    "avg_neighbors": info["avg_count"], "temperature_end": T},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": kernel, "bytes_per_launch": b_pair, "us_per_launch": t_pair * 1e6,
-                     "pair_only": pair_only},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
+                     "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "bytes_per_launch": b_pair_only,
+                     "us_per_launch": t_alone * 1e6, "fused": fused_rec},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
     }
+    if world > 1:
+        line["n_ranks_seen"] = m.comm_count()      # ncclCommCount of the engine's communicator
+    # CPU baseline: timed on rank 0 at N = 1 only; the N > 1 lines of the same box re-use that sample (scratch file)
+    cache = os.path.join(ROOT, "gpurun_out", "cpu_baseline_%d_%d.json" % (L, a.every))
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and bonds is None:
         line["cpu_baseline"] = cpu_baseline(L, x, v, lo, hi, a.every, a.cpu_steps)
         line["config"]["gpu_over_cpu"] = steps_per_s / line["cpu_baseline"]["value"]
+        try:
+            os.makedirs(os.path.dirname(cache), exist_ok=True)
+            json.dump(dict(line["cpu_baseline"], host=os.uname().nodename), open(cache, "w"))
+        except OSError:
+            pass
+    elif rank == 0 and a.gpus > 1 and not a.no_cpu_baseline and bonds is None:
+        try:
+            cb = json.load(open(cache))
+            if cb.pop("host", None) == os.uname().nodename:
+                cb["sample"] += " (re-used from this host's N=1 run)"
+                line["cpu_baseline"] = cb
+                line["config"]["gpu_over_cpu"] = steps_per_s / cb["value"]
+        except (OSError, ValueError, KeyError):
+            pass
     m.close()
     if rank == 0:
         print(json.dumps(line))

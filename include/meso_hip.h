@@ -65,6 +65,8 @@ int meso_comm_init(meso_ctx *ctx, int nranks, int rank, const int procgrid[3], i
 int meso_comm_get_unique_id(void *uid, size_t uid_bytes);
 /* brick processor grid of minimal surface for the box (Comm::set_procs, src/comm.cpp); host only, no GPU needed */
 int meso_decomp_procgrid(int nranks, const double prd[3], int procgrid[3]);
+/* ranks the transport really connects: ncclCommCount for RCCL (bench.py's n_ranks_seen), the configured count otherwise */
+int meso_comm_count(meso_ctx *ctx, int *nranks_seen);
 /* host-staged transport (tests: several ranks sharing one GPU): exchange(user, npeer, peer[], sendbuf[],
  * sendbytes[], recvbuf[], recvbytes[]) must deliver every buffer; all pointers are host memory */
 typedef int (*meso_host_exchange_fn)(void *user, int npeer, const int *peer, const void *const *sendbuf,
@@ -154,6 +156,9 @@ int meso_merged_download(meso_ctx *ctx, float *coord4, float *veloc4, int nall);
 int meso_timer_reset(meso_ctx *ctx);
 int meso_timer_get(meso_ctx *ctx, const char *name, double *ms, int64_t *calls);
 int64_t meso_ntimestep(meso_ctx *ctx);
+/* measured HBM peak for the roofline (nominal and measured): float4 copy of nbytes (read + write counted),
+ * best of reps launches timed with HIP events on the engine's stream; result in GB/s */
+int meso_membw_probe(meso_ctx *ctx, size_t nbytes, int reps, double *copy_gbs);
 
 /* ---- restart files and profiler window.  Inside LAMMPS the restart file is LAMMPS' own (the glue's
  *      Pair::write_restart keeps MesoPairDPD::write_restart's layout, pair_dpd_meso.cu:363-447).  The stand-alone driver

@@ -327,6 +327,17 @@ class Meso:
     def timer_reset(self):
         self._ck(self.lib.meso_timer_reset(self._h))
 
+    def comm_count(self):
+        n = C.c_int()
+        self._ck(self.lib.meso_comm_count(self._h, C.byref(n)))
+        return n.value
+
+    def membw_probe(self, nbytes=1 << 30, reps=5):
+        """Measured float4 copy rate of this GPU in GB/s (read + write)."""
+        g = C.c_double()
+        self._ck(self.lib.meso_membw_probe(self._h, int(nbytes), int(reps), C.byref(g)))
+        return g.value
+
     def timer(self, name):
         ms, calls = C.c_double(), C.c_int64()
         self._ck(self.lib.meso_timer_get(self._h, name.encode(), C.byref(ms), C.byref(calls)))

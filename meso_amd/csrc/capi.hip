@@ -89,6 +89,20 @@ int meso_comm_get_unique_id(void *uid, size_t uid_bytes)
     return meso::comm_unique_id(uid, uid_bytes) ? set_err(MESO_ERR_COMM, "ncclGetUniqueId failed") : MESO_OK;
 }
 
+int meso_comm_count(meso_ctx *ctx, int *nranks_seen)
+{
+    CTX(ctx);
+    if (!nranks_seen) return set_err(MESO_ERR_ARG, "null output");
+    RET(E.comm_count(nranks_seen));
+}
+
+int meso_membw_probe(meso_ctx *ctx, size_t nbytes, int reps, double *copy_gbs)
+{
+    CTX(ctx);
+    if (!copy_gbs || nbytes < 16 || reps < 1) return set_err(MESO_ERR_ARG, "bad probe arguments");
+    RET(E.membw_probe(nbytes, reps, copy_gbs));
+}
+
 int meso_decomp_procgrid(int nranks, const double prd[3], int procgrid[3])
 {
     if (nranks < 1 || !prd || !procgrid) return set_err(MESO_ERR_ARG, "invalid procgrid arguments");

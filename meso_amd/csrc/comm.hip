@@ -123,6 +123,17 @@ int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *uid, si
     return 0;
 }
 
+int Engine::comm_count(int *n)
+{
+    *n = nranks;
+    if (transport == 1 && nccl) {
+        int c = 0;
+        if (ncclCommCount((ncclComm_t)nccl, &c) != ncclSuccess) return fail(5, "ncclCommCount failed");
+        *n = c;
+    }
+    return 0;
+}
+
 void Engine::comm_free()
 {
     if (nccl) ncclCommDestroy((ncclComm_t)nccl);

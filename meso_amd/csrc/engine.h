@@ -106,6 +106,8 @@ public:
     int test_gaussian(int n, const uint32_t *u, const uint32_t *v, double *odp, float *osp);
     int test_logistic(int n, const uint32_t *u, const uint32_t *v, float *out);
     int sync();
+    int comm_count(int *n);
+    int membw_probe(size_t nbytes, int reps, double *gbs);
 
     std::string err;
     int64_t ntimestep = 0;

@@ -1456,6 +1456,34 @@ int Engine::sync()
     return 0;
 }
 
+// float4 copy rate on this device (GB/s, read + write): the measured peak quoted beside the nominal 8 TB/s
+int Engine::membw_probe(size_t nbytes, int reps, double *gbs)
+{
+    const size_t n = nbytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc(&a, n * 16));
+    if (hipMalloc(&b, n * 16) != hipSuccess) { (void)hipFree(a); return fail(2, "membw_probe: out of device memory"); }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipMemsetAsync(a, 0, n * 16, stream);
+    launch_copy_f4(a, b, n, stream);      // warm-up (page mapping)
+    float best = 1e30f;
+    for (int r = 0; r < reps; r++) {
+        (void)hipEventRecord(e0, stream);
+        launch_copy_f4(a, b, n, stream);
+        (void)hipEventRecord(e1, stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms > 0.f && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    HIPCHK(hipGetLastError());
+    *gbs = 2.0 * (double)n * 16.0 / ((double)best * 1e-3) / 1e9;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // computes
 // ------------------------------------------------------------------------------------------------

@@ -41,6 +41,7 @@ void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit,
 void launch_sum_mv2(const AtomSoA &a, int groupbit, int n, double *partial, double *result, hipStream_t s);
 void launch_pbc(const AtomSoA &a, const double *boxlo, const double *boxhi, const int *periodic, int n,
                 hipStream_t s);
+void launch_copy_f4(const float4 *src, float4 *dst, size_t n, hipStream_t s);     // bandwidth probe (meso_membw_probe)
 void launch_fill_f64(double *p, double val, int n, hipStream_t s);
 void launch_fill_i32(int *p, int val, int n, hipStream_t s);
 void launch_unpack_mass(const int *type, const double *mass_type, int ntypes, double *mass, int beg, int end,

@@ -262,6 +262,17 @@ void launch_pbc(const AtomSoA &a, const double *lo, const double *hi, const int 
                        lo[2], hi[0], hi[1], hi[2], per[0], per[1], per[2], n);
 }
 
+// bandwidth probe: the float4 copy whose rate is quoted beside the nominal HBM peak in bench.py's roofline
+__global__ void __launch_bounds__(256) k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockDim.x * blockIdx.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy_f4(const float4 *src, float4 *dst, size_t n, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_copy_f4, dim3(256 * 32), dim3(256), 0, s, src, dst, n);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_fill(T *__restrict__ p, T val, int n)
 {

@@ -25,4 +25,27 @@ def test_bench_two_processes_host_transport():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "strong" and d["value"] > 0
     assert "procgrid" in d["config"]["workload"] and 0.5 < d["config"]["temperature_end"] < 2.0
-    assert d["roofline"]["us_per_launch"] > 0 and "cpu_baseline" not in d
+    assert d["roofline"]["us_per_launch"] > 0 and d["n_ranks_seen"] == 2
+    assert d["roofline"]["peak_measured_copy"] > 1000.0
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` typed as is (the driver's form): no WORLD_SIZE in the environment, the script spawns
+    its ranks itself before touching the GPU and relays rank 0's single JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "10", "--profile-steps",
+           "10", "--box", "16", "--transport", "host"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["value"] > 0 and d["n_ranks_seen"] == 2
+
+
+def test_bench_self_launch_propagates_failure():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--box", "16",
+           "--transport", "host", "--opt", "no_such_option=1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
