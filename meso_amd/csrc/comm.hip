@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(256) k_migrate_code(const double *__restrict__
 }
 
 // ms doubles per migrant: x,y,z,vx,vy,vz,(tag,type),(mask,image) [+ nbond, nspecial, bond tags/types, special tags]
+#define MIG_HEAD 11      // doubles of a migration record before the topology words: x, v, (tag,type), (mask,image), f
 __global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
                                                       const int *__restrict__ dir_dst, int n0, int n, int ms,
                                                       double *__restrict__ buf)
@@ -311,8 +312,12 @@ __global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__re
     int2 p = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], a.image[j]);
     o[6] = *reinterpret_cast<double *>(&p);
     o[7] = *reinterpret_cast<double *>(&r);
+    // the forces travel too: the rebuild of setup() after read_restart must hand an atom that crossed a face since the
+    // file's last rebuild to its new owner WITH the force the first half-kick needs (restart_forces); elsewhere they are
+    // overwritten by the force computation that follows every rebuild
+    o[8] = a.f[0][j]; o[9] = a.f[1][j]; o[10] = a.f[2][j];
     if (a.bpa > 0 || a.msp > 0) {
-        int *t = reinterpret_cast<int *>(o + 8);
+        int *t = reinterpret_cast<int *>(o + MIG_HEAD);
         t[0] = a.nbond[j]; t[1] = a.nspecial[j];
         for (int b = 0; b < a.bpa; b++) { t[2 + 2 * b] = a.bond_tag[(size_t)j * a.bpa + b]; t[3 + 2 * b] = a.bond_type[(size_t)j * a.bpa + b]; }
         for (int s = 0; s < a.msp; s++) t[2 + 2 * a.bpa + s] = a.special[(size_t)j * a.msp + s];
@@ -333,13 +338,13 @@ __global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double 
     int i = base + q;
     a.x[0][i] = o[0]; a.x[1][i] = o[1]; a.x[2][i] = o[2];
     a.v[0][i] = o[3]; a.v[1][i] = o[4]; a.v[2][i] = o[5];
-    a.f[0][i] = 0.0; a.f[1][i] = 0.0; a.f[2][i] = 0.0;
+    a.f[0][i] = o[8]; a.f[1][i] = o[9]; a.f[2][i] = o[10];
     double t6 = o[6], t7 = o[7];
     int2 p = *reinterpret_cast<int2 *>(&t6), r = *reinterpret_cast<int2 *>(&t7);
     a.tag[i] = p.x; a.type[i] = p.y; a.mask[i] = r.x; a.image[i] = r.y;
     a.mass[i] = mass_type[p.y];
     if (a.bpa > 0 || a.msp > 0) {
-        const int *t = reinterpret_cast<const int *>(o + 8);
+        const int *t = reinterpret_cast<const int *>(o + MIG_HEAD);
         a.nbond[i] = t[0]; a.nspecial[i] = t[1];
         for (int b = 0; b < a.bpa; b++) { a.bond_tag[(size_t)i * a.bpa + b] = t[2 + 2 * b]; a.bond_type[(size_t)i * a.bpa + b] = t[3 + 2 * b]; }
         for (int s = 0; s < a.msp; s++) a.special[(size_t)i * a.msp + s] = t[2 + 2 * a.bpa + s];
@@ -641,7 +646,17 @@ int Engine::halo_borders_multi()
     for (int p = 0; p < np; p++) { peer_send_base[p] = stot; stot += peer_send_n[p]; peer_recv_base[p] = rtot; rtot += peer_recv_n[p]; }
     peer_recv_base[np] = rtot;
     nghost = rtot;
-    TRY(ensure_capacity(nlocal + nghost + 1));
+    {
+        // a growth reallocates chunk_count / chunk_offset (alloc_atoms keeps their contents as little as the single-rank
+        // path's, engine.hip halo_borders): count and scan again before the fill pass reads the offsets
+        const int nmax_before = nmax;
+        TRY(ensure_capacity(nlocal + nghost + 1));
+        if (nmax != nmax_before && nchunk > 0) {
+            launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
+            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+            launch_dir_starts(chunk_offset, nchunk, d_dir_start, stream);
+        }
+    }
     if (nsend > send_cap) return fail(4, "send list capacity exceeded");
     TRY(ensure_stage((size_t)std::max(std::max(stot, 1) * 5 * sizeof(double), (size_t)std::max(stot, 1) * 2 * sizeof(float4)),
                      (size_t)std::max(std::max(rtot, 1) * 5 * sizeof(double), (size_t)std::max(rtot, 1) * 2 * sizeof(float4))));

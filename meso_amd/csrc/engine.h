@@ -285,7 +285,7 @@ private:
     bool have_bonds = false;
     int alloc_topology(AtomSoA &a, int cap, int keep);
     int rebuild_topology();
-    int mig_stride() const { return 8 + (2 + 2 * bpa + msp + (apa > 0 ? 1 + 4 * apa : 0) + 1) / 2; }
+    int mig_stride() const { return 11 + (2 + 2 * bpa + msp + (apa > 0 ? 1 + 4 * apa : 0) + 1) / 2; }
 
     // scalars
     double *d_partial = nullptr, *d_scalar = nullptr;

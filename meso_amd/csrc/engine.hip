@@ -334,9 +334,8 @@ static hipError_t regrow(T *&p, size_t keep, size_t cap, hipStream_t s)
     if (e != hipSuccess) return e;
     if (p && keep) {
         e = hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return e;
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { (void)hipFree(q); return e; }
     }
     if (p) (void)hipFree(p);
     p = q;
@@ -423,6 +422,9 @@ int Engine::alloc_atoms(int cap)
 
 int Engine::alloc_topology(AtomSoA &a, int cap, int keep)
 {
+    // arrays laid out with other per-atom widths cannot be carried over (a second bonds_upload / read_restart on a context
+    // that already held topology): they are allocated fresh and filled again by the caller
+    if (a.bpa != bpa || a.msp != msp || a.apa != apa) keep = 0;
     size_t c = (size_t)cap, k = (size_t)keep;
     a.bpa = bpa; a.msp = msp;
     HIPCHK(regrow(a.nbond, k, c, stream));

@@ -131,6 +131,52 @@ def test_restart_over_two_ranks(tmp_path):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
+def test_two_rank_restart_between_rebuilds_keeps_migrant_forces(tmp_path):
+    """A file written BETWEEN rebuilds (step 24 of a rebuild-every-5 run): setup's rebuild migrates the atoms that crossed a
+    sub-domain face since step 20, and their saved forces must travel with them - the first half-kick after the restart uses
+    them.  (A migrant arriving with f = 0 would be off by dt/2 |f| ~ 1e-2 in velocity after one step.)"""
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(10)
+    f = tmp_path / "mid.rst"
+    gid = [np.frombuffer(np.random.default_rng(190 + k).bytes(8), np.uint8) for k in range(2)]
+    out, owner = {}, {}
+
+    def work(r, phase):
+        m = Meso()
+        m.comm_init(2, r, (2, 1, 1), "local", gid[phase])
+        if phase == 0:
+            _fluid(m, x, v, lo, hi, "dpd/meso")
+            m.run(24)
+            owner[phase, r] = m.gather(by_tag=False)[3]
+            m.write_restart(f)
+            m.run(1)
+        else:
+            m.read_restart(f)
+            m.neighbor(0.3)
+            m.neigh_modify(delay=0, every=5, check=False)
+            m.setup()
+            owner[phase, r] = m.gather(by_tag=False)[3]
+            m.run(1)
+        out[phase, r] = m.gather(by_tag=False)
+        m.close()
+
+    for phase in (0, 1):
+        th = [threading.Thread(target=work, args=(r, phase)) for r in range(2)]
+        [t.start() for t in th]
+        [t.join(timeout=200) for t in th]
+
+    def by_tag(phase):
+        tag = np.concatenate([out[phase, r][3] for r in range(2)])
+        o = np.argsort(tag)
+        return [np.concatenate([out[phase, r][k] for r in range(2)])[o] for k in range(3)]
+    a, b = by_tag(0), by_tag(1)
+    # the restart's rebuild really moved atoms to the other rank
+    assert set(owner[0, 0].tolist()) != set(owner[1, 0].tolist())
+    d = a[0] - b[0]
+    d -= np.round(d / (hi - lo)) * (hi - lo)
+    assert np.abs(d).max() < 1e-9 and np.abs(a[1] - b[1]).max() < 1e-6
+
+
 def test_bad_files_are_refused(tmp_path):
     from meso_amd.api import Meso, MesoError
     (tmp_path / "junk").write_bytes(b"not a restart file at all")

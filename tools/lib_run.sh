@@ -4,8 +4,8 @@ for rep in 1 2; do
 for box in ${BOXES:-64}; do
  for v in ${LIBS}; do
   if [ $v = - ]; then unset MESO_LIB; else export MESO_LIB=$PWD/meso_amd/libmeso_hip_$v.so; fi
-  timeout -k 10 200 python bench.py --box $box --steps ${STEPS:-1000} --warmup 100 --no-cpu-baseline --profile-steps 50 ${EXTRA} > gpurun_out/lib/${box}_$v.json 2>gpurun_out/lib/err.txt || exit 1
-  python - <<PY
+  timeout -k 10 200 python3 bench.py --box $box --steps ${STEPS:-1000} --warmup 100 --no-cpu-baseline --profile-steps 50 ${EXTRA} > gpurun_out/lib/${box}_$v.json 2>gpurun_out/lib/err.txt || exit 1
+  python3 - <<PY
 import json
 d=json.loads(open("gpurun_out/lib/${box}_$v.json").read().strip().splitlines()[-1])
 r=d["roofline"]; p=d["phases_ms"]

@@ -5,8 +5,8 @@ for rep in 1 2; do
 for set in "${SETS[@]}"; do
   args=""; for o in $set; do args="$args --opt $o"; done
   tag=$(echo "$set" | tr ' =' '__')
-  timeout -k 10 200 python bench.py --box ${BOX:-64} --steps ${STEPS:-1500} --warmup 200 --no-cpu-baseline --profile-steps 50 $args > gpurun_out/opt/$tag.json 2>gpurun_out/opt/err.txt || exit 1
-  python - <<PY
+  timeout -k 10 200 python3 bench.py --box ${BOX:-64} --steps ${STEPS:-1500} --warmup 200 --no-cpu-baseline --profile-steps 50 $args > gpurun_out/opt/$tag.json 2>gpurun_out/opt/err.txt || exit 1
+  python3 - <<PY
 import json
 d=json.loads(open("gpurun_out/opt/$tag.json").read().strip().splitlines()[-1])
 r=d["roofline"]; p=d["phases_ms"]
