@@ -40,6 +40,9 @@ int Engine::check(hipError_t e, const char *what)
 Engine::Engine(int dev) : device(dev)
 {
     for (int d = 0; d < 3; d++) { boxlo[d] = 0; boxhi[d] = 1; prd[d] = 1; periodic[d] = 1; }
+    // development switches: option defaults from the environment (whole test-suite runs under an alternative kernel path)
+    if (const char *e = getenv("MESO_PAIR_DEBUG")) pair_debug = atoi(e);
+    if (const char *e = getenv("MESO_PAIR_NPART")) pair_npart = atoi(e);
 }
 
 Engine::~Engine() { free_all(); }
@@ -385,6 +388,7 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(coord4, 0, c, stream)); HIPCHK(regrow(veloc4, 0, c, stream));
     merged_in_reorder = false;
     HIPCHK(regrow(coord4_next, 0, c, stream)); HIPCHK(regrow(veloc4_next, 0, c, stream));
+
     for (int k = 0; k < 6; k++) HIPCHK(regrow(virial[k], 0, c, stream));
     HIPCHK(regrow(e_pair, 0, c, stream));
     HIPCHK(regrow(xhold, 0, 3 * c, stream));
@@ -424,18 +428,18 @@ int Engine::alloc_topology(AtomSoA &a, int cap, int keep)
 {
     // arrays laid out with other per-atom widths cannot be carried over (a second bonds_upload / read_restart on a context
     // that already held topology): they are allocated fresh and filled again by the caller
-    if (a.bpa != bpa || a.msp != msp || a.apa != apa) keep = 0;
-    size_t c = (size_t)cap, k = (size_t)keep;
+    const size_t c = (size_t)cap;
+    const size_t kb = (a.bpa == bpa && a.msp == msp) ? (size_t)keep : 0, ka = (a.apa == apa) ? (size_t)keep : 0;
     a.bpa = bpa; a.msp = msp;
-    HIPCHK(regrow(a.nbond, k, c, stream));
-    HIPCHK(regrow(a.bond_tag, k * std::max(bpa, 1), c * std::max(bpa, 1), stream));
-    HIPCHK(regrow(a.bond_type, k * std::max(bpa, 1), c * std::max(bpa, 1), stream));
-    HIPCHK(regrow(a.nspecial, k, c, stream));
-    HIPCHK(regrow(a.special, k * std::max(msp, 1), c * std::max(msp, 1), stream));
+    HIPCHK(regrow(a.nbond, kb, c, stream));
+    HIPCHK(regrow(a.bond_tag, kb * std::max(bpa, 1), c * std::max(bpa, 1), stream));
+    HIPCHK(regrow(a.bond_type, kb * std::max(bpa, 1), c * std::max(bpa, 1), stream));
+    HIPCHK(regrow(a.nspecial, kb, c, stream));
+    HIPCHK(regrow(a.special, kb * std::max(msp, 1), c * std::max(msp, 1), stream));
     a.apa = apa;
     if (apa > 0) {
-        HIPCHK(regrow(a.nangle, k, c, stream));
-        HIPCHK(regrow(a.angle_tag, k * 4 * apa, c * 4 * apa, stream));
+        HIPCHK(regrow(a.nangle, ka, c, stream));
+        HIPCHK(regrow(a.angle_tag, ka * 4 * apa, c * 4 * apa, stream));
     }
     return 0;
 }

@@ -262,15 +262,27 @@ void launch_pbc(const AtomSoA &a, const double *lo, const double *hi, const int 
                        lo[2], hi[0], hi[1], hi[2], per[0], per[1], per[2], n);
 }
 
-// bandwidth probe: the float4 copy whose rate is quoted beside the nominal HBM peak in bench.py's roofline
-__global__ void __launch_bounds__(256) k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+// bandwidth probe: the float4 copy whose rate is quoted beside the nominal HBM peak in bench.py's roofline (four
+// independent 16-byte loads per lane in flight, one workgroup per 16 KiB)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_copy_f4(const float4 *__restrict__ src4, float4 *__restrict__ dst4, size_t n)
 {
-    for (size_t i = (size_t)blockDim.x * blockIdx.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    const f32x4 *src = (const f32x4 *)src4;
+    f32x4 *dst = (f32x4 *)dst4;
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (base + 768 < n) {
+        const f32x4 a = __builtin_nontemporal_load(src + base), b = __builtin_nontemporal_load(src + base + 256),
+                    c = __builtin_nontemporal_load(src + base + 512), d = __builtin_nontemporal_load(src + base + 768);
+        __builtin_nontemporal_store(a, dst + base); __builtin_nontemporal_store(b, dst + base + 256);
+        __builtin_nontemporal_store(c, dst + base + 512); __builtin_nontemporal_store(d, dst + base + 768);
+    } else {
+        for (size_t i = base; i < n; i += 256) dst[i] = src[i];
+    }
 }
 void launch_copy_f4(const float4 *src, float4 *dst, size_t n, hipStream_t s)
 {
     if (!n) return;
-    hipLaunchKernelGGL(k_copy_f4, dim3(256 * 32), dim3(256), 0, s, src, dst, n);
+    hipLaunchKernelGGL(k_copy_f4, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, src, dst, n);
 }
 
 template <typename T>

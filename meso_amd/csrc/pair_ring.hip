@@ -278,6 +278,8 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     // p.debug 3/4: occupancy ablation - pad the LDS request so that only 3 / 4 workgroups fit a CU (default: 5)
     if (p.debug == 3) sm = 53 * 1024;
     if (p.debug == 4) sm = 40 * 1024;
+    if (p.debug == 5) sm = 32 * 1024;
+    if (p.debug == 6) sm = 26 * 1024;
     bool ew1 = true;
     if (nt1) ew1 = p.cf1[P_EXPW] == 1.0;
     else ew1 = p.all_expw_one != 0;

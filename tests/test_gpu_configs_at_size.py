@@ -98,8 +98,11 @@ def test_config3_64cube_fp64_on_8_ranks():
     f1, f8 = one["setup"][2], got["setup"][2]
     scale = np.abs(f1).max()
     assert np.array_equal(got["setup"][3], np.arange(1, n + 1))
-    # fp32 merged coordinates are centred on each rank's own sub-box (atom_vec_meso.cu:154-156): tolerance of that rounding
-    assert np.abs(f8 - f1).max() < 5e-6 * scale
+    # fp32 merged coordinates are centred on each rank's own sub-box (atom_vec_meso.cu:154-156): the operands of a pair
+    # differ by an ulp of the coordinate, 2^-18 at |x| = 32 (one rank) against 2^-19 at 16 (eight ranks) - 8x the ulp of the
+    # L = 12 decks, whose 5e-6 tolerance scales accordingly; most components agree far better
+    err = np.abs(f8 - f1)
+    assert err.max() < 4e-5 * scale and np.quantile(err, 0.999) < 1e-5 * scale and np.median(err) < 1e-6 * scale
     assert np.abs(f8.sum(axis=0)).max() < 1e-6 * scale * np.sqrt(n)
     assert abs(sum(i["avg_count"] * c[0] for i, c in zip(info, counts)) / n - info1[0]["avg_count"]) < 1e-9
     # after 20 steps: every atom still owned exactly once, momentum conserved, thermostat sane, one global T on all ranks

@@ -8,7 +8,7 @@ for box in ${BOXES:-64 32}; do
 import json
 d=json.loads(open("gpurun_out/ab/${box}_$v.json").read().strip().splitlines()[-1])
 r=d["roofline"]; p=d["phases_ms"]
-print("$box $v %.0f steps/s  pair %.1f us (only %.1f)  neigh %.0f reorder %.0f bin %.0f" % (d["value"], r["us_per_launch"], r["pair_only"]["us_per_launch"], p["neigh"]*1e3, p["reorder"]*1e3, p["bin"]*1e3))
+print("$box $v %.0f steps/s  pair %.1f us (only %.1f)  neigh %.0f reorder %.0f bin %.0f" % (d["value"], (r.get("fused") or r)["us_per_launch"], r["us_per_launch"], p["neigh"]*1e3, p["reorder"]*1e3, p["bin"]*1e3))
 PY
  done
 done

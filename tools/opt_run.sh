@@ -10,7 +10,7 @@ for set in "${SETS[@]}"; do
 import json
 d=json.loads(open("gpurun_out/opt/$tag.json").read().strip().splitlines()[-1])
 r=d["roofline"]; p=d["phases_ms"]
-print("%-28s %.0f steps/s  pair %.1f us (only %.1f)  neigh %.0f reorder %.0f bin %.0f" % ("$set", d["value"], r["us_per_launch"], r["pair_only"]["us_per_launch"], p["neigh"]*1e3, p["reorder"]*1e3, p["bin"]*1e3))
+print("%-28s %.0f steps/s  pair %.1f us (only %.1f)  neigh %.0f reorder %.0f bin %.0f" % ("$set", d["value"], (r.get("fused") or r)["us_per_launch"], r["us_per_launch"], p["neigh"]*1e3, p["reorder"]*1e3, p["bin"]*1e3))
 PY
 done
 done
