@@ -710,9 +710,11 @@ __global__ void __launch_bounds__(256) k_ghost_morton(const double *__restrict__
 // deterministic - and writes gslot (ghost -> slot).
 __global__ void __launch_bounds__(256) k_ghost_count(const double *__restrict__ x, const double *__restrict__ y,
                                                      const double *__restrict__ z, BinGeom g, int nlocal, int nghost,
-                                                     u32 *__restrict__ code, int *__restrict__ rank, int *__restrict__ cnt)
+                                                     u32 *__restrict__ code, int *__restrict__ rank, int *__restrict__ cnt,
+                                                     const int *__restrict__ nghost_dev)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nghost_dev) nghost = min(nghost, *nghost_dev);      // nghost is a launch bound
     const bool valid = k < nghost;
     u32 m = 0;
     if (valid) {
@@ -729,11 +731,12 @@ __global__ void __launch_bounds__(256) k_ghost_count(const double *__restrict__ 
     const int r = run_rank(m, valid, cnt);
     if (valid) rank[k] = r;
 }
-void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt, hipStream_t s)
+void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt,
+                        const int *nghost_dev, hipStream_t s)
 {
     if (nghost > 0)
         hipLaunchKernelGGL(k_ghost_count, dim3((nghost + 255) / 256), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, nlocal, nghost, code,
-                           rank, cnt);
+                           rank, cnt, nghost_dev);
 }
 static inline int brick_grid(const BrickArgs &g) { return (g.nactive + 7) / 8 * 8; }
 

@@ -22,7 +22,8 @@ static int set_err(int code, const std::string &msg)
 
 #define CTX(ctx)                                                           \
     if (!(ctx) || !(ctx)->eng) return set_err(MESO_ERR_ARG, "null context"); \
-    Engine &E = *(ctx)->eng
+    Engine &E = *(ctx)->eng;                                                \
+    if (int rc_ = E.resolve_counts()) { g_err = E.err; return rc_; }
 #define RET(call)                                   \
     do {                                            \
         int _rc = (call);                           \

@@ -106,6 +106,7 @@ public:
     int test_gaussian(int n, const uint32_t *u, const uint32_t *v, double *odp, float *osp);
     int test_logistic(int n, const uint32_t *u, const uint32_t *v, float *out);
     int sync();
+    int resolve_counts();      // counts of the last rebuild that are still on their way to the host (async_counts)
     int comm_count(int *n);
     int membw_probe(size_t nbytes, int reps, double *gbs);
 
@@ -245,6 +246,13 @@ private:
     size_t brick_cap = 0;
     int brick_maxh_alloc = 0;
     bool bulk_pending = false;      // n_bulk of the last reorder is still on its way to the host
+    // rebuilds without a host round trip (one rank, cell-ordered layout): launch sizes come from the previous rebuild's counts
+    // plus head-room, kernels mask with the counts on the device, the host reads them when it next needs them
+    int async_counts = 1;           // option
+    bool counts_pending = false;
+    hipEvent_t ev_counts = nullptr;
+    int nghost_prev = -1, n_bulk_prev = -1;
+    bool async_ok() const;
     bool permute_forces = true;     // the reorder carries the forces along (not needed for the rebuilds inside run())
     bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
     double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)
@@ -291,6 +299,7 @@ private:
     double *d_partial = nullptr, *d_scalar = nullptr;
     int *d_flags = nullptr;     // [0] overflow, [1] n_bulk
     int *h_flags = nullptr;     // pinned
+    int *h_flags_dev = nullptr; // the same memory as the device sees it (kernels report counts straight to the host)
     double *h_scalar = nullptr; // pinned
     bool ev_valid = false;
 };

@@ -42,6 +42,7 @@ Engine::Engine(int dev) : device(dev)
     for (int d = 0; d < 3; d++) { boxlo[d] = 0; boxhi[d] = 1; prd[d] = 1; periodic[d] = 1; }
     // development switches: option defaults from the environment (whole test-suite runs under an alternative kernel path)
     if (const char *e = getenv("MESO_PAIR_DEBUG")) pair_debug = atoi(e);
+    if (const char *e = getenv("MESO_ASYNC_COUNTS")) async_counts = atoi(e);
     if (const char *e = getenv("MESO_PAIR_NPART")) pair_npart = atoi(e);
 }
 
@@ -320,6 +321,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "tile_plan") { tile_plan = (int)val; return 0; }
     if (key == "reorder_cap") { reorder_cap_user = (int)val; return 0; }      // tests: force the ordering pass off its LDS stage
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
+    if (key == "async_counts") { async_counts = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
@@ -690,7 +692,7 @@ int Engine::ensure_capacity(int need)
 int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag, const int *type, const int *mask,
                          const int *image)
 {
-    if (n < 0 || !x || !v || !tag || !type) return fail(1, "Invalid atom arrays");
+    if (n < 0 || (n > 0 && (!x || !v || !tag || !type))) return fail(1, "Invalid atom arrays");      // a rank may start empty
     if (!have_box) return fail(3, "Box must be set before atoms are created");
     // capacity: locals + expected ghosts (periodic images within cutghost) with head-room
     double ext = 1.0;
@@ -964,7 +966,8 @@ int Engine::reorder_locals()
         launch_reorder_place(rkey, rval_alt, estart, geom, ncodes, nlocal, reorder_cap, (int *)rkey_alt, rval, (uint32_t *)bin_key_alt, rcount,
                              stream);
         std::swap(rkey, bin_key_alt);            // sorted keys (the lane-per-atom list builder reads them)
-        HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        // n_bulk = estart[M]: the asynchronous rebuild reads it where it is (halo_borders), the others through d_flags[1]
+        if (!async_ok()) HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
     } else if (layout >= 1) {
         launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
         HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
@@ -985,12 +988,13 @@ int Engine::reorder_locals()
         launch_permute_atoms(cur, alt, rval, nlocal, permute_forces ? 1 : 0, stream);
     }
     std::swap(cur, alt);
-    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (!(nranks == 1 && layout >= 1 && async_ok())) HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
-    if (nranks == 1 && layout >= 1 && nlocal <= 524288) {
+    if (nranks == 1 && layout >= 1 && (nlocal <= 524288 || async_ok())) {
         // one rank, small box: the ghost-list pass below scans every local atom (bulk atoms have no flags), so the bulk
         // count is not needed yet; it arrives with that pass's own host round trip - one synchronisation per rebuild,
-        // not two (+4 % at 25^3-32^3; above ~0.5 M atoms the longer scan costs more than the round trip)
+        // not two (+4 % at 25^3-32^3; above ~0.5 M atoms the longer scan costs more than the round trip).  With
+        // async_counts neither round trip happens: the border scan starts from a bound (halo_borders)
         bulk_pending = true;
         return 0;
     }
@@ -1005,6 +1009,37 @@ int Engine::halo_borders()
 {
     if (nranks > 1) return halo_borders_multi();
     tbegin("halo");
+    if (async_ok() && bulk_pending) {
+        // No host round trip: the ghost count of the previous rebuild (+ 12.5 % + 1024) bounds this one's launches, every consumer
+        // masks with the device-side count (d_dir_start[27]), and the counts travel to the host behind an event that
+        // resolve_counts() waits for when the host next needs them (the next rebuild, the end of run(), any query).
+        int bound = nghost_prev + nghost_prev / 8 + 1024;
+        TRY(ensure_capacity(nlocal + bound));
+        // border scan: every local atom in small boxes; in large ones from a little before the previous border section
+        int beg = 0;
+        if (nlocal > 524288) beg = std::max(0, n_bulk_prev - n_bulk_prev / 64 - 4096) & ~255;
+        const int end = nlocal, nchunk = (end - beg + 255) / 256;
+        launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
+        const int *nb_dev = estart + bargs.M;       // n_bulk where the reorder's scan left it
+        if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
+        if (!launch_border_scan(chunk_count, chunk_offset, nchunk, d_dir_start, nb_dev, beg, std::min(bound, send_cap), d_flags, h_flags_dev,
+                                stream)) {
+            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+            launch_dir_starts_check(chunk_offset, nchunk, d_dir_start, nb_dev, beg, std::min(bound, send_cap), d_flags, stream);
+            HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_flags + 8, d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_flags + 9, nb_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+        }
+        if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_counts, stream));
+        counts_pending = true;
+        nsend = nghost = bound;            // launch bounds until resolve_counts() has the numbers
+        launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
+        launch_pack_border(cur, sendlist, nsend, d_dir_start, shift27, cur.x[0] + nlocal, cur.x[1] + nlocal, cur.x[2] + nlocal,
+                           cur.tag + nlocal, cur.type + nlocal, cur.mask + nlocal, stream);
+        tend("halo");
+        return 0;
+    }
     int beg = bulk_pending ? 0 : n_bulk, end = nlocal;
     int nchunk = (end - beg + 255) / 256;
     nsend = 0;
@@ -1029,6 +1064,7 @@ int Engine::halo_borders()
     }
     // single rank: every send is my own ghost
     nghost = nsend;
+    nghost_prev = nghost; n_bulk_prev = n_bulk;
     if (nlocal + nghost > nmax || nsend > send_cap) {
         TRY(ensure_capacity(nlocal + nghost));
         // lists are rebuilt below on the new buffers; chunk arrays were regrown, so recount
@@ -1095,10 +1131,11 @@ int Engine::build_cells_and_table()
             launch_invert_perm(bin_val, gslot, nghost, stream);
         } else {
             // counting instead of sorting: 6 launches instead of ~18 (the ghosts' comparison sort was launch-bound)
-            launch_ghost_count(cur, geom, nlocal, nghost, bin_key, bin_val, gcount, stream);
+            const int *ng_dev = counts_pending ? d_dir_start + 27 : nullptr;     // nghost is a launch bound while the counts travel
+            launch_ghost_count(cur, geom, nlocal, nghost, bin_key, bin_val, gcount, ng_dev, stream);
             HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, gcount, gstart, bargs.M + 1, stream));
             launch_ghost_order(bin_key, bin_val, gstart, bargs.M, nghost, reorder_cap, (int *)bin_key_alt, bin_val_alt, (uint32_t *)rkey_alt, gslot,
-                               gcount, stream);
+                               gcount, ng_dev, stream);
         }
         bargs.ghost_base = nlocal;
         tend("bin");
@@ -1174,6 +1211,27 @@ int Engine::ensure_table32()
     return 0;
 }
 
+bool Engine::async_ok() const
+{
+    return async_counts && nranks == 1 && layout == 2 && !ghost_sort && !reorder_sort && !have_bonds && nghost_prev >= 0 &&
+           neigh_kernel == 1 && tile_fits;
+}
+
+// the host's copy of the counts a rebuild left on the device (see halo_borders)
+int Engine::resolve_counts()
+{
+    if (!counts_pending) return 0;
+    HIPCHK(hipEventSynchronize(ev_counts));
+    counts_pending = false;
+    bulk_pending = false;
+    if (h_flags[8]) return check_overflow();
+    n_bulk = h_flags[9];
+    for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];
+    nsend = nghost = h_dir_start[27];
+    nghost_prev = nghost; n_bulk_prev = n_bulk;
+    return 0;
+}
+
 int Engine::check_overflow()
 {
     HIPCHK(hipMemcpyAsync(h_flags, d_flags, 5 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1184,6 +1242,14 @@ int Engine::check_overflow()
     }
     if (h_flags[0]) {
         char buf[200];
+        if (h_flags[0] == 200000 || h_flags[0] == 200001) {
+            HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+            counts_pending = false;
+            nghost_prev = -1;      // the next rebuild takes the synchronous path again
+            return fail(4, h_flags[0] == 200000 ? "Ghost list outgrew the bound taken from the previous rebuild (density changed by more than "
+                                                  "12 % within one rebuild interval): run again with option async_counts 0"
+                                                : "Border section moved in front of the scanned range: run again with option async_counts 0");
+        }
         if (h_flags[0] >= 100000)
             snprintf(buf, sizeof buf, "Brick halo overflow: %d atoms in one brick neighbourhood (capacity %d); local density too "
                      "high - raise option brick_margin or use neigh_kernel 0", h_flags[0] - 100000, bargs.maxh);
@@ -1197,6 +1263,7 @@ int Engine::check_overflow()
 int Engine::reneighbor()
 {
     TRY(init_params());
+    TRY(resolve_counts());       // the previous rebuild's counts (long since arrived) size this one
     // one rank: nothing happens between the wrap and the reorder, which reads the coordinates anyway - wrapped there
     wrap_in_reorder = nranks == 1 && layout >= 1 && !reorder_sort && nlocal > 0;
     if (!wrap_in_reorder) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
@@ -1451,6 +1518,7 @@ int Engine::run(int nsteps)
     }
     tend("total_steps");
     profile_tick(nsteps, nsteps);
+    TRY(resolve_counts());
     TRY(check_overflow());
     HIPCHK(hipGetLastError());
     return 0;

@@ -63,7 +63,7 @@ void launch_reorder_count(const AtomSoA &a, const BinGeom &g, const double *slab
 void launch_reorder_place(const uint32_t *key, const int *rank, const int *estart, const BinGeom &g, int ncodes, int n, int cap,
                           int *placed, int *val_sorted, uint32_t *key_sorted, int *cnt, hipStream_t s);
 void launch_ghost_order(const uint32_t *code, const int *rank, const int *gstart, int M, int nghost, int cap, int *placed,
-                        int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, hipStream_t s);
+                        int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, const int *nghost_dev /*nullable*/, hipStream_t s);
 void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s);
 // ... and the merged float4 pair of the new order in the same pass (k_merge_xvt folded in)
@@ -79,6 +79,11 @@ void launch_border_fill(const AtomSoA &a, int beg, int end, const double *slab_l
                         const int *dim_active, const int *chunk_offset /*[27][nchunk] exclusive, global*/,
                         int nchunk, int *sendlist, hipStream_t s);
 void launch_dir_starts(const int *chunk_offset, int nchunk, int *dir_start, hipStream_t s);
+// scan + direction starts + checks + host report in one single-workgroup launch; false (nothing launched) when 27 nchunk + 1 > 64 Ki
+bool launch_border_scan(const int *cnt, int *off, int nchunk, int *dir_start, const int *n_bulk, int scan_beg, int bound, int *flags,
+                        int *report /* device-visible pinned host memory, 64 ints */, hipStream_t s);
+void launch_dir_starts_check(const int *chunk_offset, int nchunk, int *dir_start, const int *n_bulk, int scan_beg, int bound, int *flags,
+                             hipStream_t s);
 void launch_border_count_code(const int *code, int beg, int end, int *chunk_count, int nchunk, hipStream_t s);
 void launch_border_fill_code(const int *code, int beg, int end, const int *chunk_offset, int nchunk, int *list,
                              hipStream_t s);
@@ -197,7 +202,9 @@ size_t brick_hoff_pitch();
 size_t brick_hdr_pitch();
 void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s);
 // ghost binning by counting (no sort): cnt[M+1] zeroed by the caller, scanned into gstart between the two calls
-void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt, hipStream_t s);
+// nghost_dev != null: nghost is only a launch bound, the count itself is read on the device
+void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt,
+                        const int *nghost_dev, hipStream_t s);
 
 struct ExclArgs;
 // cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows

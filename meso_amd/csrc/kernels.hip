@@ -411,9 +411,10 @@ __global__ void __launch_bounds__(256) k_reorder_keys_count(const double *__rest
 }
 __global__ void __launch_bounds__(256) k_reorder_place(const u32 *__restrict__ key, const int *__restrict__ rank,
                                                        const int *__restrict__ estart, int sub_bits, int n,
-                                                       int *__restrict__ placed)
+                                                       int *__restrict__ placed, const int *__restrict__ n_dev)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);         // n is a launch bound; the count itself has not reached the host yet
     if (i < n) placed[estart[key[i] >> sub_bits] + rank[i]] = i;
 }
 #define REORDER_CODES 128
@@ -493,7 +494,8 @@ void launch_reorder_place(const uint32_t *key, const int *rank, const int *estar
                           int *placed, int *val_sorted, uint32_t *key_sorted, int *cnt, hipStream_t s)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_reorder_place, dim3(nblk(n, 256)), dim3(256), 0, s, key, rank, estart, reorder_sub_bits(g), n, placed);
+    hipLaunchKernelGGL(k_reorder_place, dim3(nblk(n, 256)), dim3(256), 0, s, key, rank, estart, reorder_sub_bits(g), n, placed,
+                       (const int *)nullptr);
     const size_t dyn = (size_t)cap * 8;
     if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_reorder_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipLaunchKernelGGL(k_reorder_order, dim3((ncodes + REORDER_CODES) / REORDER_CODES), dim3(REORDER_CODES), dyn, s, estart,
@@ -503,9 +505,10 @@ void launch_reorder_place(const uint32_t *key, const int *rank, const int *estar
 // ghosts: same scheme on the plain Morton code (rank from k_ghost_count, brick.hip); the ordering pass sorts the ghosts of a
 // code by ghost index and writes gslot (ghost -> slot) as the inverse
 void launch_ghost_order(const uint32_t *code, const int *rank, const int *gstart, int M, int nghost, int cap, int *placed,
-                        int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, hipStream_t s)
+                        int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, const int *nghost_dev, hipStream_t s)
 {
-    if (nghost > 0) hipLaunchKernelGGL(k_reorder_place, dim3(nblk(nghost, 256)), dim3(256), 0, s, code, rank, gstart, 0, nghost, placed);
+    if (nghost > 0)
+        hipLaunchKernelGGL(k_reorder_place, dim3(nblk(nghost, 256)), dim3(256), 0, s, code, rank, gstart, 0, nghost, placed, nghost_dev);
     const size_t dyn = (size_t)cap * 8;
     if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_reorder_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipLaunchKernelGGL(k_reorder_order, dim3((M + REORDER_CODES) / REORDER_CODES), dim3(REORDER_CODES), dyn, s, gstart, M, code,
@@ -777,6 +780,90 @@ void launch_dir_starts(const int *chunk_offset, int nchunk, int *dir_start, hipS
 {
     hipLaunchKernelGGL(k_dir_starts, dim3(1), dim3(64), 0, s, chunk_offset, nchunk, dir_start);
 }
+// ... and the checks of a rebuild whose counts stay on the device: the send list must fit the launch bound the host chose,
+// and the border section must start at or behind the first atom the border scan looked at; flags[0] reports a violation
+__global__ void k_dir_starts_check(const int *__restrict__ chunk_offset, int nchunk, int *__restrict__ dir_start, const int *__restrict__ n_bulk,
+                                   int scan_beg, int bound, int *__restrict__ flags)
+{
+    int d = threadIdx.x;
+    if (d < 28) dir_start[d] = chunk_offset[(size_t)d * nchunk];
+    if (d == 0) {
+        const int tot = chunk_offset[(size_t)27 * nchunk];
+        if (tot > bound) flags[0] = 200000;
+        else if (*n_bulk < scan_beg) flags[0] = 200001;
+    }
+}
+void launch_dir_starts_check(const int *chunk_offset, int nchunk, int *dir_start, const int *n_bulk, int scan_beg, int bound, int *flags,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dir_starts_check, dim3(1), dim3(64), 0, s, chunk_offset, nchunk, dir_start, n_bulk, scan_beg, bound, flags);
+}
+
+// One launch for the tail of the border pass when its counts fit one workgroup (27 x nchunk <= 64 Ki): exclusive scan of the
+// chunk counts (tiles of 4096, carry in a register of thread 0), the 28 direction starts, the checks of k_dir_starts_check,
+// and the report for the host - flags[0], n_bulk and the direction starts - written straight into pinned host memory
+// (`report`, 64 ints: [8] flag, [9] n_bulk, [16..43] dir_start): no scan launches, no copy launches.
+__global__ void __launch_bounds__(1024) k_border_scan(const int *__restrict__ cnt, int *__restrict__ off, int n, int nchunk, int *__restrict__ dir_start,
+                                                      const int *__restrict__ n_bulk, int scan_beg, int bound, int *__restrict__ flags,
+                                                      int *__restrict__ report)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + tid * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
+        const int t = v[0] + v[1] + v[2] + v[3];
+        int incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int pre = carry_s;
+        for (int k = 0; k < w; k++) pre += wsum[k];
+        int run = pre + incl - t;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n) off[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = run;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (the scanned offsets were written by this workgroup: read them back through global memory after the barrier)
+    if (tid < 28) {
+        const int ds = off[(size_t)tid * nchunk];
+        dir_start[tid] = ds;
+        report[16 + tid] = ds;
+    }
+    if (tid == 0) {
+        const int tot = off[(size_t)27 * nchunk];
+        int f = flags[0];
+        if (tot > bound) f = 200000;
+        else if (*n_bulk < scan_beg) f = 200001;
+        if (f) flags[0] = f;
+        report[8] = f;
+        report[9] = *n_bulk;
+    }
+}
+bool launch_border_scan(const int *cnt, int *off, int nchunk, int *dir_start, const int *n_bulk, int scan_beg, int bound, int *flags,
+                        int *report, hipStream_t s)
+{
+    const int n = 27 * nchunk + 1;
+    if (n > 65536) return false;
+    hipLaunchKernelGGL(k_border_scan, dim3(1), dim3(1024), 0, s, cnt, off, n, nchunk, dir_start, n_bulk, scan_beg, bound, flags, report);
+    return true;
+}
 
 struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0 when not crossing a PBC)
 struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction
@@ -801,7 +888,7 @@ __global__ void __launch_bounds__(256) k_pack_border(AtomSoA a, const int *__res
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
     __syncthreads();
     int k = blockDim.x * blockIdx.x + threadIdx.x;
-    if (k >= nsend) return;
+    if (k >= min(nsend, ds[27])) return;      // nsend may be a launch bound (counts still on their way to the host)
     int j = sendlist[k];
     int d = dir_of_entry(ds, k);
     dx[k] = a.x[0][j] + sh.s[d][0];
@@ -823,7 +910,7 @@ __global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__re
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
     __syncthreads();
     int k = blockDim.x * blockIdx.x + threadIdx.x;
-    if (k >= nsend) return;
+    if (k >= min(nsend, ds[27])) return;      // nsend may be a launch bound
     int j = sendlist[k];
     int d = dir_of_entry(ds, k);
     float4 c;
