@@ -53,6 +53,10 @@ int meso_device_sync(meso_ctx *ctx);
  *   fuse_clear    1  force kernel writes f instead of clear + accumulate
  *   overlap       1  several ranks: ghost refresh on a side stream under the bulk force kernel
  *   brick_margin  1  multiplier on the expected brick-neighbourhood population (raise for strongly inhomogeneous systems)
+ *   async_counts  1  one rank: a rebuild does not wait for the host - launch bounds come from the previous rebuild's counts,
+ *                    kernels mask with the device-side counts, the host reads them (pinned memory) when it next needs them
+ *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost
+ *                    binning on the side stream, joined by events (same neighbour sets and forces; measured slower)
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */
 int meso_set_option(meso_ctx *ctx, const char *key, double value);
 

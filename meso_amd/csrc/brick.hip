@@ -804,9 +804,13 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
                        const ExclArgs *excl, int dbg, hipStream_t s)
 {
     if (g.nactive <= 0) return;
-    // enough workgroups to occupy the card three deep (identity brick list: about half of the bricks own atoms)
+    // few bricks (small boxes, sub-boxes of many ranks): several workgroups share a brick as long as all of them still fit the
+    // card in one round (3 workgroups per CU); only the bricks that overlap the bin grid own atoms (measured: 25^3 best with 4
+    // workgroups per brick, 32^3 with 2, from 48^3 on with 1)
+    const int occupied = ((g.mbin[0] + 3) / 4) * ((g.mbin[1] + 3) / 4) * ((g.mbin[2] + 3) / 4);
     int split = 1;
-    while (split < 4 && g.nactive * split < 2 * 3 * 256) split *= 2;
+    while (split < 4 && occupied * split * 2 <= 900) split *= 2;
+    if (dbg >= 100) { split = dbg - 100; dbg = 0; }     // timing experiments: pair_debug 110 + split
     const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
     ExclArgs ex = {nullptr, nullptr, nullptr, 0};
     const bool with_tags = excl && excl->tagc;

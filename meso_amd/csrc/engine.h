@@ -253,6 +253,17 @@ private:
     hipEvent_t ev_counts = nullptr;
     int nghost_prev = -1, n_bulk_prev = -1;
     bool async_ok() const;
+    // ... and with the two halves of the rebuild on two streams (option overlap_rebuild): the reorder of the locals on the
+    // main stream, border lists + ghost creation + ghost binning on the side stream (north_star: reorder on a side stream
+    // overlapped with halo pack/unpack; the reference overlaps its sort-phase transfers, mvv_meso.cu:296-316)
+    int overlap_rebuild = 0;        // measured slower at every size (profiles/r02_notes.md section 5): kept as a tested option
+    bool ghosts_binned = false;     // this rebuild's ghosts were binned by rebuild_overlapped
+    int rebuild_overlapped();
+    void *scan_temp_side = nullptr;
+    size_t scan_temp_side_bytes = 0;
+    int *gtmp_placed = nullptr, *perm_inverse = nullptr;
+    uint32_t *gtmp_code = nullptr;
+    hipEvent_t ev_wrap = nullptr, ev_ghosts = nullptr;
     bool permute_forces = true;     // the reorder carries the forces along (not needed for the rebuilds inside run())
     bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
     double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)

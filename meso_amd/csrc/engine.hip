@@ -43,6 +43,7 @@ Engine::Engine(int dev) : device(dev)
     // development switches: option defaults from the environment (whole test-suite runs under an alternative kernel path)
     if (const char *e = getenv("MESO_PAIR_DEBUG")) pair_debug = atoi(e);
     if (const char *e = getenv("MESO_ASYNC_COUNTS")) async_counts = atoi(e);
+    if (const char *e = getenv("MESO_OVERLAP_REBUILD")) overlap_rebuild = atoi(e);
     if (const char *e = getenv("MESO_PAIR_NPART")) pair_npart = atoi(e);
 }
 
@@ -322,6 +323,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "reorder_cap") { reorder_cap_user = (int)val; return 0; }      // tests: force the ordering pass off its LDS stage
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "async_counts") { async_counts = (int)val; return 0; }
+    if (key == "overlap_rebuild") { overlap_rebuild = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
@@ -401,12 +403,19 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(rval, 0, c, stream)); HIPCHK(regrow(rval_alt, 0, c, stream));
     HIPCHK(regrow(sendlist, 0, c, stream));
     HIPCHK(regrow(gslot, 0, c, stream));
+    HIPCHK(regrow(gtmp_placed, 0, c, stream)); HIPCHK(regrow(gtmp_code, 0, c, stream)); HIPCHK(regrow(perm_inverse, 0, c, stream));
     send_cap = cap;
     chunk_cap = (cap + 255) / 256 + 1;
     HIPCHK(regrow(chunk_count, 0, (size_t)27 * chunk_cap + 1, stream));
     HIPCHK(regrow(chunk_offset, 0, (size_t)27 * chunk_cap + 1, stream));
     size_t tb = std::max(sort_temp_bytes_u32(cap), sort_temp_bytes_u64(cap));
     tb = std::max(tb, scan_temp_bytes(27 * chunk_cap + 1));
+    if (tb > scan_temp_side_bytes) {       // the side stream's scans (overlapped rebuild) need their own scratch
+        if (scan_temp_side) (void)hipFree(scan_temp_side);
+        scan_temp_side = nullptr;
+        HIPCHK(hipMalloc(&scan_temp_side, tb));
+        scan_temp_side_bytes = tb;
+    }
     if (tb > sort_temp_bytes) {
         if (sort_temp) (void)hipFree(sort_temp);
         sort_temp = nullptr;
@@ -863,6 +872,12 @@ int Engine::init_params()
             HIPCHK(dalloc(brick_pos, M / 16 + 1));
             HIPCHK(dalloc(brick_active, M / 16 + 1));
             size_t tb = scan_temp_bytes((int)(2 * M + 2));  // atoms per extended code (2M + 1) is the longest scan
+            if (tb > scan_temp_side_bytes) {
+                if (scan_temp_side) (void)hipFree(scan_temp_side);
+                scan_temp_side = nullptr;
+                HIPCHK(hipMalloc(&scan_temp_side, tb));
+                scan_temp_side_bytes = tb;
+            }
             if (tb > sort_temp_bytes) {
                 if (sort_temp) (void)hipFree(sort_temp);
                 sort_temp = nullptr;
@@ -982,7 +997,8 @@ int Engine::reorder_locals()
     if (layout >= 1) {
         // the gather also writes the merged float4 pair of the new order, with the signatures of the current step
         launch_permute_merge(cur, alt, rval, nlocal, permute_forces ? 1 : 0, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
-                             0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), stream);
+                             0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), nullptr,
+                             stream);
         merged_in_reorder = true;      // (alloc_atoms clears it: a regrown coord4 has lost the values)
     } else {
         launch_permute_atoms(cur, alt, rval, nlocal, permute_forces ? 1 : 0, stream);
@@ -1001,6 +1017,69 @@ int Engine::reorder_locals()
     HIPCHK(hipStreamSynchronize(stream));
     if (h_flags[0]) return check_overflow();
     n_bulk = h_flags[1];
+    return 0;
+}
+
+// One rank, no host round trip, two streams.  Which atoms become ghosts depends on the (wrapped) positions only, not on the
+// storage order, so the two halves of a rebuild are independent until the very end:
+//   main stream: reorder of the locals - count per extended code (wraps the coordinates), scan, place + order, gather
+//                (which also leaves the inverse permutation);
+//   side stream: border lists on the OLD order, ghost creation into the arrays of the NEW order (behind the locals), ghost
+//                binning (count, scan, order -> gstart, gslot);
+//   join:        the send list is translated to the new order (one small kernel) - the per-step refresh reads it.
+// Ghost numbering differs from the serial path (ascending old instead of new index inside a direction); ghost SLOTS,
+// neighbour sets and forces do not (fixed-point force sums are order independent).
+int Engine::rebuild_overlapped()
+{
+    tbegin("reorder");
+    const int ncodes = 2 * bargs.M;
+    if (!ev_wrap) { HIPCHK(hipEventCreateWithFlags(&ev_wrap, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_ghosts, hipEventDisableTiming)); }
+    const int bound = nghost_prev + nghost_prev / 8 + 1024;
+    TRY(ensure_capacity(nlocal + bound));
+    // ---- main: key, rank and count per extended code; the periodic wrap happens here
+    launch_reorder_count(cur, geom, slab_lo, slab_hi, rkey, rval_alt, rcount, nlocal, wrap_in_reorder ? boxlo : nullptr, boxhi, periodic, stream);
+    HIPCHK(hipEventRecord(ev_wrap, stream));
+    // ---- side: borders and ghosts from the old order
+    HIPCHK(hipStreamWaitEvent(side, ev_wrap, 0));
+    const int end = nlocal, nchunk = (end + 255) / 256;
+    launch_border_count(cur, 0, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, side);
+    if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
+    const int cap_bound = std::min(bound, send_cap);
+    if (!launch_border_scan(chunk_count, chunk_offset, nchunk, d_dir_start, d_flags + 3 /* any value >= 0: no range check */, 0, cap_bound,
+                            d_flags, h_flags_dev, side)) {
+        HIPCHK(exclusive_scan_i32(scan_temp_side, scan_temp_side_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, side));
+        launch_dir_starts_check(chunk_offset, nchunk, d_dir_start, d_flags + 3, 0, cap_bound, d_flags, side);
+        HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, side));
+        HIPCHK(hipMemcpyAsync(h_flags + 8, d_flags, sizeof(int), hipMemcpyDeviceToHost, side));
+    }
+    nsend = nghost = bound;            // launch bounds until resolve_counts() has the numbers
+    launch_border_fill(cur, 0, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, side);
+    // ghosts go behind the locals of the arrays the gather below fills (alt becomes cur)
+    launch_pack_border(cur, sendlist, nsend, d_dir_start, shift27, alt.x[0] + nlocal, alt.x[1] + nlocal, alt.x[2] + nlocal,
+                       alt.tag + nlocal, alt.type + nlocal, alt.mask + nlocal, side);
+    const int *ng_dev = d_dir_start + 27;
+    launch_ghost_count(alt, geom, nlocal, nghost, bin_key, bin_val, gcount, ng_dev, side);
+    HIPCHK(exclusive_scan_i32(scan_temp_side, scan_temp_side_bytes, gcount, gstart, bargs.M + 1, side));
+    launch_ghost_order(bin_key, bin_val, gstart, bargs.M, nghost, reorder_cap, gtmp_placed, bin_val_alt, gtmp_code, gslot, gcount, ng_dev, side);
+    HIPCHK(hipEventRecord(ev_ghosts, side));
+    // ---- main: scan, placement, ordering, gather
+    HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, rcount, estart, ncodes + 1, stream));
+    launch_reorder_place(rkey, rval_alt, estart, geom, ncodes, nlocal, reorder_cap, (int *)rkey_alt, rval, (uint32_t *)bin_key_alt, rcount, stream);
+    std::swap(rkey, bin_key_alt);
+    launch_permute_merge(cur, alt, rval, nlocal, permute_forces ? 1 : 0, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
+                         0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), perm_inverse,
+                         stream);
+    merged_in_reorder = true;
+    std::swap(cur, alt);
+    // ---- join
+    HIPCHK(hipStreamWaitEvent(stream, ev_ghosts, 0));
+    launch_translate_list(sendlist, perm_inverse, nsend, ng_dev, estart + bargs.M, h_flags_dev, stream);
+    if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_counts, stream));
+    counts_pending = true;
+    bulk_pending = true;
+    ghosts_binned = true;
+    tend("reorder");
     return 0;
 }
 
@@ -1122,7 +1201,9 @@ int Engine::build_cells_and_table()
             bargs.nactive = bargs.nbricks;
             bargs.nactive_dev = nullptr;
         }
-        if (ghost_sort) {
+        if (ghosts_binned) {
+            // (rebuild_overlapped binned this rebuild's ghosts on the side stream)
+        } else if (ghost_sort) {
             launch_ghost_morton(cur, geom, nlocal, nghost, bin_key, bin_val, stream);
             if (nghost > 0)
                 HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nghost,
@@ -1268,8 +1349,13 @@ int Engine::reneighbor()
     wrap_in_reorder = nranks == 1 && layout >= 1 && !reorder_sort && nlocal > 0;
     if (!wrap_in_reorder) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
     TRY(migrate());
-    TRY(reorder_locals());
-    TRY(halo_borders());
+    ghosts_binned = false;
+    if (async_ok() && overlap_rebuild && nlocal > 0) {
+        TRY(rebuild_overlapped());
+    } else {
+        TRY(reorder_locals());
+        TRY(halo_borders());
+    }
     // neighbour rows and the ring records of the force kernel keep atom indices in 25 bits (pair_ring.hip, meso_device.h)
     if ((long)nlocal + nghost > (1L << 25))
         return fail(4, "Too many atoms on one rank: local + ghost atoms exceed 33554432 (25-bit neighbour indices); use more ranks");

@@ -68,7 +68,9 @@ void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int 
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s);
 // ... and the merged float4 pair of the new order in the same pass (k_merge_xvt folded in)
 void launch_permute_merge(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, float4 *coord4,
-                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, hipStream_t s);
+                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, int *inverse /*nullable: old -> new place*/,
+                          hipStream_t s);
+void launch_translate_list(int *list, const int *inverse, int bound, const int *n_dev, const int *n_bulk, int *report, hipStream_t s);
 void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s);
 
 // ---- halo: border lists + pack (comm_meso.cu:41-186, atom_vec_dpd_atomic_meso.cu:61-244) --------------

@@ -543,13 +543,14 @@ void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int 
 // gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
 // mg.coord4 != null: the merged float4 pair of the atom's new place is written as well (gpu_merge_xvt folded into the gather:
 // the reorder has x, v, tag and type in registers anyway; 17 us of re-reading them at 64^3)
-struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; };
+struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; int *inverse; };
 __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n, int with_f,
                                                        MergeOut mg)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
     if (i >= n) return;
     int j = from[i];
+    if (mg.inverse) mg.inverse[j] = i;      // old place -> new place (the overlapped rebuild translates its send list with it)
     double xx[3], vv[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -592,13 +593,13 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
 }
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s)
 {
-    MergeOut mg = {nullptr, nullptr, 0.0, 0.0, 0.0, 0u};
+    MergeOut mg = {nullptr, nullptr, 0.0, 0.0, 0.0, 0u, nullptr};
     if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f, mg);
 }
 void launch_permute_merge(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, float4 *coord4,
-                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, hipStream_t s)
+                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, int *inverse, hipStream_t s)
 {
-    MergeOut mg = {coord4, veloc4, cx, cy, cz, seed};
+    MergeOut mg = {coord4, veloc4, cx, cy, cz, seed, inverse};
     if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f, mg);
 }
 
@@ -856,6 +857,19 @@ __global__ void __launch_bounds__(1024) k_border_scan(const int *__restrict__ cn
         report[9] = *n_bulk;
     }
 }
+// send list built on the pre-reorder order -> indices of the new order; also the last word of the host report (n_bulk)
+__global__ void __launch_bounds__(256) k_translate_list(int *__restrict__ list, const int *__restrict__ inverse, int bound,
+                                                        const int *__restrict__ n_dev, const int *__restrict__ n_bulk, int *__restrict__ report)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && report) report[9] = *n_bulk;
+    if (k < min(bound, *n_dev)) list[k] = inverse[list[k]];
+}
+void launch_translate_list(int *list, const int *inverse, int bound, const int *n_dev, const int *n_bulk, int *report, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_translate_list, dim3(nblk(std::max(bound, 1), 256)), dim3(256), 0, s, list, inverse, bound, n_dev, n_bulk, report);
+}
+
 bool launch_border_scan(const int *cnt, int *off, int nchunk, int *dir_start, const int *n_bulk, int scan_beg, int bound, int *flags,
                         int *report, hipStream_t s)
 {
