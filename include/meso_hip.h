@@ -38,11 +38,9 @@ int meso_init(int device, meso_ctx **ctx);
 int meso_finalize(meso_ctx *ctx);
 int meso_device_sync(meso_ctx *ctx);
 /* engine options (profiling windows, kernel variants); unknown keys are an error.  Defaults are the measured best:
- *   layout        2  cell order = storage order, global-index rows | 1 bricks (LDS-staged force kernel, 16-bit rows)
- *                    | 0 bin-sorted cell list (reference-like); fixed at setup
- *   pair_kernel   2  auto: ring kernel (both styles) on layout 2 | 0 lane per atom | 1 tile / brick kernel
- *                    | 3 MLP + ballot compaction | 4 MLP | 5 ring
- *   neigh_kernel  1  wave-per-bin tile builder (layout 2) / wave64 builder (layout 0) | 0 lane-per-atom builders
+ *   pair_kernel   2  ring kernel (both styles) | 0 lane per atom (the kernel that also books energy and virial); the tile, MLP
+ *                    and brick kernels and the bin-sorted / brick layouts of round 1 were retired (option layout accepts 2 only)
+ *   neigh_kernel  1  wave-per-bin tile builder | 0 lane-per-atom cell builder (also the fallback for very wide rows)
  *   fuse_step     1  final(s) + initial(s+1) + merge(s+1) in one pass between the steps of one run
  *   fuse_pair     1  ... inside the ring kernel's epilogue (forces are then not stored on those steps)
  *   pair_share    1  ring kernel: pairs inside one aligned 256-atom group are evaluated once (Newton pairing)

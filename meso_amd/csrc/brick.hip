@@ -1,20 +1,15 @@
-// Brick kernels: the LDS-staged layout of the DPD hot path (engine option layout=1).
+// Brick kernels: the neighbour-table builder of the DPD hot path and its per-rebuild plan.
 //
 // Local atoms are sorted by [border bit][Morton(bin)][Morton(sub-cell)] (atom_meso.cu:268-308), so every aligned
 // group of 64 Morton codes is a 4x4x4 brick of bins whose atoms are contiguous in memory (one run per section:
-// bulk, border), and ghosts are sorted by Morton(bin) behind them.  One workgroup owns one brick.  A per-rebuild
-// PLAN kernel writes, for every brick, the map "halo slot -> global atom index" of its 6x6x6-bin neighbourhood
-// (~1900 atoms at rho=4, whole bin runs in halo-bin order).  The list builder and the force kernel copy the
-// neighbourhood's coordinates from HBM into LDS ONCE per launch with coalesced reads, and every neighbour gather
-// then hits LDS: the lane-per-atom gathers of the cell-ordered kernels are bound by the L1 tag rate (one 128-byte
-// line per clock per CU, ~50 lines per 64-lane gather; profiles/r01_notes.md), LDS serves 4 random 16-byte reads
-// per clock.  Neighbour rows hold 16-bit halo-local BYTE offsets (slot * 16): half the table traffic of the
-// reference's int rows and no address arithmetic in the scan.
-//   rows:  8 entries = one 16-byte word; word(i, c) = ((i>>6)*(n_col/8) + c)*64 + (i&63)   (a wave reads 1 KiB)
+// bulk, border), and ghosts are sorted by Morton(bin) behind them.  One workgroup owns one brick (or shares it with a few
+// others in small boxes).  The PLAN - for every brick the map "halo slot -> global atom index" of its 6x6x6-bin
+// neighbourhood (~1900 atoms at rho=4, whole bin runs in halo-bin order) - is computed in the builder's prologue (or by
+// k_brick_plan, option tile_plan); the builder copies the neighbourhood's coordinates from HBM into LDS ONCE per launch
+// with coalesced reads and every candidate read then hits LDS.
 //
-// Replaces gpu_build_neighbor_list + gpu_join/transpose (neigh_build_meso.cu:20-240) and gpu_dpd_fast
-// (pair_dpd_fast_meso.cu:91-205); membership test and per-pair arithmetic are those of the other kernels, so
-// results agree to summation order (and the fp32 force sums are order-independent 64-bit fixed point).
+// Replaces gpu_build_neighbor_list + gpu_join/transpose (neigh_build_meso.cu:20-240).  (Round 1 also kept a force kernel
+// and a 16-bit-row builder on this layout - `layout=1`; retired in round 2, the cell-ordered ring kernel is faster.)
 #include "kernels.h"
 #include "meso_device.h"
 
@@ -155,71 +150,6 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
         }
     }
 }
-
-// =========================================================================================
-// neighbour table builder
-// =========================================================================================
-__global__ void __launch_bounds__(BRK_THREADS) k_brick_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
-                                                            int n_col, int *__restrict__ count,
-                                                            unsigned short *__restrict__ table16, int *__restrict__ overflow)
-{
-#pragma clang fp contract(fast)
-    __shared__ float4 hc[BRK_MAXH];
-    __shared__ int hoff[BRK_NHB + 1];
-    __shared__ u32 stage[8 * BRK_THREADS];      // stage[q][thread]: the open 8-entry chunk of each lane
-    const int tid = threadIdx.x;
-    const int slot = brick_slot(g);
-    if (slot < 0) return;
-    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
-    const int nh = hdr[0], o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
-    if (n0 + n1 == 0) return;
-    for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
-    for (int h = tid; h < nh; h += BRK_THREADS) hc[h] = coord4[g.hmap[(size_t)slot * g.maxh + h]];
-    __syncthreads();
-    uint4 *rows = (uint4 *)table16;
-    for (int o = tid; o < n0 + n1; o += BRK_THREADS) {
-        const int i = o < n0 ? o0 + o : o1 + (o - n0);
-        const u32 info = g.own_info[i];
-        const int loc = (int)(info & 0xFFFFu), hb = (int)(info >> 16);
-        const float4 ci = hc[loc];
-        int n = 0;
-        auto flush = [&](int c) {
-            const u32 e0 = stage[tid], e1 = stage[BRK_THREADS + tid], e2 = stage[2 * BRK_THREADS + tid],
-                      e3 = stage[3 * BRK_THREADS + tid], e4 = stage[4 * BRK_THREADS + tid], e5 = stage[5 * BRK_THREADS + tid],
-                      e6 = stage[6 * BRK_THREADS + tid], e7 = stage[7 * BRK_THREADS + tid];
-            rows[row_word(i, c, n_col)] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
-        };
-        auto test = [&](int k, const float4 c) {
-            const float dx = ci.x - c.x, dy = ci.y - c.y, dz = ci.z - c.z;
-            const float d = dx * dx + dy * dy + dz * dz;
-            if (d <= rc2 && k != loc) {
-                stage[(n & 7) * BRK_THREADS + tid] = (u32)k << 4;        // byte offset into the staged coordinates
-                if ((n & 7) == 7 && n < n_col) flush(n >> 3);
-                n++;
-            }
-        };
-#pragma unroll 1
-        for (int r = 0; r < 9; r++) {
-            // x-adjacent halo bins are consecutive halo-bin indices: one contiguous run of halo slots per (y,z) row
-            const int hrow = hb + (r % 3 - 1) * BRK_H + (r / 3 - 1) * BRK_H * BRK_H;
-            const int kb = hoff[hrow - 1], ke = hoff[hrow + 2];
-            int k = kb;
-            for (; k + 4 <= ke; k += 4) {       // 4 LDS reads in flight per lane
-                const float4 c0 = hc[k], c1 = hc[k + 1], c2 = hc[k + 2], c3 = hc[k + 3];
-                test(k, c0); test(k + 1, c1); test(k + 2, c2); test(k + 3, c3);
-            }
-            for (; k < ke; k++) test(k, hc[k]);
-        }
-        // tail chunk: unused slots point at the atom itself (rsq = 0 is rejected by the force kernel)
-        if ((n & 7) && n < n_col) {
-            for (int q = n & 7; q < 8; q++) stage[q * BRK_THREADS + tid] = (u32)loc << 4;
-            flush(n >> 3);
-        }
-        if (n > n_col) { atomicMax(overflow, n); n = n_col; }
-        count[i] = n;
-    }
-}
-
 
 // =========================================================================================
 // neighbour table builder, wave-per-bin ballot stenciling (cell-ordered layout, global-index rows)
@@ -480,192 +410,6 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     }
 }
 
-// halo-local rows -> global-index rows, transposed 64-atom tiles (for the lane-per-atom kernels, energy/virial
-// steps and the introspection calls)
-__global__ void __launch_bounds__(256) k_brick_convert(BrickArgs g, int n_col, const int *__restrict__ count,
-                                                      const unsigned short *__restrict__ table16,
-                                                      int *__restrict__ table32)
-{
-    const int slot = brick_slot(g);
-    if (slot < 0) return;
-    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
-    const int o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
-    const u32 *hmap = g.hmap + (size_t)slot * g.maxh;
-    for (int o = threadIdx.x; o < n0 + n1; o += 256) {
-        const int i = o < n0 ? o0 + o : o1 + (o - n0);
-        const size_t base = ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
-        const int n = count[i];
-        for (int p = 0; p < n; p++)
-            table32[base + (size_t)p * 64] = (int)hmap[table16[row_word(i, p >> 3, n_col) * 8 + (p & 7)] >> 4];
-    }
-}
-
-// =========================================================================================
-// pair force (dpd/fast/meso)
-// =========================================================================================
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-
-template <bool NT1>
-__global__ void __launch_bounds__(BRK_THREADS, 2) k_brick_pair(BrickArgs g, PairArgs a,
-                                                              const unsigned short *__restrict__ table16)
-{
-#pragma clang fp contract(fast)
-    __shared__ float4 hc[BRK_MAXH];              // staged coordinates (x, y, z, type)
-    __shared__ u32 hgi[BRK_MAXH];                // halo slot -> global index (velocity gathers of the hits)
-    __shared__ u32 ring[BRK_WAVES][BRK_RING];    // per wave: queued hits, owner lane << 16 | partner byte offset
-    __shared__ u64 facc[BRK_WAVES][3][64];       // per wave: force sums, 2^-32 fixed point
-    extern __shared__ float cf32[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * N_COEFF;
-    for (int p = tid; p < ncf; p += BRK_THREADS) cf32[p] = a.coeff32[p];
-    const int slot = brick_slot(g);
-    if (slot < 0) return;
-    const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
-    const int nh = hdr[0], o0 = hdr[1], n0 = hdr[2], o1 = hdr[3], n1 = hdr[4];
-    const int n_own = n0 + n1;
-    if (n_own == 0) return;
-    // work-range filter (compute_bulk / compute_border): nothing of this brick inside [beg, end)
-    if ((n0 == 0 || o0 >= a.end || o0 + n0 <= a.beg) && (n1 == 0 || o1 >= a.end || o1 + n1 <= a.beg)) return;
-    for (int h = tid; h < nh; h += BRK_THREADS) {
-        const u32 src = g.hmap[(size_t)slot * g.maxh + h];
-        hgi[h] = src;
-        hc[h] = a.coord4[src];
-    }
-    __syncthreads();
-    if (a.debug == 1) return;
-
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, a.nall * 16, 0x00020000);
-    const float dtis = (float)a.dt_inv_sqrt;
-    const uint4 *rows = (const uint4 *)table16;
-    u32 *myring = ring[w];
-    u64 *myf = &facc[w][0][0];
-    const char *hcb = (const char *)hc;
-
-    for (int obase = w * 64; obase < n_own; obase += BRK_WAVES * 64) {
-        const int o = obase + lane;
-        const int i = o < n0 ? o0 + o : o1 + (o - n0);
-        const bool mine = o < n_own && i >= a.beg && i < a.end;
-        int n = 0;
-        u32 myoff = 0;
-        float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
-        if (mine) {
-            myoff = (g.own_info[i] & 0xFFFFu) << 4;
-            c1 = *(const float4 *)(hcb + myoff);
-            v1 = a.veloc4[i];
-            n = a.count[i];
-        }
-        myf[lane] = 0; myf[64 + lane] = 0; myf[128 + lane] = 0;
-        const u32 t1 = __float_as_uint(c1.w);
-        const u32 lanehi = (u32)lane << BRK_OWNER_SHIFT;
-        const int nch = (n + 7) >> 3;
-        int nchmax = nch;
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) nchmax = max(nchmax, __shfl_xor(nchmax, s, 64));
-        nchmax = __builtin_amdgcn_readfirstlane(nchmax);
-
-        int qhead = 0, qtail = 0;     // wave-uniform
-        int pn = 0;                   // hits of the batch whose velocity gathers are in flight
-        u32 pe = 0;
-        float4 pv2 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-        auto compute = [&]() {        // evaluate the pending batch (lane = hit)
-            if (pn > 0) {
-                // the owner's slot and velocity come from the owner lane's registers: fetched with every lane enabled
-                // (a bpermute reads 0 from disabled lanes)
-                const u32 owner = pe >> BRK_OWNER_SHIFT;
-                const int oaddr = (int)(owner << 2);
-                const u32 ooff = (u32)__builtin_amdgcn_ds_bpermute(oaddr, (int)myoff);
-                float4 vi;
-                vi.x = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.x)));
-                vi.y = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.y)));
-                vi.z = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.z)));
-                vi.w = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v1.w)));
-                if (lane < pn) {
-                    const float4 ci = *(const float4 *)(hcb + ooff), cj = *(const float4 *)(hcb + (pe & 0xFFFFu));
-                    float c_cutinv, c_ew, c_a0, c_gamma, c_sigma;
-                    if (NT1) {
-                        c_cutinv = (float)a.cf1[P_CUTINV]; c_ew = (float)a.cf1[P_EXPW]; c_a0 = (float)a.cf1[P_A0];
-                        c_gamma = (float)a.cf1[P_GAMMA]; c_sigma = (float)a.cf1[P_SIGMA];
-                    } else {
-                        const float *cf = cf32 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(cj.w)) * N_COEFF;
-                        c_cutinv = cf[P_CUTINV]; c_ew = cf[P_EXPW]; c_a0 = cf[P_A0]; c_gamma = cf[P_GAMMA]; c_sigma = cf[P_SIGMA];
-                    }
-                    const float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
-                    const float rsq = dx * dx + dy * dy + dz * dz;
-                    const float rn = gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w));
-                    const float rinv = __builtin_amdgcn_rsqf(rsq);
-                    const float r = rsq * rinv;
-                    const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;
-                    const float dot = dx * dvx + dy * dvy + dz * dvz;
-                    const float wc = 1.0f - r * c_cutinv;
-                    float wr = wc;
-                    if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
-                    float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
-                    fpair *= rinv;
-                    __hip_atomic_fetch_add(&myf[owner], to_fixed(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(&myf[64 + owner], to_fixed(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(&myf[128 + owner], to_fixed(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-                pn = 0;
-            }
-        };
-        auto issue = [&](int nb) {    // request the partner velocities of the next nb queued hits
-            if (lane < nb) {
-                pe = myring[(qhead + lane) & (BRK_RING - 1)];
-                const u32 gj = hgi[(pe & 0xFFFFu) >> 4];
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(gj << 4), 0, 0);
-                pv2 = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-            }
-            pn = nb;
-            qhead += nb;
-        };
-
-        const uint4 *myrows = rows + row_word(mine ? i : 0, 0, a.n_col);
-        uint4 wcur = make_uint4(0, 0, 0, 0);
-        if (nch > 0) wcur = myrows[0];
-#pragma unroll 1
-        for (int c = 0; c < nchmax; c++) {
-            const bool active = c < nch;
-            const u32 ww[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
-            if (c + 1 < nch) wcur = myrows[(size_t)(c + 1) * 64];
-            // two half-chunks of 4: LDS latency is short, and 4 partner coordinates in flight keep the kernel at
-            // 80 VGPRs (two workgroups of 10 waves per CU need 6 wave slots on a SIMD)
-#pragma unroll
-            for (int hq = 0; hq < 2; hq++) {
-                u32 joff[4];
-                float4 c2[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const u32 word = ww[2 * hq + (q >> 1)];
-                    joff[q] = (q & 1) ? (word >> 16) : (word & 0xFFFFu);
-                    c2[q] = *(const float4 *)(hcb + joff[q]);      // lanes past their row re-read a valid slot; masked below
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
-                    const float rsq = dx * dx + dy * dy + dz * dz;
-                    const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
-                    const bool hit = active & (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ);    // tail slots hold the atom itself
-                    const u64 m = __builtin_amdgcn_ballot_w64(hit);
-                    if (hit) myring[__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (BRK_RING - 1)] = joff[q] | lanehi;
-                    qtail += __popcll(m);
-                    if (q & 1) {
-                        while (qtail - qhead >= 64) { compute(); issue(64); }
-                    }
-                }
-            }
-        }
-        compute();
-        while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
-
-        if (mine) {
-            const double fx = from_fixed(myf[lane]), fy = from_fixed(myf[64 + lane]), fz = from_fixed(myf[128 + lane]);
-            if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
-            else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
-        }
-    }
-}
-
 // =========================================================================================
 // cell structure kernels
 // =========================================================================================
@@ -740,22 +484,6 @@ void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int ngho
 }
 static inline int brick_grid(const BrickArgs &g) { return (g.nactive + 7) / 8 * 8; }
 
-// flag[b] = 1 if brick b owns atoms (bulk or border section); the engine scans the flags and compacts the ids
-__global__ void __launch_bounds__(256) k_brick_flags(const int *__restrict__ estart, int M, int nb, int *__restrict__ flag)
-{
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const size_t e0 = (size_t)BRK_CODES * b, e1 = (size_t)M + e0;
-    flag[b] = (estart[e0 + BRK_CODES] > estart[e0] || estart[e1 + BRK_CODES] > estart[e1]) ? 1 : 0;
-}
-__global__ void __launch_bounds__(256) k_brick_compact(const int *__restrict__ flag, const int *__restrict__ pos, int nb,
-                                                       int *__restrict__ active, int *__restrict__ nactive)
-{
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    if (flag[b]) active[pos[b]] = b;
-    if (b == nb - 1) *nactive = pos[b] + flag[b];
-}
 int brick_codes() { return BRK_CODES; }
 int brick_static_maxh() { return BRK_MAXH; }        // capacity of the brick-layout kernels (static LDS arrays)
 int brick_static_maxown() { return BRK_MAXOWN; }
@@ -763,17 +491,6 @@ int brick_static_maxown() { return BRK_MAXOWN; }
 int tile_build_maxh_limit(int n_col, int with_tags) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / (with_tags ? 20 : 16)); }
 size_t brick_hoff_pitch() { return BRK_HOFF_PITCH; }
 size_t brick_hdr_pitch() { return BRK_HDR_PITCH; }
-
-void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s)
-{
-    int nb = M / BRK_CODES;
-    hipLaunchKernelGGL(k_brick_flags, dim3((nb + 255) / 256), dim3(256), 0, s, estart, M, nb, flag);
-}
-void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s)
-{
-    int nb = M / BRK_CODES;
-    hipLaunchKernelGGL(k_brick_compact, dim3((nb + 255) / 256), dim3(256), 0, s, flag, pos, nb, active, nactive);
-}
 
 void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s)
 {
@@ -829,29 +546,5 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     }
 }
 int tile_build_rowcap() { return TB_ROWCAP_MAX; }
-
-void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,
-                        unsigned short *table16, int *overflow, hipStream_t s)
-{
-    if (g.nactive <= 0) return;
-    hipLaunchKernelGGL(k_brick_build, dim3(brick_grid(g)), dim3(BRK_THREADS), 0, s, g, coord4, rc2, n_col, count, table16,
-                       overflow);
-}
-
-void launch_brick_convert(const BrickArgs &g, int n_col, const int *count, const unsigned short *table16, int *table32,
-                          hipStream_t s)
-{
-    if (g.nactive <= 0) return;
-    hipLaunchKernelGGL(k_brick_convert, dim3(brick_grid(g)), dim3(256), 0, s, g, n_col, count, table16, table32);
-}
-
-void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, hipStream_t s)
-{
-    if (p.end <= p.beg || g.nactive <= 0) return;
-    const bool nt1 = p.ntypes == 1;
-    size_t sm = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * 4;
-    if (nt1) hipLaunchKernelGGL((k_brick_pair<true>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16);
-    else hipLaunchKernelGGL((k_brick_pair<false>), dim3(brick_grid(g)), dim3(BRK_THREADS), sm, s, g, p, table16);
-}
 
 } // namespace meso

@@ -230,17 +230,15 @@ private:
     int n_col = 0;
     int *pair_count = nullptr, *pair_table = nullptr;
     size_t table_tiles = 0;
-    uint32_t *bin_id = nullptr, *bin_key = nullptr, *bin_key_alt = nullptr;
-    int *bin_val = nullptr, *bin_val_alt = nullptr, *bin_start = nullptr;
-    int bin_cap = 0;
+    uint32_t *bin_key = nullptr, *bin_key_alt = nullptr;      // ghost binning scratch
+    int *bin_val = nullptr, *bin_val_alt = nullptr;
     int64_t nbuild = 0;
     int ago = 0;
 
     // brick layout
-    int layout = 2;                 // 0: bin-sorted cell list, 1: bricks with LDS-staged halos, 2: cell-ordered atoms
+    static constexpr int layout = 2;   // cell order = storage order (the bin-sorted and brick layouts of round 1 were retired)
     int *estart = nullptr, *gstart = nullptr, *gslot = nullptr;
     int4 *binrange = nullptr;
-    int *brick_flag = nullptr, *brick_pos = nullptr, *brick_active = nullptr;
     int *brick_hoff = nullptr, *brick_hdr = nullptr;
     uint32_t *brick_hmap = nullptr, *brick_own = nullptr;
     size_t brick_cap = 0;
@@ -268,8 +266,6 @@ private:
     bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
     double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)
     size_t estart_cap = 0;
-    unsigned short *table16 = nullptr;
-    bool table32_valid = false;
     BrickArgs bargs{};
     int l1bits = 0;
     int ensure_table32();

@@ -81,12 +81,12 @@ void Engine::free_all()
     dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
     dfree(pair_count); dfree(pair_table);
-    dfree(bin_id); dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(bin_start);
+    dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
-    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(table16);
-    dfree(brick_flag); dfree(brick_pos); dfree(brick_active); dfree(binrange);
+    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot);
+    dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
     dfree(d_partial); dfree(d_scalar); dfree(d_flags); dfree(sendlist_aux);
@@ -313,7 +313,13 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
     if (key == "fuse_step") { fuse_step = (int)val; return 0; }
     if (key == "overlap") { overlap = (int)val; return 0; }
-    if (key == "pair_kernel") { pair_kernel = (int)val; return 0; }
+    if (key == "pair_kernel") {
+        // 2 (= 5): ring kernel; 0: lane per atom (the reference-like kernel that also serves the energy/virial steps).
+        // The tile, MLP and brick kernels of round 1 were retired.
+        if (val != 0 && val != 2 && val != 5) return fail(1, "pair_kernel: 0 (lane per atom) or 2 (ring); the other kernels were retired");
+        pair_kernel = (int)val;
+        return 0;
+    }
     if (key == "fuse_pair") { fuse_pair = (int)val; return 0; }
     if (key == "brick_margin") { if (val < 1.0) return fail(1, "brick_margin must be >= 1"); brick_margin = val; params_ready = false; return 0; }
     if (key == "pair_share") { pair_share = (int)val; return 0; }
@@ -325,7 +331,10 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "async_counts") { async_counts = (int)val; return 0; }
     if (key == "overlap_rebuild") { overlap_rebuild = (int)val; return 0; }
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
-    if (key == "layout") { if (is_setup) return fail(3, "layout must be chosen before setup"); layout = (int)val; return 0; }
+    if (key == "layout") {     // kept for scripts of round 1: only the cell-ordered layout exists
+        if (val != 2) return fail(1, "layout: only 2 (cell order = storage order); layouts 0 and 1 were retired");
+        return 0;
+    }
     if (key == "groupbit") { groupbit = (int)val; return 0; }
     return fail(1, "Unknown option '" + key + "'");
 }
@@ -397,7 +406,7 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(e_pair, 0, c, stream));
     HIPCHK(regrow(xhold, 0, 3 * c, stream));
     HIPCHK(regrow(pair_count, 0, c, stream));
-    HIPCHK(regrow(bin_id, 0, c, stream)); HIPCHK(regrow(bin_key, 0, c, stream)); HIPCHK(regrow(bin_key_alt, 0, c, stream));
+    HIPCHK(regrow(bin_key, 0, c, stream)); HIPCHK(regrow(bin_key_alt, 0, c, stream));
     HIPCHK(regrow(bin_val, 0, c, stream)); HIPCHK(regrow(bin_val_alt, 0, c, stream));
     HIPCHK(regrow(rkey, 0, c, stream)); HIPCHK(regrow(rkey_alt, 0, c, stream));
     HIPCHK(regrow(rval, 0, c, stream)); HIPCHK(regrow(rval_alt, 0, c, stream));
@@ -426,8 +435,6 @@ int Engine::alloc_atoms(int cap)
         table_tiles = ((size_t)cap + 63) / 64;
         dfree(pair_table);
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
-        dfree(table16);
-        HIPCHK(dalloc(table16, table_tiles * 64 * (size_t)n_col));
         dfree(brick_own);
         HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
@@ -561,7 +568,7 @@ int Engine::rebuild_topology()
 {
     if (!have_bonds) return 0;
     int nall = nlocal + nghost;
-    launch_tag_cell(cur.tag, layout >= 1 ? gslot : nullptr, nlocal, nghost, tagc, stream);
+    launch_tag_cell(cur.tag, gslot, nlocal, nghost, tagc, stream);
     HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
     launch_set_map(tagc, nall, maxtag, tagmap, stream);
     // (d_flags[4] counts partners that are neither local nor ghost; it stays set until check_overflow reports it)
@@ -844,8 +851,6 @@ int Engine::init_params()
         table_tiles = ((size_t)nmax + 63) / 64;
         dfree(pair_table);
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
-        dfree(table16);
-        HIPCHK(dalloc(table16, table_tiles * 64 * (size_t)n_col));
         dfree(brick_own);
         HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
@@ -855,7 +860,7 @@ int Engine::init_params()
         while ((1 << (l1bits + 1)) <= max_bin * 2) l1bits++;
         size_t M = (size_t)1 << (3 * l1bits);
         if (2 * M + 1 > estart_cap) {
-            dfree(estart); dfree(gstart); dfree(brick_flag); dfree(brick_pos); dfree(brick_active);
+            dfree(estart); dfree(gstart);
             estart_cap = 2 * M + 1;
             HIPCHK(dalloc(estart, estart_cap));
             HIPCHK(dalloc(gstart, M + 1));
@@ -868,9 +873,6 @@ int Engine::init_params()
             HIPCHK(hipMemsetAsync(rcount, 0, (2 * M + 1) * sizeof(int), stream));
             dfree(binrange);
             HIPCHK(dalloc(binrange, 2 * M));
-            HIPCHK(dalloc(brick_flag, M / 16 + 1));
-            HIPCHK(dalloc(brick_pos, M / 16 + 1));
-            HIPCHK(dalloc(brick_active, M / 16 + 1));
             size_t tb = scan_temp_bytes((int)(2 * M + 2));  // atoms per extended code (2M + 1) is the longest scan
             if (tb > scan_temp_side_bytes) {
                 if (scan_temp_side) (void)hipFree(scan_temp_side);
@@ -893,17 +895,16 @@ int Engine::init_params()
             const double binvol = geom.binsize[0] * geom.binsize[1] * geom.binsize[2];
             const double mean = density * 216.0 * binvol * brick_margin;
             int want = ((int)std::ceil(mean + 6.5 * std::sqrt(mean)) + 63) / 64 * 64;
-            if (layout == 1) want = brick_static_maxh();
-            else if (want < brick_static_maxh()) want = brick_static_maxh();
+            if (want < brick_static_maxh()) want = brick_static_maxh();
             tile_fits = want <= tile_build_maxh_limit(n_col, have_bonds && msp > 0 ? 1 : 0);
             bargs.maxh = want;
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
             const double m128 = density * 128.0 * binvol * brick_margin;
             reorder_cap = std::min(7680, std::max(2048, ((int)std::ceil(m128 + 6.5 * std::sqrt(m128)) + 63) / 64 * 64));
             if (reorder_cap_user > 0) reorder_cap = reorder_cap_user;
-            bargs.maxown = layout == 1 ? brick_static_maxown() : 0;
+            bargs.maxown = 0;
         }
-        if (layout >= 1 && (M / brick_codes() + 8 > brick_cap || bargs.maxh != brick_maxh_alloc)) {
+        if ((M / brick_codes() + 8 > brick_cap || bargs.maxh != brick_maxh_alloc)) {
             dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr);
             brick_cap = M / brick_codes() + 8;
             brick_maxh_alloc = bargs.maxh;
@@ -914,11 +915,6 @@ int Engine::init_params()
         bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / brick_codes());
         bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
         for (int d = 0; d < 3; d++) bargs.mbin[d] = geom.mbin[d];
-    }
-    if (geom.nbin + 1 > bin_cap) {
-        dfree(bin_start);
-        bin_cap = geom.nbin + 1;
-        HIPCHK(dalloc(bin_start, (size_t)bin_cap));
     }
     // coefficient tables (prepare_coeff pair_dpd_meso.cu:68-89)
     dfree(d_coeff64); dfree(d_coeff32); dfree(d_mass_type);
@@ -966,12 +962,12 @@ int Engine::reorder_locals()
     merged_in_reorder = false;
     if (nlocal == 0) {
         n_bulk = 0;
-        if (layout >= 1) launch_estart(rkey, 0, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);   // an empty rank: all zero
+        launch_estart(rkey, 0, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);   // an empty rank: all zero
         return 0;
     }
     tbegin("reorder");
     int bits = reorder_key_bits(geom);
-    if (layout >= 1 && !reorder_sort) {
+    if (!reorder_sort) {
         // counting per extended code instead of a comparison sort (kernels.hip): ~8 launches instead of ~28; estart - first
         // index of every extended code ([border][Morton(bin)]), the border section starts at estart[M] = n_bulk - is the scan
         const int ncodes = 2 * bargs.M;
@@ -983,30 +979,24 @@ int Engine::reorder_locals()
         std::swap(rkey, bin_key_alt);            // sorted keys (the lane-per-atom list builder reads them)
         // n_bulk = estart[M]: the asynchronous rebuild reads it where it is (halo_borders), the others through d_flags[1]
         if (!async_ok()) HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
-    } else if (layout >= 1) {
+    } else {
+        // option reorder_sort: the former path - one rocPRIM radix_sort_pairs on the full key (same resulting order)
         launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
         HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
         launch_estart(rkey, nlocal, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);
         HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
-    } else {
-        launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
-        HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, rkey, rkey_alt, rval, rval_alt, nlocal, bits, stream));
-        HIPCHK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
-        launch_count_border(rkey, nlocal, bits - 1, d_flags + 1, stream);
     }
-    if (layout >= 1) {
+    {
         // the gather also writes the merged float4 pair of the new order, with the signatures of the current step
         launch_permute_merge(cur, alt, rval, nlocal, permute_forces ? 1 : 0, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
                              0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), nullptr,
                              stream);
         merged_in_reorder = true;      // (alloc_atoms clears it: a regrown coord4 has lost the values)
-    } else {
-        launch_permute_atoms(cur, alt, rval, nlocal, permute_forces ? 1 : 0, stream);
     }
     std::swap(cur, alt);
-    if (!(nranks == 1 && layout >= 1 && async_ok())) HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (!(nranks == 1 && async_ok())) HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
-    if (nranks == 1 && layout >= 1 && (nlocal <= 524288 || async_ok())) {
+    if (nranks == 1 && (nlocal <= 524288 || async_ok())) {
         // one rank, small box: the ghost-list pass below scans every local atom (bulk atoms have no flags), so the bulk
         // count is not needed yet; it arrives with that pass's own host round trip - one synchronisation per rebuild,
         // not two (+4 % at 25^3-32^3; above ~0.5 M atoms the longer scan costs more than the round trip).  With
@@ -1166,7 +1156,7 @@ int Engine::halo_forward_seed(uint32_t sd, bool async)
     if (nsend <= 0) return 0;
     tbegin("halo");
     launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,
-                        layout >= 1 ? gslot : nullptr, stream);
+                        gslot, stream);
     tend("halo");
     return 0;
 }
@@ -1183,24 +1173,13 @@ int Engine::merge_locals(uint32_t sd)
 // binning_meso (neighbor_meso.cu:535-711) + full_bin_meso (neigh_build_meso.cu:254-417)
 int Engine::build_cells_and_table()
 {
-    int nall = nlocal + nghost;
     float rc2 = (float)((cutmax + skin) * (cutmax + skin));
-    if (layout >= 1) {
-        // locals are already cell-ordered by the reorder sort; only the ghosts need binning
+    {
+        // locals are already cell-ordered by the reorder; only the ghosts need binning
         tbegin("bin");
-        if (layout == 1) {
-            // ids of the bricks that own atoms, compacted in Morton order; the count stays on the device
-            launch_brick_flags(estart, bargs.M, brick_flag, stream);
-            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, brick_flag, brick_pos, bargs.nbricks, stream));
-            launch_brick_compact(brick_flag, brick_pos, bargs.M, brick_active, d_flags + 2, stream);
-            bargs.active = brick_active;
-            bargs.nactive = bargs.nbricks;
-            bargs.nactive_dev = d_flags + 2;
-        } else {
-            bargs.active = nullptr;          // every brick, in workgroup-id order (brick_slot)
-            bargs.nactive = bargs.nbricks;
-            bargs.nactive_dev = nullptr;
-        }
+        bargs.active = nullptr;          // every brick, in workgroup-id order (brick_slot)
+        bargs.nactive = bargs.nbricks;
+        bargs.nactive_dev = nullptr;
         if (ghosts_binned) {
             // (rebuild_overlapped binned this rebuild's ghosts on the side stream)
         } else if (ghost_sort) {
@@ -1226,14 +1205,7 @@ int Engine::build_cells_and_table()
         merged_in_reorder = false;
         TRY(halo_forward_seed(sd_now));
         TRY(rebuild_topology());
-        if (layout == 1) {
-            bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
-            tbegin("neigh");
-            launch_brick_plan(bargs, d_flags, stream);
-            launch_brick_build(bargs, coord4, rc2, n_col, pair_count, table16, d_flags, stream);
-            tend("neigh");
-            table32_valid = false;
-        } else {
+        {
             tbegin("neigh");
             ExclArgs ex = {nullptr, nullptr, nullptr, 0};
             if (have_bonds && msp > 0) { ex.tagc = tagc; ex.nspecial = cur.nspecial; ex.special = cur.special; ex.msp = msp; }
@@ -1246,7 +1218,6 @@ int Engine::build_cells_and_table()
                 launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr,
                                   pair_debug >= 10 ? pair_debug - 10 : 0, stream);
                 tend("neigh");
-                table32_valid = true;
                 nbuild++;
                 return 0;
             }
@@ -1254,47 +1225,18 @@ int Engine::build_cells_and_table()
             launch_cell_build(coord4, rkey, reorder_sub_bits(geom), binrange, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count, pair_table,
                               d_flags, have_bonds ? &ex : nullptr, stream);
             tend("neigh");
-            table32_valid = true;
         }
         nbuild++;
         return 0;
     }
-    tbegin("bin");
-    launch_assign_bin(cur, geom, nlocal, nall, bin_id, bin_val, stream);
-    HIPCHK(hipMemcpyAsync(bin_key, bin_id, (size_t)nall * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-    int bits = 1;
-    while ((1 << bits) < geom.nbin) bits++;
-    HIPCHK(sort_pairs_u32(sort_temp, sort_temp_bytes, bin_key, bin_key_alt, bin_val, bin_val_alt, nall, bits, stream));
-    launch_bin_bounds(bin_key, nall, geom.nbin, bin_start, stream);
-    tend("bin");
-    TRY(merge_locals(0));
-    TRY(halo_forward_seed(0));
-    tbegin("neigh");
-    if (neigh_kernel == 0)
-        launch_neigh_build_simple(coord4, bin_id, bin_start, bin_val, geom, rc2, nlocal, n_col, pair_count, pair_table,
-                                  d_flags, stream);
-    else
-        launch_neigh_build_wave(coord4, bin_id, bin_start, bin_val, geom, rc2, nlocal, n_col, pair_count, pair_table,
-                                d_flags, stream);
-    tend("neigh");
-    table32_valid = true;
-    nbuild++;
-    return 0;
 }
 
-// brick rows hold halo-local 16-bit indices; the lane-per-atom kernels (energy/virial steps) and the
-// introspection calls want global indices
-int Engine::ensure_table32()
-{
-    if (layout != 1 || table32_valid) return 0;
-    launch_brick_convert(bargs, n_col, pair_count, table16, pair_table, stream);
-    table32_valid = true;
-    return 0;
-}
+// (the rows of the cell-ordered layout always hold global indices)
+int Engine::ensure_table32() { return 0; }
 
 bool Engine::async_ok() const
 {
-    return async_counts && nranks == 1 && layout == 2 && !ghost_sort && !reorder_sort && !have_bonds && nghost_prev >= 0 &&
+    return async_counts && nranks == 1 && !ghost_sort && !reorder_sort && !have_bonds && nghost_prev >= 0 &&
            neigh_kernel == 1 && tile_fits;
 }
 
@@ -1346,7 +1288,7 @@ int Engine::reneighbor()
     TRY(init_params());
     TRY(resolve_counts());       // the previous rebuild's counts (long since arrived) size this one
     // one rank: nothing happens between the wrap and the reorder, which reads the coordinates anyway - wrapped there
-    wrap_in_reorder = nranks == 1 && layout >= 1 && !reorder_sort && nlocal > 0;
+    wrap_in_reorder = nranks == 1 && !reorder_sort && nlocal > 0;
     if (!wrap_in_reorder) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
     TRY(migrate());
     ghosts_binned = false;
@@ -1414,7 +1356,7 @@ int Engine::force_clear(int r)
 // local range are refreshed for LOCAL and BULK calls, the ghost range for LOCAL and BORDER calls, exactly the
 // split the reference uses to hide its host round trip.
 // kernel choice (option pair_kernel): 0 lane per atom, 1 tile, 2 auto, 3 mlpc, 4 mlp, 5 ring
-bool Engine::ring_selected() const { return (pair_kernel == 5 || pair_kernel == 2) && layout == 2; }
+bool Engine::ring_selected() const { return pair_kernel == 5 || pair_kernel == 2; }
 
 void Engine::launch_pair(PairArgs &p, int ev)
 {
@@ -1429,12 +1371,9 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.all_expw_one = 1;
     p.share = (pair_share && (p.end == nlocal || (p.end & (pair_ring_group() - 1)) == 0)) ? 1 : 0;
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
-    const bool cell = layout == 2;
+    // two kernels: the ring kernel (both styles) and the lane-per-atom kernel that also books energy and virial
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
-    else if ((pair_kernel == 5 || pair_kernel == 2) && cell) launch_pair_dpd_ring(p, pair_style, stream);
-    else if (pair_kernel == 3 || (pair_kernel == 2 && pair_style == 0)) launch_pair_dpd_mlpc(p, pair_style, stream);
-    else if (pair_kernel == 2 || pair_kernel == 4 || pair_kernel == 5 || cell) launch_pair_dpd_mlp(p, pair_style, stream);
-    else launch_pair_dpd_tile(p, pair_style, stream);
+    else launch_pair_dpd_ring(p, pair_style, stream);
 }
 
 int Engine::pair_compute(int r, int eflag, int vflag)
@@ -1460,14 +1399,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.accumulate = 1;
     p.fuse_nve = 0;
     p.debug = 0;
-    p.chunked = layout == 2 ? 1 : 0;
-    if (layout == 1 && !ev && pair_kernel == 1 && pair_style == 1) {
-        p.nall = nlocal + nghost;
-        tbegin("pair");
-        launch_brick_pair(bargs, p, table16, stream);
-        tend("pair");
-        return 0;
-    }
+    p.chunked = 1;
     TRY(ensure_table32());
     tbegin("pair");
     launch_pair(p, ev);
@@ -1479,9 +1411,8 @@ int Engine::pair_compute(int r, int eflag, int vflag)
 int Engine::setup()
 {
     if (nlocal <= 0 && nranks == 1) return fail(3, "No atoms have been uploaded");
-    if (have_bonds && layout != 2) return fail(3, "bonded topology needs the cell-ordered layout (layout=2)");
     if ((pair_rng || pair_poly || pair_ftab) && !ring_selected())
-        return fail(3, "pair styles dpd/mini/meso, dpd/polyforce/meso and dpd/tableforce/meso run on the default force kernel only (layout=2, pair_kernel=2)");
+        return fail(3, "pair styles dpd/mini/meso, dpd/polyforce/meso and dpd/tableforce/meso run on the default force kernel only (pair_kernel=2)");
     TRY(init_params());
     TRY(reneighbor());
     nbuild = 0;
@@ -1521,7 +1452,7 @@ int Engine::run(int nsteps)
             int rr = reneighbor();
             permute_forces = true;
             if (rr) return rr;
-            merged = layout >= 1; ghosts_fresh = merged;    // the rebuild merged with this step's seed
+            merged = true; ghosts_fresh = true;    // the rebuild merged with this step's seed
         }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
@@ -1540,7 +1471,7 @@ int Engine::run(int nsteps)
         p.dt_inv_sqrt = 1.0 / std::sqrt(dt);
         p.accumulate = fuse_clear ? 0 : 1;
         p.debug = pair_debug;
-        p.chunked = layout == 2 ? 1 : 0;
+        p.chunked = 1;
         if (!fuse_clear) TRY(force_clear(0));
         // step boundary in the force kernel's epilogue: final(s) + initial(s+1) + merge(s+1) of the atoms a launch owns;
         // the merged arrays of step s+1 go to the second buffer (this step's are still being gathered from)
@@ -1566,13 +1497,7 @@ int Engine::run(int nsteps)
             p.beg = split ? (part == 0 ? 0 : n_split) : 0;
             p.end = split ? (part == 0 ? n_split : nlocal) : nlocal;
             if (split && part == 1 && !ghosts_fresh) TRY(halo_wait());
-            if (layout == 1 && pair_kernel == 1 && pair_style == 1) {
-                p.nall = nlocal + nghost;
-                tbegin("pair");
-                launch_brick_pair(bargs, p, table16, stream);
-                tend("pair");
-            } else {
-                TRY(ensure_table32());
+            {
                 tbegin("pair");
                 launch_pair(p, 0);
                 tend("pair");
@@ -1746,9 +1671,7 @@ int Engine::neigh_download(int *count, int *table, int stride)
     for (int i = 0; i < nlocal; i++) {
         int n = std::min(count[i], stride);
         for (int p = 0; p < n; p++)
-            table[(size_t)i * stride + p] =
-                layout == 2 ? h[((((size_t)(i >> 6)) * (n_col >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)]
-                            : h[(((size_t)(i >> 6)) * n_col + p) * 64 + (i & 63)];
+            table[(size_t)i * stride + p] = h[((((size_t)(i >> 6)) * (n_col >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)];
     }
     return 0;
 }

@@ -64,7 +64,6 @@ void launch_reorder_place(const uint32_t *key, const int *rank, const int *estar
                           int *placed, int *val_sorted, uint32_t *key_sorted, int *cnt, hipStream_t s);
 void launch_ghost_order(const uint32_t *code, const int *rank, const int *gstart, int M, int nghost, int cap, int *placed,
                         int *slotval, uint32_t *code_sorted, int *gslot, int *cnt, const int *nghost_dev /*nullable*/, hipStream_t s);
-void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s);
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s);
 // ... and the merged float4 pair of the new order in the same pass (k_merge_xvt folded in)
 void launch_permute_merge(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, float4 *coord4,
@@ -99,20 +98,7 @@ void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const
                          uint32_t seed, float4 *dcoord, float4 *dveloc, const int *dest_slot /*nullable*/,
                          hipStream_t s);
 
-// ---- cell binning (neighbor_meso.cu:386-475) ----------------------------------------------------------
-void launch_assign_bin(const AtomSoA &a, const BinGeom &g, int nlocal, int nall, uint32_t *bin_id, int *atom_id,
-                       hipStream_t s);
-void launch_bin_bounds(const uint32_t *sorted_bin, int nall, int nbin, int *bin_start /*[nbin+1]*/,
-                       hipStream_t s);
 
-// ---- neighbour table (neigh_build_meso.cu:20-240) -----------------------------------------------------
-// Table layout (wave64): entry p of atom i at table[((i>>6)*n_col + p)*64 + (i&63)].
-void launch_neigh_build_simple(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
-                               const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col,
-                               int *count, int *table, int *overflow, hipStream_t s);
-void launch_neigh_build_wave(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
-                             const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col,
-                             int *count, int *table, int *overflow, hipStream_t s);
 
 // ---- pair force (pair_dpd_meso.cu:91-205, pair_dpd_fast_meso.cu:91-205) -------------------------------
 struct NveArgs {
@@ -158,10 +144,6 @@ struct PairArgs {
     NveArgs nve;
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
-// lane-per-atom with 8-deep memory-level parallelism (forces only)
-void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s);
-// the same with a ballot-compacted heavy phase (per-wave LDS ring)
-void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s);
 // fp32 style on chunked-8 rows: light cutoff scan per lane, hits compacted into a per-wave LDS ring of 4-byte
 // records, heavy phase on full waves with the partner data re-gathered through buffer loads (pair_ring.hip)
 int pair_ring_group();   // atoms per workgroup of the ring kernel (alignment of paired launches)
@@ -172,8 +154,6 @@ struct ExclArgs;
 void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key_shift, const int4 *binrange, int M,
                        const int *mbin, float rc2, int nlocal, int n_col, int *count, int *table, int *overflow,
                        const ExclArgs *excl, hipStream_t s);
-// wave-per-tile, ballot-compacted variant (forces only)
-void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s);
 
 // ---- bricks (brick.hip): Morton-aligned 4x4x4-bin bricks with a per-rebuild plan of their 6x6x6-bin neighbourhoods; used by
 // the tile list builder of the cell-ordered layout and by the brick layout (LDS-staged force kernel, 16-bit rows) ---------
@@ -213,18 +193,10 @@ struct ExclArgs;
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
                        const ExclArgs *excl, int dbg, hipStream_t s);
 int tile_build_rowcap();
-void launch_brick_flags(const int *estart, int M, int *flag, hipStream_t s);
-void launch_brick_compact(const int *flag, const int *pos, int M, int *active, int *nactive, hipStream_t s);
 void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s);
 void launch_code_starts_u32(const uint32_t *sorted_key, int n, int ncodes, int *start, hipStream_t s);
 void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *key, int *val,
                          hipStream_t s);
-void launch_brick_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count,
-                        unsigned short *table16, int *overflow, hipStream_t s);
-void launch_brick_convert(const BrickArgs &g, int n_col, const int *count, const unsigned short *table16,
-                          int *table32, hipStream_t s);
-// dpd/fast/meso only (the fp64 style runs on the converted global-index rows)
-void launch_brick_pair(const BrickArgs &g, const PairArgs &p, const unsigned short *table16, hipStream_t s);
 
 // ---- bonded topology (bond.hip) -----------------------------------------------------------------------
 void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, int *tagc, hipStream_t s);

@@ -525,21 +525,6 @@ void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_
                        n);
 }
 
-// first sorted position whose key carries the border bit == n_bulk
-__global__ void __launch_bounds__(256) k_count_border(const u32 *__restrict__ key, int n, int border_bit,
-                                                      int *__restrict__ n_bulk)
-{
-    int i = blockDim.x * blockIdx.x + threadIdx.x;
-    if (i > n) return;
-    bool cur = (i == n) ? true : ((key[i] >> border_bit) & 1u) != 0;
-    bool prev = (i == 0) ? false : ((key[i - 1] >> border_bit) & 1u) != 0;
-    if (cur && !prev) *n_bulk = i;
-}
-void launch_count_border(const uint32_t *sorted_key, int n, int border_bit, int *n_bulk_out, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_count_border, dim3(nblk(n + 1, 256)), dim3(256), 0, s, sorted_key, n, border_bit, n_bulk_out);
-}
-
 // gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
 // mg.coord4 != null: the merged float4 pair of the atom's new place is written as well (gpu_merge_xvt folded into the gather:
 // the reorder has x, v, tag and type in registers anyway; 17 us of re-reading them at 64^3)
@@ -967,211 +952,6 @@ void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const
 }
 
 // =========================================================================================
-// cell binning
-// =========================================================================================
-// gpu_assign_bin_id (neighbor_meso.cu:386-421)
-__global__ void __launch_bounds__(256) k_assign_bin(const double *__restrict__ x, const double *__restrict__ y,
-                                                    const double *__restrict__ z, BinGeom g, int nlocal, int nall,
-                                                    u32 *__restrict__ bin_id, int *__restrict__ atom_id)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nall) return;
-    const double c[3] = {x[i], y[i], z[i]};
-    int b[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        b[d] = clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1.0), 0, g.mbin[d]);
-        if (i >= nlocal) b[d] = (c[d] >= g.lo[d]) ? (c[d] <= g.hi[d] ? b[d] : g.mbin[d] - 1) : 0;
-    }
-    atom_id[i] = i;
-    bin_id[i] = b[0] + g.mbin[0] * (b[1] + b[2] * g.mbin[1]);
-}
-void launch_assign_bin(const AtomSoA &a, const BinGeom &g, int nlocal, int nall, uint32_t *bin_id, int *atom_id,
-                       hipStream_t s)
-{
-    if (nall > 0)
-        hipLaunchKernelGGL(k_assign_bin, dim3(nblk(nall, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], g, nlocal, nall,
-                           bin_id, atom_id);
-}
-
-// gpu_find_bin_boundary (neighbor_meso.cu:423-460): bin_start[b] = first sorted slot with bin >= b
-__global__ void __launch_bounds__(256) k_bin_bounds(const u32 *__restrict__ sorted_bin, int nall, int nbin,
-                                                    int *__restrict__ bin_start)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > nall) return;
-    int prev = (i == 0) ? -1 : (int)sorted_bin[i - 1];
-    int cur = (i == nall) ? nbin : (int)sorted_bin[i];
-    for (int b = prev + 1; b <= cur; b++) bin_start[b] = i;
-}
-void launch_bin_bounds(const uint32_t *sorted_bin, int nall, int nbin, int *bin_start, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_bin_bounds, dim3(nblk(nall + 1, 256)), dim3(256), 0, s, sorted_bin, nall, nbin, bin_start);
-}
-
-// =========================================================================================
-// neighbour table
-// =========================================================================================
-__device__ inline float dist2(float4 a, float4 b)
-{
-    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    return dx * dx + dy * dy + dz * dz;
-}
-
-// v1: one lane per centre atom, 27-bin walk (reference: gpu_build_neighbor_list, neigh_build_meso.cu:20-119;
-// same membership test, fp32 distance, j != i, dr2 <= rc2_tail)
-__global__ void __launch_bounds__(256) k_neigh_simple(const float4 *__restrict__ coord4,
-                                                      const u32 *__restrict__ bin_of_atom,
-                                                      const int *__restrict__ bin_start,
-                                                      const int *__restrict__ sorted_atom, BinGeom g, float rc2,
-                                                      int nlocal, int n_col, int *__restrict__ count,
-                                                      int *__restrict__ table, int *__restrict__ overflow)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nlocal) return;
-    float4 ci = coord4[i];
-    int b = (int)bin_of_atom[i];
-    int bx = b % g.mbin[0], by = (b / g.mbin[0]) % g.mbin[1], bz = b / (g.mbin[0] * g.mbin[1]);
-    int *col = table + ((size_t)(i >> 6) * n_col) * 64 + (i & 63);
-    int n = 0;
-    for (int dz = -1; dz <= 1; dz++) {
-        int z2 = bz + dz;
-        if (z2 < 0 || z2 >= g.mbin[2]) continue;
-        for (int dy = -1; dy <= 1; dy++) {
-            int y2 = by + dy;
-            if (y2 < 0 || y2 >= g.mbin[1]) continue;
-            int x0 = bx - 1 < 0 ? 0 : bx - 1, x1 = bx + 1 >= g.mbin[0] ? g.mbin[0] - 1 : bx + 1;
-            int row = g.mbin[0] * (y2 + z2 * g.mbin[1]);
-            int pb = bin_start[row + x0], pe = bin_start[row + x1 + 1];   // 3 x-adjacent bins are contiguous
-            for (int p = pb; p < pe; p++) {
-                int j = sorted_atom[p];
-                float d2 = dist2(ci, coord4[j]);
-                if (j != i && d2 <= rc2) {
-                    if (n < n_col) col[(size_t)n * 64] = j;
-                    n++;
-                }
-            }
-        }
-    }
-    if (n > n_col) { atomicMax(overflow, n); n = n_col; }
-    count[i] = n;
-}
-
-void launch_neigh_build_simple(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
-                               const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col, int *count,
-                               int *table, int *overflow, hipStream_t s)
-{
-    if (nlocal > 0)
-        hipLaunchKernelGGL(k_neigh_simple, dim3(nblk(nlocal, 256)), dim3(256), 0, s, coord4, bin_of_atom, bin_start,
-                           sorted_atom, g, rc2, nlocal, n_col, count, table, overflow);
-}
-
-// v2: one wave per 64-atom tile of centres; candidates on lanes, centres looped; ballot + popcount give
-// every hit its slot (no global atomics); rows are staged in LDS and written out as whole 256-byte
-// lines of the transposed table.  Centres of one tile are consecutive in the cell-sorted order, so the
-// candidate ranges of neighbouring centres overlap and stay in L1/L2.
-#define NB_LDS_ROWS 64        // slots staged per centre; longer rows spill straight to global
-__global__ void __launch_bounds__(64) k_neigh_wave(const float4 *__restrict__ coord4,
-                                                   const u32 *__restrict__ bin_of_atom,
-                                                   const int *__restrict__ bin_start,
-                                                   const int *__restrict__ sorted_atom, BinGeom g, float rc2,
-                                                   int nlocal, int n_col, int *__restrict__ count,
-                                                   int *__restrict__ table, int *__restrict__ overflow)
-{
-    __shared__ int rows[NB_LDS_ROWS][65];   // [slot][centre], +1 pad: conflict-free both ways
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int base = tile * 64;
-    const int ncen = min(64, nlocal - base);
-    const u64 lt = (1ULL << lane) - 1ULL;
-    int *tcol = table + ((size_t)tile * n_col) * 64;
-
-    // lane c keeps centre c's data; broadcast to the wave with readlane as centres are visited
-    float4 cme = make_float4(0.f, 0.f, 0.f, 0.f);
-    int bme = 0;
-    if (lane < ncen) { cme = coord4[base + lane]; bme = (int)bin_of_atom[base + lane]; }
-    int my_n = 0;   // lane c: row length of centre c
-
-    int c = 0;
-    while (c < ncen) {
-        // group of consecutive centres sharing one bin (cell-sorted order makes groups long)
-        int b = __shfl(bme, c, 64);
-        u64 same = __ballot(lane >= c && lane < ncen && bme == b);
-        // centres c..ce-1 share the bin: length of the run of ones starting at bit c
-        u64 run = ~(same >> c);
-        int glen = run ? __ffsll((long long)run) - 1 : 64 - c;
-        int ce = c + glen;
-        int bx = b % g.mbin[0], by = (b / g.mbin[0]) % g.mbin[1], bz = b / (g.mbin[0] * g.mbin[1]);
-        // the 27-bin stencil is 9 contiguous runs of the cell-sorted array (3 x-adjacent bins each);
-        // concatenate them into one virtual candidate range so every 64-lane batch is full
-        int rs[9], rl[9], total = 0;
-        int x0 = bx - 1 < 0 ? 0 : bx - 1, x1 = bx + 1 >= g.mbin[0] ? g.mbin[0] - 1 : bx + 1;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            int z2 = bz + k / 3 - 1, y2 = by + k % 3 - 1;
-            bool ok = z2 >= 0 && z2 < g.mbin[2] && y2 >= 0 && y2 < g.mbin[1];
-            int row = ok ? g.mbin[0] * (y2 + z2 * g.mbin[1]) : 0;
-            int pb = bin_start[row + x0], pe = bin_start[row + x1 + 1];
-            rs[k] = pb;
-            rl[k] = ok ? pe - pb : 0;
-            total += rl[k];
-        }
-        for (int v0 = 0; v0 < total; v0 += 64) {
-            int off = v0 + lane, p = -1;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                if (p < 0) {
-                    if (off < rl[k]) p = rs[k] + off;
-                    else off -= rl[k];
-                }
-            }
-            int j = -1;
-            float4 cj = make_float4(1e30f, 1e30f, 1e30f, 0.f);
-            if (p >= 0) { j = sorted_atom[p]; cj = coord4[j]; }
-            for (int q = c; q < ce; q++) {
-                float4 cq;
-                cq.x = __shfl(cme.x, q, 64);
-                cq.y = __shfl(cme.y, q, 64);
-                cq.z = __shfl(cme.z, q, 64);
-                float d2 = dist2(cq, cj);
-                bool hit = (j >= 0) && (j != base + q) && (d2 <= rc2);
-                u64 m = __ballot(hit);
-                if (m == 0) continue;
-                int nq = __shfl(my_n, q, 64);
-                int slot = nq + __popcll(m & lt);
-                if (hit) {
-                    if (slot < NB_LDS_ROWS) rows[slot][q] = j;
-                    else if (slot < n_col) tcol[(size_t)slot * 64 + q] = j;
-                }
-                if (lane == q) my_n = nq + __popcll(m);
-            }
-        }
-        c = ce;
-    }
-    // overflow check + counts
-    int nfin = my_n;
-    if (nfin > n_col) { atomicMax(overflow, nfin); nfin = n_col; }
-    if (lane < ncen) count[base + lane] = nfin;
-    // write staged rows: slot-major, one coalesced 256-B line per slot
-    int nmax = nfin;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-    int lim = nmax < NB_LDS_ROWS ? nmax : NB_LDS_ROWS;
-    __syncthreads();
-    for (int sidx = 0; sidx < lim; sidx++)
-        if (sidx < nfin) tcol[(size_t)sidx * 64 + lane] = rows[sidx][lane];
-}
-
-void launch_neigh_build_wave(const float4 *coord4, const uint32_t *bin_of_atom, const int *bin_start,
-                              const int *sorted_atom, const BinGeom &g, float rc2, int nlocal, int n_col, int *count,
-                              int *table, int *overflow, hipStream_t s)
-{
-    if (nlocal > 0)
-        hipLaunchKernelGGL(k_neigh_wave, dim3(nblk(nlocal, 64)), dim3(64), 0, s, coord4, bin_of_atom, bin_start,
-                           sorted_atom, g, rc2, nlocal, n_col, count, table, overflow);
-}
-
-// =========================================================================================
 // pair force, v1: one lane per i-particle over the transposed table
 // =========================================================================================
 template <bool FAST, bool EV>
@@ -1301,6 +1081,11 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
 // Morton(bin) behind them, so the atoms of any bin are at most three contiguous runs of the merged arrays
 // (bulk, border, ghost) and a candidate's global index IS its position: no per-candidate indirection, and the
 // 27-bin walk of a lane reads contiguous float4 runs that its wave-mates (same or adjacent bins) share in L1.
+__device__ inline float dist2(float4 a, float4 b)
+{
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return dx * dx + dy * dy + dz * dz;
+}
 __device__ inline u32 compact3b(u32 x)
 {
     x &= 0x09249249;
@@ -1439,503 +1224,6 @@ void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key
     if (excl) ex = *excl;
     hipLaunchKernelGGL(k_cell_build, dim3(g), dim3(256), 0, s, coord4, sorted_key, key_shift, binrange, M, mbin[0], mbin[1],
                        mbin[2], rc2, nlocal, n_col, count, table, overflow, ex);
-}
-
-// pair force v3: lane per atom like v1, but the row is consumed 8 entries at a time -- 8 index loads, then 8
-// coordinate gathers, then the velocity gathers of the hits are all in flight together, so a wave keeps ~8
-// L2 requests per lane outstanding instead of one (v1 measured 86 % of wave cycles waiting on memory).
-template <bool FAST, int PAIR3_CH, int OCC, bool NT1>
-__global__ void __launch_bounds__(256, OCC) k_pair_dpd_mlp(PairArgs a)
-{
-    extern __shared__ double smem[];
-    double *cf64 = smem;
-    float *cf32 = (float *)smem;
-    const int ncf = a.ntypes * a.ntypes * N_COEFF;
-    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
-        if (FAST) cf32[p] = a.coeff32[p];
-        else cf64[p] = a.coeff64[p];
-    }
-    __syncthreads();
-    const int nbk = gridDim.x;
-    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
-    const int i = a.beg + blk * blockDim.x + threadIdx.x;
-    if (i >= a.end) return;
-    const float4 c1 = a.coord4[i];
-    const float4 v1 = a.veloc4[i];
-    const u32 t1 = __float_as_uint(c1.w), s1 = __float_as_uint(v1.w);
-    const int n = a.count[i];
-    const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
-    const int4 *rows = (const int4 *)a.table;
-    const float dtis32 = (float)a.dt_inv_sqrt;
-    float fx32 = 0.f, fy32 = 0.f, fz32 = 0.f;
-    double fx = 0., fy = 0., fz = 0.;
-
-    for (int p0 = 0; p0 < n; p0 += PAIR3_CH) {
-        int j[PAIR3_CH];
-        float4 c2[PAIR3_CH], v2[PAIR3_CH];
-        bool hit[PAIR3_CH];
-        if (a.chunked) {
-            // chunked-8 rows: PAIR3_CH entries = PAIR3_CH/4 aligned 16-byte loads (tail slots hold i itself)
-            if constexpr (PAIR3_CH >= 4) {
-#pragma unroll
-                for (int q4 = 0; q4 < PAIR3_CH / 4; q4++) {
-                    int4 w = rows[2 * row_word8(i, p0 >> 3, a.n_col) + ((p0 & 7) >> 2) + q4];
-                    j[4 * q4] = w.x; j[4 * q4 + 1] = w.y; j[4 * q4 + 2] = w.z; j[4 * q4 + 3] = w.w;
-                }
-            } else {
-                int2 w = ((const int2 *)a.table)[4 * row_word8(i, p0 >> 3, a.n_col) + ((p0 & 7) >> 1)];
-                j[0] = w.x; j[1] = w.y;
-            }
-#pragma unroll
-            for (int q = 0; q < PAIR3_CH; q++) j[q] = (p0 + q < n) ? j[q] : i;
-        } else {
-#pragma unroll
-            for (int q = 0; q < PAIR3_CH; q++) j[q] = (p0 + q < n) ? col[(size_t)(p0 + q) * 64] : i;   // self: rsq = 0, rejected
-        }
-#pragma unroll
-        for (int q = 0; q < PAIR3_CH; q++) c2[q] = a.coord4[j[q]];
-#pragma unroll
-        for (int q = 0; q < PAIR3_CH; q++) {
-            const int cidx = t1 * a.ntypes + __float_as_uint(c2[q].w);
-            if (FAST) {
-                float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
-                float rsq = dx * dx + dy * dy + dz * dz;
-                hit[q] = rsq < (NT1 ? (float)a.cf1[P_CUTSQ] : cf32[cidx * N_COEFF + P_CUTSQ]) && rsq >= (float)MESO_EPSILON_SQ;
-            } else {
-                double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
-                double rsq = dx * dx + dy * dy + dz * dz;
-                hit[q] = rsq < (NT1 ? a.cf1[P_CUTSQ] : cf64[cidx * N_COEFF + P_CUTSQ]) && rsq >= MESO_EPSILON_SQ;
-            }
-            v2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hit[q]) v2[q] = a.veloc4[j[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < PAIR3_CH; q++) {
-            if (!hit[q]) continue;
-            const int cidx = t1 * a.ntypes + __float_as_uint(c2[q].w);
-            const u32 s2 = __float_as_uint(v2[q].w);
-            if (FAST) {
-                const float *cfp = cf32 + cidx * N_COEFF;
-                const float c_cutinv = NT1 ? (float)a.cf1[P_CUTINV] : cfp[P_CUTINV], c_ew = NT1 ? (float)a.cf1[P_EXPW] : cfp[P_EXPW];
-                const float c_a0 = NT1 ? (float)a.cf1[P_A0] : cfp[P_A0], c_gamma = NT1 ? (float)a.cf1[P_GAMMA] : cfp[P_GAMMA];
-                const float c_sigma = NT1 ? (float)a.cf1[P_SIGMA] : cfp[P_SIGMA];
-                float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
-                float rsq = dx * dx + dy * dy + dz * dz;
-                float rn = gaussian_tea_fast(s1, s2);
-                float rinv = __builtin_amdgcn_rsqf(rsq);
-                float r = rsq * rinv;
-                float dvx = v1.x - v2[q].x, dvy = v1.y - v2[q].y, dvz = v1.z - v2[q].z;
-                float dot = dx * dvx + dy * dvy + dz * dvz;
-                float wc = 1.0f - r * c_cutinv;
-                float wr = wc;
-                if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
-                float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis32);
-                fpair *= rinv;
-                fx32 += dx * fpair; fy32 += dy * fpair; fz32 += dz * fpair;
-            } else {
-                const double *cfp = cf64 + cidx * N_COEFF;
-                const double c_cutinv = NT1 ? a.cf1[P_CUTINV] : cfp[P_CUTINV], c_ew = NT1 ? a.cf1[P_EXPW] : cfp[P_EXPW];
-                const double c_a0 = NT1 ? a.cf1[P_A0] : cfp[P_A0], c_gamma = NT1 ? a.cf1[P_GAMMA] : cfp[P_GAMMA];
-                const double c_sigma = NT1 ? a.cf1[P_SIGMA] : cfp[P_SIGMA];
-                double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
-                double rsq = dx * dx + dy * dy + dz * dz;
-                double rn = gaussian_tea(s1, s2);
-                double rinv = rsqrt(rsq);
-                double r = rsq * rinv;
-                double dvx = (double)v1.x - (double)v2[q].x, dvy = (double)v1.y - (double)v2[q].y, dvz = (double)v1.z - (double)v2[q].z;
-                double dot = dx * dvx + dy * dvy + dz * dvz;
-                double wc = 1.0 - r * c_cutinv;
-                double wr = wc;
-                if (c_ew != 1.0) wr = powd_poly(wc, c_ew);
-                double fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * a.dt_inv_sqrt);
-                fpair *= rinv;
-                fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
-            }
-            // keep the (long) per-pair arithmetic of different slots from being interleaved: the gathers above
-            // already provide the memory-level parallelism, interleaving only costs registers (occupancy)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (FAST) { fx = fx32; fy = fy32; fz = fz32; }
-    if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
-    else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
-}
-
-// pair force v4 = v3's memory-level parallelism + a ballot-compacted heavy phase.  Phase A (per lane, 8 row entries
-// at a time): row words, coordinate gathers, cutoff tests, velocity gathers of the hits.  Hits are appended to a
-// per-wave LDS ring with ballot + popcount; whenever 64 are queued the wave evaluates them with every lane busy
-// (TEA, Gaussian, weights cost ~100 VALU instructions per pair; only ~47 % of list entries are inside r_c, so
-// the lane-per-atom form runs that code at < 50 % lane efficiency).  Per-atom sums are wave-scope LDS adds in a
-// fixed order: results are reproducible run to run, and there are no global atomics.
-#define P4_WAVES 4
-#define P4_RING 128
-template <bool FAST, int CH, bool ACC64>
-__global__ void __launch_bounds__(64 * P4_WAVES, FAST ? 4 : 2) k_pair_dpd_mlpc(PairArgs a)
-{
-    typedef typename std::conditional<ACC64, double, float>::type acc_t;
-    extern __shared__ double smem[];
-    const int ncf = a.ntypes * a.ntypes * N_COEFF;
-    double *cf64 = smem;
-    float *cf32 = (float *)smem;
-    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
-        if (FAST) cf32[p] = a.coeff32[p];
-        else cf64[p] = a.coeff64[p];
-    }
-    const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t per_wave = 64 * 16 * 2 + P4_RING * 16 * 2 + P4_RING * 4 + 64 * 3 * sizeof(acc_t);
-    char *wb = (char *)smem + off + (size_t)w * per_wave;
-    float4 *own_c = (float4 *)wb;
-    float4 *own_v = own_c + 64;
-    float4 *ring_c = own_v + 64;
-    float4 *ring_v = ring_c + P4_RING;
-    int *ring_id = (int *)(ring_v + P4_RING);
-    acc_t *facc = (acc_t *)(ring_id + P4_RING);
-    __syncthreads();
-
-    const int nbk = gridDim.x;
-    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
-    const int i = a.beg + blk * blockDim.x + threadIdx.x;
-    const bool mine = i < a.end;
-    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
-    int n = 0;
-    if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
-    own_c[lane] = c1;
-    own_v[lane] = v1;
-    facc[lane] = 0; facc[64 + lane] = 0; facc[128 + lane] = 0;
-    const u32 t1 = __float_as_uint(c1.w);
-    const int4 *rows = (const int4 *)a.table;
-    const u64 lt = (1ULL << lane) - 1ULL;
-    const float dtis32 = (float)a.dt_inv_sqrt;
-    int nmax = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-    int qhead = 0, qtail = 0;
-
-    auto drain = [&](int nb) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < nb) {
-            const int slot = (qhead + lane) & (P4_RING - 1);
-            const float4 cj = ring_c[slot], vj = ring_v[slot];
-            const int ai = ring_id[slot];
-            const float4 ci = own_c[ai], vi = own_v[ai];
-            const u32 si = __float_as_uint(vi.w), sj = __float_as_uint(vj.w);
-            const int cidx = __float_as_uint(ci.w) * a.ntypes + __float_as_uint(cj.w);
-            if (FAST) {
-                const float *cf = cf32 + cidx * N_COEFF;
-                const float c_cutinv = cf[P_CUTINV], c_ew = cf[P_EXPW], c_a0 = cf[P_A0], c_gamma = cf[P_GAMMA], c_sigma = cf[P_SIGMA];
-                float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
-                float rsq = dx * dx + dy * dy + dz * dz;
-                float rn = gaussian_tea_fast(si, sj);
-                float rinv = __builtin_amdgcn_rsqf(rsq);
-                float r = rsq * rinv;
-                float dvx = vi.x - vj.x, dvy = vi.y - vj.y, dvz = vi.z - vj.z;
-                float dot = dx * dvx + dy * dvy + dz * dvz;
-                float wc = 1.0f - r * c_cutinv;
-                float wr = wc;
-                if (c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
-                float fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis32);
-                fpair *= rinv;
-                __hip_atomic_fetch_add(&facc[ai], (acc_t)(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&facc[64 + ai], (acc_t)(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&facc[128 + ai], (acc_t)(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            } else {
-                const double *cf = cf64 + cidx * N_COEFF;
-                const double c_cutinv = cf[P_CUTINV], c_ew = cf[P_EXPW], c_a0 = cf[P_A0], c_gamma = cf[P_GAMMA], c_sigma = cf[P_SIGMA];
-                double dx = (double)ci.x - (double)cj.x, dy = (double)ci.y - (double)cj.y, dz = (double)ci.z - (double)cj.z;
-                double rsq = dx * dx + dy * dy + dz * dz;
-                double rn = gaussian_tea(si, sj);
-                double rinv = rsqrt(rsq);
-                double r = rsq * rinv;
-                double dvx = (double)vi.x - (double)vj.x, dvy = (double)vi.y - (double)vj.y, dvz = (double)vi.z - (double)vj.z;
-                double dot = dx * dvx + dy * dvy + dz * dvz;
-                double wc = 1.0 - r * c_cutinv;
-                double wr = wc;
-                if (c_ew != 1.0) wr = powd_poly(wc, c_ew);
-                double fpair = c_a0 * wc - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * a.dt_inv_sqrt);
-                fpair *= rinv;
-                __hip_atomic_fetch_add(&facc[ai], (acc_t)(dx * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&facc[64 + ai], (acc_t)(dy * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&facc[128 + ai], (acc_t)(dz * fpair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-        qhead += nb;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-
-    for (int p0 = 0; p0 < nmax; p0 += CH) {
-        int j[CH];
-        float4 c2[CH], v2[CH];
-        bool hit[CH];
-        if (a.chunked) {
-#pragma unroll
-            for (int q4 = 0; q4 < CH / 4; q4++) {
-                int4 wv = make_int4(i, i, i, i);
-                if (p0 + 4 * q4 < n) wv = rows[2 * row_word8(i, p0 >> 3, a.n_col) + ((p0 & 7) >> 2) + q4];
-                j[4 * q4] = wv.x; j[4 * q4 + 1] = wv.y; j[4 * q4 + 2] = wv.z; j[4 * q4 + 3] = wv.w;
-            }
-#pragma unroll
-            for (int q = 0; q < CH; q++) j[q] = (p0 + q < n) ? j[q] : i;
-        } else {
-            const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
-#pragma unroll
-            for (int q = 0; q < CH; q++) j[q] = (p0 + q < n) ? col[(size_t)(p0 + q) * 64] : i;
-        }
-        if (!mine) {
-#pragma unroll
-            for (int q = 0; q < CH; q++) j[q] = a.beg;   // a valid index; never a hit (n == 0)
-        }
-#pragma unroll
-        for (int q = 0; q < CH; q++) c2[q] = a.coord4[j[q]];
-#pragma unroll
-        for (int q = 0; q < CH; q++) {
-            const int cidx = t1 * a.ntypes + __float_as_uint(c2[q].w);
-            if (FAST) {
-                float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
-                float rsq = dx * dx + dy * dy + dz * dz;
-                hit[q] = p0 + q < n && rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
-            } else {
-                double dx = (double)c1.x - (double)c2[q].x, dy = (double)c1.y - (double)c2[q].y, dz = (double)c1.z - (double)c2[q].z;
-                double rsq = dx * dx + dy * dy + dz * dz;
-                hit[q] = p0 + q < n && rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
-            }
-            v2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hit[q]) v2[q] = a.veloc4[j[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < CH; q++) {
-            const u64 m = __ballot(hit[q]);
-            if (m) {
-                if (hit[q]) {
-                    const int slot = (qtail + __popcll(m & lt)) & (P4_RING - 1);
-                    ring_c[slot] = c2[q];
-                    ring_v[slot] = v2[q];
-                    ring_id[slot] = lane;
-                }
-                qtail += __popcll(m);
-                if (qtail - qhead >= 64) drain(64);
-            }
-        }
-    }
-    if (qtail > qhead) drain(qtail - qhead);
-
-    if (mine) {
-        double fx = (double)facc[lane], fy = (double)facc[64 + lane], fz = (double)facc[128 + lane];
-        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
-        else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
-    }
-}
-
-void launch_pair_dpd_mlpc(const PairArgs &p, int fast, hipStream_t s)
-{
-    int n = p.end - p.beg;
-    if (n <= 0) return;
-    size_t ncf = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? 4 : 8);
-    // accumulators are fp64 in both styles: ds_add_f32 is ~2x slower than ds_add_f64 on gfx950 (332 vs 156 us)
-    size_t per_wave = 64 * 16 * 2 + P4_RING * 16 * 2 + P4_RING * 4 + 64 * 3 * 8;
-    size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * P4_WAVES;
-    dim3 grid((nblk(n, 64 * P4_WAVES) + 7) / 8 * 8), block(64 * P4_WAVES);
-    if (fast) hipLaunchKernelGGL((k_pair_dpd_mlpc<true, 8, true>), grid, block, sm, s, p);
-    else hipLaunchKernelGGL((k_pair_dpd_mlpc<false, 4, true>), grid, block, sm, s, p);
-}
-
-void launch_pair_dpd_mlp(const PairArgs &p, int fast, hipStream_t s)
-{
-    int n = p.end - p.beg;
-    if (n <= 0) return;
-    size_t sm = (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? sizeof(float) : sizeof(double));
-    dim3 grid((nblk(n, 256) + 7) / 8 * 8), block(256);
-    // depth x occupancy measured on 64^3 (profiles/r01_notes.md): fp32 8-deep at 4 waves/SIMD (112 VGPRs).  A branch-free
-    // heavy phase (select instead of exec mask, 2-8 slots interleaved) was slower at every depth (162-230 us): it
-    // costs registers/occupancy and the velocity gathers of the misses.
-    const bool nt1 = p.ntypes == 1;
-    if (fast && nt1) hipLaunchKernelGGL((k_pair_dpd_mlp<true, 8, 4, true>), grid, block, sm, s, p);
-    else if (fast) hipLaunchKernelGGL((k_pair_dpd_mlp<true, 8, 4, false>), grid, block, sm, s, p);
-    else if (nt1) hipLaunchKernelGGL((k_pair_dpd_mlp<false, 2, 4, true>), grid, block, sm, s, p);
-    else hipLaunchKernelGGL((k_pair_dpd_mlp<false, 2, 4, false>), grid, block, sm, s, p);
-}
-
-// =========================================================================================
-// pair force, v2: wave-per-tile, ballot-compacted heavy phase
-// =========================================================================================
-// One wave owns a 64-atom tile.  Phase A walks the transposed rows exactly like v1 (coalesced 256-B row
-// reads, one candidate per lane) but only tests the cutoff; hits are compacted with ballot + popcount
-// into a 128-entry LDS ring.  Phase B drains the ring 64 pairs at a time, so the expensive part (TEA,
-// Gaussian, weights) runs with every lane busy instead of the ~45 % in-range fraction of the list.
-// Per-atom sums are kept in LDS and combined with wave-scope ds_add (one wave per tile -> fixed order
-// -> bit-reproducible run to run; no global atomics).
-template <typename T> struct PairAcc;
-template <> struct PairAcc<float> { typedef float type; };
-template <> struct PairAcc<double> { typedef double type; };
-
-#define PAIR2_WAVES 4
-#define PAIR2_RING 128
-
-template <bool FAST>
-__global__ void __launch_bounds__(64 * PAIR2_WAVES) k_pair_dpd_tile(PairArgs a, int ntiles, int tile0)
-{
-    typedef typename PairAcc<typename std::conditional<FAST, float, double>::type>::type acc_t;
-    extern __shared__ double smem[];
-    const int ncf = a.ntypes * a.ntypes * N_COEFF;
-    double *cf64 = smem;
-    float *cf32 = (float *)smem;
-    for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
-        if (FAST) cf32[p] = a.coeff32[p];
-        else cf64[p] = a.coeff64[p];
-    }
-    // per-wave LDS carve (after the coefficient table, 16-B aligned)
-    size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
-    char *base = (char *)smem + off;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t per_wave = 64 * 16 * 2 + PAIR2_RING * 16 + PAIR2_RING * 4 + 64 * 3 * sizeof(acc_t);
-    char *wb = base + (size_t)w * per_wave;
-    float4 *own_c = (float4 *)wb;
-    float4 *own_v = own_c + 64;
-    float4 *ring = own_v + 64;
-    int *ring_a = (int *)(ring + PAIR2_RING);
-    acc_t *facc = (acc_t *)(ring_a + PAIR2_RING);
-    __syncthreads();
-
-    // XCD-aware tile order: blocks b and b+8 share an L2, so hand each XCD a contiguous run of tiles
-    int wid = blockIdx.x * PAIR2_WAVES + w;
-    int nw = gridDim.x * PAIR2_WAVES;
-    int per = nw / 8;
-    int tile = (nw % 8 == 0) ? ((blockIdx.x & 7) * per + (blockIdx.x >> 3) * PAIR2_WAVES + w) : wid;
-    if (tile >= ntiles) return;
-    tile += tile0;
-    const int i = tile * 64 + lane;
-    const bool mine = i >= a.beg && i < a.end;
-    const u64 lt = (1ULL << lane) - 1ULL;
-
-    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
-    int n = 0;
-    if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
-    own_c[lane] = c1;
-    own_v[lane] = v1;
-    facc[lane] = 0; facc[64 + lane] = 0; facc[128 + lane] = 0;
-    const u32 t1 = __float_as_uint(c1.w);
-    const int *col = a.table + ((size_t)tile * a.n_col) * 64 + lane;
-    int nmax = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-    __builtin_amdgcn_wave_barrier();
-
-    int qhead = 0, qtail = 0;
-    const float dtis32 = (float)a.dt_inv_sqrt;
-
-    auto drain = [&](int nb) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < nb) {
-            int slot = (qhead + lane) & (PAIR2_RING - 1);
-            float4 e = ring[slot];
-            int pk = ring_a[slot];
-            int ai = pk & 63, cidx = pk >> 6;
-            int j = __float_as_int(e.w);
-            float4 ci = own_c[ai], vi = own_v[ai];
-            float4 v2 = a.veloc4[j];
-            u32 si = __float_as_uint(vi.w), sj = __float_as_uint(v2.w);
-            if (FAST) {
-                const float *cf = cf32 + cidx * N_COEFF;
-                float dx = ci.x - e.x, dy = ci.y - e.y, dz = ci.z - e.z;
-                float rsq = dx * dx + dy * dy + dz * dz;
-                float rn = gaussian_tea_fast(si, sj);
-                float rinv = __builtin_amdgcn_rsqf(rsq);
-                float r = rsq * rinv;
-                float dvx = vi.x - v2.x, dvy = vi.y - v2.y, dvz = vi.z - v2.z;
-                float dot = dx * dvx + dy * dvy + dz * dvz;
-                float wc = 1.0f - r * cf[P_CUTINV];
-                float ew = cf[P_EXPW];
-                float wr = (ew == 1.0f) ? wc : __powf(wc, ew);
-                float fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * dtis32);
-                fpair *= rinv;
-                __hip_atomic_fetch_add((float *)&facc[ai], dx * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add((float *)&facc[64 + ai], dy * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add((float *)&facc[128 + ai], dz * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            } else {
-                const double *cf = cf64 + cidx * N_COEFF;
-                double dx = (double)ci.x - (double)e.x, dy = (double)ci.y - (double)e.y, dz = (double)ci.z - (double)e.z;
-                double rsq = dx * dx + dy * dy + dz * dz;
-                double rn = gaussian_tea(si, sj);
-                double rinv = rsqrt(rsq);
-                double r = rsq * rinv;
-                double dvx = (double)vi.x - (double)v2.x, dvy = (double)vi.y - (double)v2.y, dvz = (double)vi.z - (double)v2.z;
-                double dot = dx * dvx + dy * dvy + dz * dvz;
-                double wc = 1.0 - r * cf[P_CUTINV];
-                double ew = cf[P_EXPW];
-                double wr = (ew == 1.0) ? wc : powd_poly(wc, ew);
-                double fpair = cf[P_A0] * wc - (cf[P_GAMMA] * wr * wr * dot * rinv) + (cf[P_SIGMA] * wr * rn * a.dt_inv_sqrt);
-                fpair *= rinv;
-                __hip_atomic_fetch_add((double *)&facc[ai], dx * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add((double *)&facc[64 + ai], dy * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add((double *)&facc[128 + ai], dz * fpair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-        qhead += nb;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-
-    for (int p = 0; p < nmax; p++) {
-        bool active = p < n;
-        int j = 0;
-        float4 c2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) { j = col[(size_t)p * 64]; c2 = a.coord4[j]; }
-        int cidx = t1 * a.ntypes + __float_as_uint(c2.w);
-        bool hit;
-        if (FAST) {
-            float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
-            float rsq = dx * dx + dy * dy + dz * dz;
-            hit = active && rsq < cf32[cidx * N_COEFF + P_CUTSQ] && rsq >= (float)MESO_EPSILON_SQ;
-        } else {
-            double dx = (double)c1.x - (double)c2.x, dy = (double)c1.y - (double)c2.y, dz = (double)c1.z - (double)c2.z;
-            double rsq = dx * dx + dy * dy + dz * dz;
-            hit = active && rsq < cf64[cidx * N_COEFF + P_CUTSQ] && rsq >= MESO_EPSILON_SQ;
-        }
-        u64 m = __ballot(hit);
-        if (m) {
-            if (hit) {
-                int slot = (qtail + __popcll(m & lt)) & (PAIR2_RING - 1);
-                ring[slot] = make_float4(c2.x, c2.y, c2.z, __int_as_float(j));
-                ring_a[slot] = lane | (cidx << 6);
-            }
-            qtail += __popcll(m);
-            if (qtail - qhead >= 64) drain(64);
-        }
-    }
-    if (qtail > qhead) drain(qtail - qhead);
-
-    if (mine) {
-        double fx = (double)facc[lane], fy = (double)facc[64 + lane], fz = (double)facc[128 + lane];
-        if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
-        else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
-    }
-}
-
-static size_t pair2_smem(int ntypes, int fast)
-{
-    size_t ncf = (size_t)ntypes * ntypes * N_COEFF * (fast ? 4 : 8);
-    size_t off = (ncf + 15) & ~(size_t)15;
-    size_t per_wave = 64 * 16 * 2 + PAIR2_RING * 16 + PAIR2_RING * 4 + 64 * 3 * (fast ? 4 : 8);
-    return off + per_wave * PAIR2_WAVES;
-}
-
-void launch_pair_dpd_tile(const PairArgs &p, int fast, hipStream_t s)
-{
-    if (p.end <= p.beg) return;
-    int tile0 = p.beg >> 6, tile1 = (p.end + 63) >> 6;
-    int ntiles = tile1 - tile0;
-    int nb = (ntiles + PAIR2_WAVES - 1) / PAIR2_WAVES;
-    nb = (nb + 7) / 8 * 8;   // multiple of 8 so the XCD remap is a bijection onto [0, 8*per)
-    size_t sm = pair2_smem(p.ntypes, fast);
-    if (fast) hipLaunchKernelGGL((k_pair_dpd_tile<true>), dim3(nb), dim3(64 * PAIR2_WAVES), sm, s, p, ntiles, tile0);
-    else hipLaunchKernelGGL((k_pair_dpd_tile<false>), dim3(nb), dim3(64 * PAIR2_WAVES), sm, s, p, ntiles, tile0);
 }
 
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s)

@@ -113,6 +113,10 @@ def test_settings_and_kernel_restrictions():
         with pytest.raises(MesoError):
             m.pair_style("dpd/mini/meso", 1.5, 1)              # fixed cutoff 1
     with Meso() as m:
-        m.set_option("pair_kernel", 4)
+        m.set_option("pair_kernel", 0)
         with pytest.raises(MesoError):
             _mini(m, x, v, lo, hi)                             # default force kernel only
+    with Meso() as m:
+        for key, val in (("pair_kernel", 3), ("layout", 1)):   # kernels and layouts retired in round 2
+            with pytest.raises(MesoError):
+                m.set_option(key, val)

@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 
 # engine code paths: (layout, pair_kernel).  layout 0 = global-index rows gathered through L2, layout 1 = bricks
 # with LDS-staged halos and 16-bit rows; pair_kernel 0 = lane per atom, 1 = ballot-compacted (tile / brick).
-PATHS = {"lane": (("layout", 0), ("pair_kernel", 0)), "tile": (("layout", 0), ("pair_kernel", 1)),
-         "brick": (("layout", 1), ("pair_kernel", 1)), "brick-rows+lane": (("layout", 1), ("pair_kernel", 0)),
-         "cell+mlp": (("layout", 2), ("pair_kernel", 2)), "cell+mlpc": (("layout", 2), ("pair_kernel", 3)),
-         "bins+mlpc": (("layout", 0), ("pair_kernel", 3)), "cell+ring": (("layout", 2), ("pair_kernel", 5))}
+# the two force kernels (ring; lane per atom = the one that also books energy/virial) x the two list builders (wave-per-bin
+# tile builder; lane-per-atom cell builder), ring with and without Newton pairing / two lanes per atom
+PATHS = {"ring": (("pair_kernel", 2),), "lane": (("pair_kernel", 0),), "ring+cell-builder": (("pair_kernel", 2), ("neigh_kernel", 0)),
+         "lane+cell-builder": (("pair_kernel", 0), ("neigh_kernel", 0)), "ring-unpaired": (("pair_share", 0),),
+         "ring-1-lane": (("pair_npart", 1),), "ring-4-lanes": (("pair_npart", 4),), "ring-unfused": (("fuse_pair", 0),)}
 
 
 @pytest.fixture(scope="module")
@@ -85,10 +86,10 @@ def test_gaussian_tea(Meso, oracle):
     assert np.abs(dp).max() <= 4.0 and abs(dp.mean()) < 0.03 and abs(dp.var() - 1) < 0.03
 
 
-@pytest.mark.parametrize("kernel,layout", [(0, 0), (1, 0), (1, 1), (1, 2)])
-def test_merged_arrays_and_neighbor_sets(Meso, oracle, kernel, layout):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_merged_arrays_and_neighbor_sets(Meso, oracle, kernel):
     L = 7
-    m, _ = _engine(Meso, L, kernel=kernel, opts=(("layout", layout),))
+    m, _ = _engine(Meso, L, kernel=kernel)
     s = _oracle_sim(L)
     nl, ng, nb = m.counts()
     assert nl == s.n and ng == len(s.gsrc)
@@ -160,7 +161,7 @@ def test_sigma0_vs_stock_lammps_cpu(Meso, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("path", ["lane", "tile", "brick", "cell+mlp", "cell+mlpc"])
+@pytest.mark.parametrize("path", ["lane", "ring", "ring+cell-builder", "ring-unfused"])
 @pytest.mark.parametrize("style,every,sigma,steps", [("dpd/meso", 5, 3.0, 12), ("dpd/meso", 1, 3.0, 12),
                                                      ("dpd/fast/meso", 5, 0.0, 12), ("dpd/fast/meso", 5, 3.0, 1)])
 def test_trajectory_vs_meso_oracle(Meso, oracle, style, every, sigma, steps, path):
@@ -190,8 +191,8 @@ def test_kernels_agree_on_a_large_box(Meso, style, tol):
     """32^3 (131 k atoms, 512+ workgroups, XCD remap active): every force kernel against the lane-per-atom one.
     (A register-spilling build of the compacted fp64 kernel was correct at 25^3 and wrong here.)"""
     ref = None
-    for path in ("cell-lane", "cell+mlp", "cell+mlpc", "cell+ring", "brick", "tile"):
-        opts = {"cell-lane": (("layout", 2), ("pair_kernel", 0)), "cell+mlp": (("layout", 2), ("pair_kernel", 4))}.get(path, PATHS.get(path))
+    for path in ("lane", "ring", "ring-unpaired", "ring-1-lane", "ring+cell-builder"):
+        opts = PATHS[path]
         m, _ = _engine(Meso, 32, style=style, opts=opts)
         m.force_clear("local")
         m.compute()
@@ -343,8 +344,7 @@ run             200
 
 def test_builders_agree_on_a_large_box(Meso):
     """32^3 after 40 steps: the wave-per-bin tile builder and the lane-per-atom cell builder produce the same rows
-    (as sets) for every atom of the same state; the brick
-    layout's 16-bit rows convert to the same sets too."""
+    (as sets) for every atom of the same state."""
     m, _ = _engine(Meso, 32, style="dpd/fast/meso", opts=(("neigh_kernel", 0),))
     m.run(40)
     tabs = {}
@@ -361,16 +361,7 @@ def test_builders_agree_on_a_large_box(Meso):
     a = np.sort(np.where(np.arange(t0.shape[1])[None, :] < c0[:, None], t0, -1), axis=1)
     b = np.sort(np.where(np.arange(t1.shape[1])[None, :] < c1[:, None], t1, -1), axis=1)
     assert np.array_equal(a, b)
-    # brick rows (converted to global indices) on the initial configuration, where no trajectory rounding can differ
-    rows = {}
-    for name, opts in (("cell", (("neigh_kernel", 0),)), ("brick", (("layout", 1),))):
-        m, _ = _engine(Meso, 32, style="dpd/fast/meso", opts=opts)
-        count, table = m.neigh_table()
-        tag = m.gather(by_tag=False)[3]
-        c4 = m.merged()[0][:, :3]                            # neighbours (ghosts too) are identified by their coordinates
-        rows[name] = {int(tag[i]): frozenset(map(tuple, c4[table[i, :count[i]]].tolist())) for i in range(0, len(tag), 37)}
-        m.close()
-    assert rows["cell"] == rows["brick"]
+
 
 
 @pytest.mark.parametrize("style", ["dpd/fast/meso", "dpd/meso"])
@@ -395,7 +386,7 @@ def test_full_size_box_invariants(Meso, style):
 
 
 @pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-9), ("dpd/fast/meso", 2e-3)])
-@pytest.mark.parametrize("path", ["default", "lane", "cell+mlp", "cell+mlpc", "brick"])
+@pytest.mark.parametrize("path", ["default", "lane", "ring-unpaired", "ring-1-lane", "ring+cell-builder"])
 def test_general_coefficients_noncubic_box(Meso, oracle, style, tol, path):
     """Two atom types, per-pair cutoffs (1.0 / 0.8 / 0.9), weight exponents s = 1, 0.5 and 2 (the pow() branches), a
     10 x 8 x 12 box: forces of every kernel against the oracle."""
@@ -569,13 +560,13 @@ def test_option_matrix_sigma0_trajectories(Meso, style, tol):
         return out
 
     ref = run({})
-    for layout, pk, nk, fs, fp, sh in itertools.product((0, 1, 2), (0, 1, 2, 3, 4, 5), (0, 1), (0, 1), (0, 1), (0, 1)):
-        if (fp, sh) != (1, 1) and (layout, pk) not in ((2, 2), (2, 5)):
+    for pk, nk, fs, fp, sh, ac in itertools.product((0, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
+        if (fp, sh) != (1, 1) and pk != 2:
             continue                                               # switches that only the ring kernel reads
-        out = run({"layout": layout, "pair_kernel": pk, "neigh_kernel": nk, "fuse_step": fs, "fuse_pair": fp, "pair_share": sh})
+        out = run({"pair_kernel": pk, "neigh_kernel": nk, "fuse_step": fs, "fuse_pair": fp, "pair_share": sh, "async_counts": ac})
         d = out[0] - ref[0]
         d -= np.round(d / prd) * prd
-        assert np.abs(d).max() < tol and np.abs(out[1] - ref[1]).max() < 50 * tol, (layout, pk, nk, fs, fp, sh)
+        assert np.abs(d).max() < tol and np.abs(out[1] - ref[1]).max() < 50 * tol, (pk, nk, fs, fp, sh, ac)
     # lanes per atom of the ring kernel (1, 2, 4; the default picks by launch size), with and without pairing / epilogue
     for npart, fp, sh in itertools.product((1, 2, 4), (0, 1), (0, 1)):
         out = run({"pair_npart": npart, "fuse_pair": fp, "pair_share": sh})
