@@ -275,11 +275,17 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
         // the 9 candidate runs and their prefix
         int rstart[9], pre[10];
         pre[0] = 0;
+        {
+            // lanes 0..8 read the two offsets of "their" run in one LDS round trip; the 18 values then move to SGPRs with
+            // v_readlane (18 dependent LDS reads + readfirstlane before)
+            const int rl = lane < 9 ? lane : 0;
+            const int hrow_l = hb + (rl % 3 - 1) * BRK_H + (rl / 3 - 1) * BRK_H * BRK_H;
+            const int lo_l = hoff[hrow_l - 1], hi_l = hoff[hrow_l + 2];
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-            const int hrow = hb + (r % 3 - 1) * BRK_H + (r / 3 - 1) * BRK_H * BRK_H;
-            rstart[r] = __builtin_amdgcn_readfirstlane(hoff[hrow - 1]);
-            pre[r + 1] = pre[r] + (__builtin_amdgcn_readfirstlane(hoff[hrow + 2]) - rstart[r]);
+            for (int r = 0; r < 9; r++) {
+                rstart[r] = __builtin_amdgcn_readlane(lo_l, r);
+                pre[r + 1] = pre[r] + (__builtin_amdgcn_readlane(hi_l, r) - rstart[r]);
+            }
         }
         const int ncand = pre[9];
         const int nbatch = (ncand + 63) >> 6;
@@ -311,15 +317,20 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             // own atoms of this group: global index and coordinates, wave-uniform (SGPRs)
             int gi[TB_G];
             float ox[TB_G], oy[TB_G], oz[TB_G];
+            {
+                // lanes 0..TB_G-1 read one own atom each (four LDS reads for the whole group), v_readlane moves the values to SGPRs
+                const int tl = own0 + g0 + (lane < ng ? lane : 0);
+                const int gi_l = (int)hgi[tl];
+                const float ox_l = hx[tl], oy_l = hy[tl], oz_l = hz[tl];
 #pragma unroll
-            for (int t = 0; t < TB_G; t++) {
-                gi[t] = 0; ox[t] = oy[t] = oz[t] = 0.f;
-                if (t < ng) {
-                    gi[t] = __builtin_amdgcn_readfirstlane((int)hgi[own0 + g0 + t]);
-                    // one LDS word for the whole wave, then SGPRs
-                    ox[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hx[own0 + g0 + t])));
-                    oy[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hy[own0 + g0 + t])));
-                    oz[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hz[own0 + g0 + t])));
+                for (int t = 0; t < TB_G; t++) {
+                    gi[t] = 0; ox[t] = oy[t] = oz[t] = 0.f;
+                    if (t < ng) {
+                        gi[t] = __builtin_amdgcn_readlane(gi_l, t);
+                        ox[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox_l), t));
+                        oy[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy_l), t));
+                        oz[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oz_l), t));
+                    }
                 }
             }
             int nrow[TB_G];
@@ -350,6 +361,8 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                 }
             };
             auto scan_full = [&](const int cs, const float cx, const float cy, const float cz, const int ctag) {
+                // (two own atoms per packed fp32 instruction - v_pk_add/mul/fma_f32 with the own coordinates as SGPR pairs - was
+                // measured: 307 -> 312 us; the scan is not bound by the number of distance instructions)
 #pragma unroll
                 for (int t = 0; t < TB_G; t++) {
                     {
@@ -361,8 +374,6 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                             const int nsp = ex.nspecial[gi[t]];
                             for (int sp = 0; sp < nsp; sp++) hit = hit & (ex.special[(size_t)gi[t] * ex.msp + sp] != ctag);
                         }
-                        // no "any hit?" branch: a batch of 64 candidates almost always holds one, and straight-line code lets
-                        // the chains of the group's atoms overlap
                         // lane mask straight from the compares (LLVM predicates: 5 = OLE, 33 = NE) unless exclusions apply
                         const u64 m = EXCL ? __builtin_amdgcn_ballot_w64(hit)
                                            : (__builtin_amdgcn_fcmpf(d, rc2, 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33));
