@@ -97,6 +97,23 @@ def cpu_baseline(L, x, v, lo, hi, every, steps):
         s1.run(every, ev_last=False)
         out["single_thread"] = {"value": every / (time.perf_counter() - t0), "unit": "timesteps/s", "cores": 1,
                                 "sample": "%d steps" % every}
+    # the reference ITSELF on one host core, when oracle/_ref (its unmodified CPU sources, oracle/build_ref.sh) travelled with
+    # the snapshot: two runs of different length, the difference excludes set-up and file I/O
+    try:
+        from oracle import ref
+        if os.path.exists(ref.BIN):
+            ta = []
+            for nst in (every, 3 * every):
+                t0 = time.perf_counter()
+                ref.run(x, v, lo, hi, nsteps=nst, sample=[nst], every=every, timeout=300)
+                ta.append(time.perf_counter() - t0)
+            if ta[1] > ta[0]:
+                out["reference_one_core"] = {"value": 2 * every / (ta[1] - ta[0]), "unit": "timesteps/s", "cores": 1, "kind": "reference",
+                                             "sample": "oracle/_ref/ref_lmp (the reference's own pair_dpd.cpp, neigh_half_bin.cpp, comm.cpp, "
+                                                       "fix_nve.cpp ... compiled unmodified): %d steps minus %d steps of the same box, "
+                                                       "atom sorting off" % (3 * every, every)}
+    except Exception as e:      # noqa: BLE001 - the baseline must never break the bench line
+        out["reference_one_core"] = {"error": repr(e)[:200]}
     return out
 
 
