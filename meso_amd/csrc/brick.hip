@@ -468,23 +468,26 @@ __global__ void __launch_bounds__(256) k_ghost_count(const double *__restrict__ 
                                                      u32 *__restrict__ code, int *__restrict__ rank, int *__restrict__ cnt,
                                                      const int *__restrict__ nghost_dev)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nghost_dev) nghost = min(nghost, *nghost_dev);      // nghost is a launch bound
-    const bool valid = k < nghost;
-    u32 m = 0;
-    if (valid) {
-        const double c[3] = {x[nlocal + k], y[nlocal + k], z[nlocal + k]};
-        int b[3];
+    if (nghost_dev) nghost = *nghost_dev;      // nghost only sized the grid; the count is on the device
+    // whole waves take part in every trip (run_rank is a wave-level operation)
+    for (int base = blockIdx.x * blockDim.x; base < nghost; base += gridDim.x * blockDim.x) {
+        const int k = base + (int)threadIdx.x;
+        const bool valid = k < nghost;
+        u32 m = 0;
+        if (valid) {
+            const double c[3] = {x[nlocal + k], y[nlocal + k], z[nlocal + k]};
+            int b[3];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            b[d] = clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1.0), 0, g.mbin[d]);
-            b[d] = (c[d] >= g.lo[d]) ? (c[d] <= g.hi[d] ? b[d] : g.mbin[d] - 1) : 0;
+            for (int d = 0; d < 3; d++) {
+                b[d] = clampi((int)((c[d] - g.lo[d]) * g.bininv[d] + 1.0), 0, g.mbin[d]);
+                b[d] = (c[d] >= g.lo[d]) ? (c[d] <= g.hi[d] ? b[d] : g.mbin[d] - 1) : 0;
+            }
+            m = interleave3((u32)b[0], (u32)b[1], (u32)b[2]);
+            code[k] = m;
         }
-        m = interleave3((u32)b[0], (u32)b[1], (u32)b[2]);
-        code[k] = m;
+        const int r = run_rank(m, valid, cnt);
+        if (valid) rank[k] = r;
     }
-    const int r = run_rank(m, valid, cnt);
-    if (valid) rank[k] = r;
 }
 void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int nghost, uint32_t *code, int *rank, int *cnt,
                         const int *nghost_dev, hipStream_t s)

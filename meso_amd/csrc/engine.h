@@ -247,6 +247,7 @@ private:
     // rebuilds without a host round trip (one rank, cell-ordered layout): launch sizes come from the previous rebuild's counts
     // plus head-room, kernels mask with the counts on the device, the host reads them when it next needs them
     int async_counts = 1;           // option
+    double async_grid_scale = 1.125;   // grids of the ghost kernels: previous ghost count x this + 1024 (they loop: any count is covered)
     bool counts_pending = false;
     hipEvent_t ev_counts = nullptr;
     int nghost_prev = -1, n_bulk_prev = -1;

@@ -413,9 +413,9 @@ __global__ void __launch_bounds__(256) k_reorder_place(const u32 *__restrict__ k
                                                        const int *__restrict__ estart, int sub_bits, int n,
                                                        int *__restrict__ placed, const int *__restrict__ n_dev)
 {
-    int i = blockDim.x * blockIdx.x + threadIdx.x;
-    if (n_dev) n = min(n, *n_dev);         // n is a launch bound; the count itself has not reached the host yet
-    if (i < n) placed[estart[key[i] >> sub_bits] + rank[i]] = i;
+    // n_dev: n only sized the grid (an estimate); the count is on the device and the loop covers whatever it turns out to be
+    if (n_dev) n = *n_dev;
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) placed[estart[key[i] >> sub_bits] + rank[i]] = i;
 }
 #define REORDER_CODES 128
 __global__ void __launch_bounds__(REORDER_CODES) k_reorder_order(const int *__restrict__ estart, int ncodes,
@@ -846,9 +846,9 @@ __global__ void __launch_bounds__(1024) k_border_scan(const int *__restrict__ cn
 __global__ void __launch_bounds__(256) k_translate_list(int *__restrict__ list, const int *__restrict__ inverse, int bound,
                                                         const int *__restrict__ n_dev, const int *__restrict__ n_bulk, int *__restrict__ report)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0 && report) report[9] = *n_bulk;
-    if (k < min(bound, *n_dev)) list[k] = inverse[list[k]];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && report) report[9] = *n_bulk;
+    const int n = *n_dev;          // (bound only sized the grid)
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) list[k] = inverse[list[k]];
 }
 void launch_translate_list(int *list, const int *inverse, int bound, const int *n_dev, const int *n_bulk, int *report, hipStream_t s)
 {
@@ -886,16 +886,17 @@ __global__ void __launch_bounds__(256) k_pack_border(AtomSoA a, const int *__res
     __shared__ int ds[28];
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
     __syncthreads();
-    int k = blockDim.x * blockIdx.x + threadIdx.x;
-    if (k >= min(nsend, ds[27])) return;      // nsend may be a launch bound (counts still on their way to the host)
-    int j = sendlist[k];
-    int d = dir_of_entry(ds, k);
-    dx[k] = a.x[0][j] + sh.s[d][0];
-    dy[k] = a.x[1][j] + sh.s[d][1];
-    dz[k] = a.x[2][j] + sh.s[d][2];
-    dtag[k] = a.tag[j];
-    dtype[k] = a.type[j];
-    dmask[k] = a.mask[j];
+    // the list length is ds[27]; nsend only sized the grid (an estimate while the counts are on their way to the host)
+    for (int k = blockDim.x * blockIdx.x + threadIdx.x; k < ds[27]; k += gridDim.x * blockDim.x) {
+        int j = sendlist[k];
+        int d = dir_of_entry(ds, k);
+        dx[k] = a.x[0][j] + sh.s[d][0];
+        dy[k] = a.x[1][j] + sh.s[d][1];
+        dz[k] = a.x[2][j] + sh.s[d][2];
+        dtag[k] = a.tag[j];
+        dtype[k] = a.type[j];
+        dmask[k] = a.mask[j];
+    }
 }
 
 // pack_comm_vel (atom_vec_dpd_atomic_meso.cu:165-228) fused with gpu_merge_xvt for the ghost range:
@@ -908,23 +909,23 @@ __global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__re
     __shared__ int ds[28];
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
     __syncthreads();
-    int k = blockDim.x * blockIdx.x + threadIdx.x;
-    if (k >= min(nsend, ds[27])) return;      // nsend may be a launch bound
-    int j = sendlist[k];
-    int d = dir_of_entry(ds, k);
-    float4 c;
-    c.x = (float)((a.x[0][j] + sh.s[d][0]) - ce.c[d][0]);
-    c.y = (float)((a.x[1][j] + sh.s[d][1]) - ce.c[d][1]);
-    c.z = (float)((a.x[2][j] + sh.s[d][2]) - ce.c[d][2]);
-    c.w = __uint_as_float((u32)(a.type[j] - 1));
-    const int out = dest_slot ? dest_slot[k] : k;
-    dcoord[out] = c;
-    float4 v;
-    v.x = (float)a.v[0][j];
-    v.y = (float)a.v[1][j];
-    v.z = (float)a.v[2][j];
-    v.w = __uint_as_float(signature(seed, a.tag[j], v.x, v.y, v.z));
-    dveloc[out] = v;
+    for (int k = blockDim.x * blockIdx.x + threadIdx.x; k < ds[27]; k += gridDim.x * blockDim.x) {      // (nsend only sized the grid)
+        int j = sendlist[k];
+        int d = dir_of_entry(ds, k);
+        float4 c;
+        c.x = (float)((a.x[0][j] + sh.s[d][0]) - ce.c[d][0]);
+        c.y = (float)((a.x[1][j] + sh.s[d][1]) - ce.c[d][1]);
+        c.z = (float)((a.x[2][j] + sh.s[d][2]) - ce.c[d][2]);
+        c.w = __uint_as_float((u32)(a.type[j] - 1));
+        const int out = dest_slot ? dest_slot[k] : k;
+        dcoord[out] = c;
+        float4 v;
+        v.x = (float)a.v[0][j];
+        v.y = (float)a.v[1][j];
+        v.z = (float)a.v[2][j];
+        v.w = __uint_as_float(signature(seed, a.tag[j], v.x, v.y, v.z));
+        dveloc[out] = v;
+    }
 }
 
 void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start, const double *shift27,
