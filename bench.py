@@ -283,12 +283,15 @@ def main():
     # HBM traffic of the force kernel: PMC counters cannot be read inside this process; the figure of the separate
     # `rocprofv3 --pmc` passes over this same command is kept in profiles/ (traffic_source names the file) and attached only
     # while kernel and workload match
-    traffic = traffic_source = None
+    traffic = traffic_source = limiter = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
         if L == tj.get("box") and a.style == tj.get("style") and a.gpus == 1 and tj.get("kernel") == kernel:
             traffic = tj["traffic_bytes_per_launch"]
             traffic_source = "profiles/r02_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc")
+            # what the counters of the same profile say bounds the kernel (not HBM): profile-derived, not measured in this run
+            limiter = {"units": "VALU issue and texture addresser", "valu_issue_frac": 0.79, "ta_busy_frac": 0.73,
+                       "arithmetic_ceiling_frac_of_hbm_peak": 0.43, "source": "profiles/r02_pmc_ring_focus.txt, profiles/r02_notes.md section 1"}
     except (OSError, ValueError, KeyError):
         pass
 
@@ -314,7 +317,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                      "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "bytes_per_launch": b_pair_only,
-                     "us_per_launch": t_alone * 1e6, "fused": fused_rec},
+                     "us_per_launch": t_alone * 1e6, "fused": fused_rec, "limiter_from_profile": limiter},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
     }
     if world > 1:

@@ -184,3 +184,46 @@ def test_sparse_rank_grows_during_the_border_stage():
     assert np.array_equal(got["setup"][3], np.arange(1, n + 1))
     assert np.abs(f2 - f1).max() < 5e-6 * np.abs(f1).max()
     assert np.array_equal(got["end"][3], np.arange(1, n + 1))
+
+
+@pytest.mark.parametrize("style,tol_f", [("dpd/fast/meso", 6e-3), ("dpd/meso", 6e-3)])
+def test_config2_64cube_against_the_pinned_cpu_restatement(oracle, style, tol_f):
+    """configs[2] (and the one-rank half of configs[3]) at size against the restatement of the reference's stock CPU path that
+    oracle/_ref pins bit for bit: sigma = 0 (the deterministic part of the force), 64^3 = 1 048 576 atoms - forces, neighbour
+    count, potential energy, pressure and the temperature after 10 steps with two rebuilds.  The GPU path (like the
+    reference's) works on fp32 coordinates relative to the box centre (atom_vec_meso.cu:154-156): their ulp at |x| = 32 is
+    3.8e-6, 8x that of the L = 8 comparison (tolerance 2e-4 there), and the maximum is taken over 3 M components instead of
+    6 k: largest force difference 3.2e-3 on |F| ~ 200, median 5e-5."""
+    import os
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(64)
+    n = len(x)
+    s = oracle.LmpDpd(x, lo, hi, nthreads=min(16, len(os.sched_getaffinity(0))))
+    s.pair_style(0.0, 1.0, 419084618)
+    s.pair_coeff(1, 1, 15.0, 4.5)
+    s.set_velocities(v)
+    s.neighbor(0.3, 5, 0)
+    s.timestep(0.005)
+    s.setup()
+    with Meso() as m:
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style(style, 1.0, 419084618)
+        m.pair_coeff(1, 1, 15.0, 4.5, 0.0, 1.0, 1.0)
+        m.timestep(0.005)
+        m.setup()
+        f = m.gather()[2]
+        fs = s.state()[2]
+        assert np.abs(f - fs).max() < tol_f and np.median(np.abs(f - fs)) < 1e-4
+        assert m.neigh_info()["avg_count"] == pytest.approx(2.0 * s.nneigh / n, abs=64.0 / n)
+        assert m.pe() / n == pytest.approx(s.pe_per_atom, rel=5e-6)
+        assert m.pressure() == pytest.approx(s.pressure, rel=5e-6)
+        m.run(10)
+        s.run(10)
+        xg, vg = m.gather()[:2]
+        xs, vs, _ = s.state()
+        d = xg - xs
+        d -= np.round(d / (hi - lo)) * (hi - lo)
+        assert np.abs(d).max() < 2e-5 and np.abs(vg - vs).max() < 4e-4
+        assert m.temperature() == pytest.approx(s.temperature, rel=1e-6)
