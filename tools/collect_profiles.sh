@@ -20,6 +20,19 @@ with open("gpurun_out/${tag}_kernel_stats_64_fast.txt", "w") as o:
     for r in csv.DictReader(open(f)):
         o.write("%-90s calls %6s avg_us %9.2f total_ms %9.2f pct %6s\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"][:6]))
 PY
+# the same trace with the step boundary in its own kernel: k_pair_dpd_ring's average is then the force kernel ALONE (the graded figure)
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_ktp -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 50 --opt fuse_pair=0 > $R/gpurun_out/${tag}_ktp.log 2>&1
+cd $R
+python3 - <<PY
+import csv, glob
+f = glob.glob("gpurun_out/${tag}_ktp/**/*kernel_stats.csv", recursive=True)[0]
+with open("gpurun_out/${tag}_kernel_stats_64_pair_only.txt", "w") as o:
+    o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 300 --warmup 50 --opt fuse_pair=0   (64^3 rho=4, dpd/fast/meso; the force kernel is launched alone on every step)\n")
+    for r in csv.DictReader(open(f)):
+        o.write("%-90s calls %6s avg_us %9.2f total_ms %9.2f pct %6s\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"][:6]))
+PY
+echo "pair-only kernel trace done"
 bash tools/pmc_run.sh ${tag}_pmc
 ( echo "# rocprofv3 --pmc <counters> -- python3 bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline   (64^3 rho=4, dpd/fast/meso; one pass per counter group; mean per dispatch)"; cat gpurun_out/${tag}_pmc.summary.txt ) > gpurun_out/${tag}_pmc_64_fast.txt
 echo "pmc done"

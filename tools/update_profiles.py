@@ -4,7 +4,7 @@
 import json, re, shutil, sys
 tag = sys.argv[1]
 import os
-for f in ("bench64_fast.json", "kernel_stats_64_fast.txt", "pmc_64_fast.txt", "pmc_pair_only.txt"):
+for f in ("bench64_fast.json", "kernel_stats_64_fast.txt", "kernel_stats_64_pair_only.txt", "pmc_64_fast.txt", "pmc_pair_only.txt"):
     shutil.copy("gpurun_out/%s_%s" % (tag, f), "profiles/%s_%s" % (tag, f))
 for f in ("bench25_fast.json", "bench32_fast.json", "bench48_fast.json", "bench64_dp.json", "bench25_dp_every1.json", "bench128_fast.json",
           "bench64_polymer.json", "bench128_polymer.json"):
