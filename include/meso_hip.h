@@ -53,6 +53,8 @@ int meso_device_sync(meso_ctx *ctx);
  *   brick_margin  1  multiplier on the expected brick-neighbourhood population (raise for strongly inhomogeneous systems)
  *   async_counts  1  one rank: a rebuild does not wait for the host - launch bounds come from the previous rebuild's counts,
  *                    kernels mask with the device-side counts, the host reads them (pinned memory) when it next needs them
+ *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
+ *                    images (no k_pack_forward launch between rebuilds); -1 = for boxes of at most 524 288 local atoms, 0 off, 1 on
  *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost
  *                    binning on the side stream, joined by events (same neighbour sets and forces; measured slower)
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */

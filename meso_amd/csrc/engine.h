@@ -255,6 +255,13 @@ private:
     // ... and with the two halves of the rebuild on two streams (option overlap_rebuild): the reorder of the locals on the
     // main stream, border lists + ghost creation + ghost binning on the side stream (north_star: reorder on a side stream
     // overlapped with halo pack/unpack; the reference overlaps its sort-phase transfers, mvv_meso.cu:296-316)
+    // one rank, small boxes: the step-boundary epilogue also refreshes the ghosts (no k_pack_forward launch between rebuilds)
+    int ghost_epilogue = -1;        // option: -1 by size (<= 524288 local atoms: +5 % at 25^3, +3 % at 32^3, +1 % at 48^3, -2 % at 64^3), 0 off, 1 on
+    int *img_cnt = nullptr, *img = nullptr;
+    double *d_shift27 = nullptr;
+    bool images_ready = false;      // this rebuild recorded the images
+    bool build_images_now = false;
+    bool images_on() const { return nranks == 1 && (ghost_epilogue == 1 || (ghost_epilogue < 0 && nlocal <= 524288)); }
     int overlap_rebuild = 0;        // measured slower at every size (profiles/r02_notes.md section 5): kept as a tested option
     bool ghosts_binned = false;     // this rebuild's ghosts were binned by rebuild_overlapped
     int rebuild_overlapped();

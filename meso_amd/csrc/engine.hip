@@ -44,6 +44,7 @@ Engine::Engine(int dev) : device(dev)
     if (const char *e = getenv("MESO_PAIR_DEBUG")) pair_debug = atoi(e);
     if (const char *e = getenv("MESO_ASYNC_COUNTS")) async_counts = atoi(e);
     if (const char *e = getenv("MESO_OVERLAP_REBUILD")) overlap_rebuild = atoi(e);
+    if (const char *e = getenv("MESO_GHOST_EPILOGUE")) ghost_epilogue = atoi(e);
     if (const char *e = getenv("MESO_PAIR_NPART")) pair_npart = atoi(e);
 }
 
@@ -81,7 +82,7 @@ void Engine::free_all()
     dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
     dfree(pair_count); dfree(pair_table);
-    dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt);
+    dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(img_cnt); dfree(img); dfree(d_shift27);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
@@ -330,6 +331,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "async_counts") { async_counts = (int)val; return 0; }
     if (key == "overlap_rebuild") { overlap_rebuild = (int)val; return 0; }
+    if (key == "ghost_epilogue") { ghost_epilogue = (int)val; return 0; }
     if (key == "async_grid_scale") { async_grid_scale = val; return 0; }      // tests: under-sized grids must still cover every ghost
     if (key == "pair_debug") { pair_debug = (int)val; return 0; }
     if (key == "layout") {     // kept for scripts of round 1: only the cell-ordered layout exists
@@ -414,6 +416,8 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(sendlist, 0, c, stream));
     HIPCHK(regrow(gslot, 0, c, stream));
     HIPCHK(regrow(gtmp_placed, 0, c, stream)); HIPCHK(regrow(gtmp_code, 0, c, stream)); HIPCHK(regrow(perm_inverse, 0, c, stream));
+    HIPCHK(regrow(img_cnt, 0, c, stream)); HIPCHK(regrow(img, 0, c * 8, stream));
+    images_ready = false;
     send_cap = cap;
     chunk_cap = (cap + 255) / 256 + 1;
     HIPCHK(regrow(chunk_count, 0, (size_t)27 * chunk_cap + 1, stream));
@@ -830,6 +834,8 @@ int Engine::init_params()
         peer27[dir] = loc[0] + procgrid[0] * (loc[1] + procgrid[1] * loc[2]);
     }
     build_peer_tables();
+    if (!d_shift27) HIPCHK(dalloc(d_shift27, 81));
+    HIPCHK(hipMemcpy(d_shift27, shift27, 81 * sizeof(double), hipMemcpyHostToDevice));
 
     // bins aligned with the sub-box, one ghost layer each side
     double subvol = 1.0;
@@ -991,7 +997,7 @@ int Engine::reorder_locals()
         // the gather also writes the merged float4 pair of the new order, with the signatures of the current step
         launch_permute_merge(cur, alt, rval, nlocal, permute_forces ? 1 : 0, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
                              0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), nullptr,
-                             stream);
+                             images_on() ? img_cnt : nullptr, stream);
         merged_in_reorder = true;      // (alloc_atoms clears it: a regrown coord4 has lost the values)
     }
     std::swap(cur, alt);
@@ -1060,7 +1066,7 @@ int Engine::rebuild_overlapped()
     std::swap(rkey, bin_key_alt);
     launch_permute_merge(cur, alt, rval, nlocal, permute_forces ? 1 : 0, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
                          0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), perm_inverse,
-                         stream);
+                         images_on() ? img_cnt : nullptr, stream);
     merged_in_reorder = true;
     std::swap(cur, alt);
     // ---- join
@@ -1158,8 +1164,12 @@ int Engine::halo_forward_seed(uint32_t sd, bool async)
     if (nranks > 1) return halo_forward_multi_begin(sd, async);
     if (nsend <= 0) return 0;
     tbegin("halo");
+    // at a rebuild (merged_in_reorder was just consumed: the counters were cleared by the gather) the kernel also records every
+    // source atom's images for the step-boundary epilogue
+    const bool rec = build_images_now && images_on();
     launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,
-                        gslot, stream);
+                        gslot, rec ? img_cnt : nullptr, img, nlocal, stream);
+    if (rec) images_ready = true;
     tend("halo");
     return 0;
 }
@@ -1204,9 +1214,15 @@ int Engine::build_cells_and_table()
         tend("bin");
         // merged arrays with the signatures of the CURRENT step: the force kernel of this step uses them as they are
         const u32 sd_now = premix_tea<64>((u32)seed, (u32)ntimestep);
+        images_ready = false;
+        build_images_now = merged_in_reorder;      // the gather of this rebuild cleared the image counters
         if (!merged_in_reorder) TRY(merge_locals(sd_now));
         merged_in_reorder = false;
-        TRY(halo_forward_seed(sd_now));
+        {
+            const int rc_fwd = halo_forward_seed(sd_now);
+            build_images_now = false;
+            if (rc_fwd) return rc_fwd;
+        }
         TRY(rebuild_topology());
         {
             tbegin("neigh");
@@ -1442,7 +1458,7 @@ int Engine::run(int nsteps)
 {
     if (!is_setup) return fail(3, "run before setup");
     tbegin("total_steps");
-    bool initial_done = false, merged = false;
+    bool initial_done = false, merged = false, ghosts_by_epilogue = false;
     for (int it = 0; it < nsteps; it++) {
         profile_tick(it, nsteps);
         ntimestep++;
@@ -1463,7 +1479,8 @@ int Engine::run(int nsteps)
         // the few bulk atoms behind it simply wait for the ghosts too
         const int n_split = n_bulk & ~(pair_ring_group() - 1);
         const bool split = nranks > 1 && overlap && n_split > 0 && n_split < nlocal;
-        if (!ghosts_fresh) TRY(halo_forward_seed(sd, split));
+        if (!ghosts_fresh && !ghosts_by_epilogue) TRY(halo_forward_seed(sd, split));
+        ghosts_by_epilogue = false;
         PairArgs p;
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
         for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
@@ -1495,6 +1512,9 @@ int Engine::run(int nsteps)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
                                   0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
                                   premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
+        // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
+        const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
+        if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }
         // bulk atoms have no ghost partners: their forces are computed while the ghosts are in flight
         for (int part = 0; part < (split ? 2 : 1); part++) {
             p.beg = split ? (part == 0 ? 0 : n_split) : 0;
@@ -1514,6 +1534,7 @@ int Engine::run(int nsteps)
             if (!next_rebuild) { std::swap(coord4, coord4_next); std::swap(veloc4, veloc4_next); }
             initial_done = true;
             merged = !next_rebuild;
+            ghosts_by_epilogue = img_step;
         } else if (fuse_step && it + 1 < nsteps) {
             // one pass for final(s) + initial(s+1); the merge for s+1 rides along when s+1 provably keeps the table
             tbegin("nve");

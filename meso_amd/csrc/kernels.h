@@ -68,7 +68,7 @@ void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *per
 // ... and the merged float4 pair of the new order in the same pass (k_merge_xvt folded in)
 void launch_permute_merge(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, float4 *coord4,
                           float4 *veloc4, double cx, double cy, double cz, uint32_t seed, int *inverse /*nullable: old -> new place*/,
-                          hipStream_t s);
+                          int *zero /*nullable: per-atom counter cleared for the new order*/, hipStream_t s);
 void launch_translate_list(int *list, const int *inverse, int bound, const int *n_dev, const int *n_bulk, int *report, hipStream_t s);
 void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s);
 
@@ -96,7 +96,7 @@ void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const 
 void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start /*dev [28]*/,
                          const double *shift27 /*host [27][3]*/, const double *center27 /*host [27][3]*/,
                          uint32_t seed, float4 *dcoord, float4 *dveloc, const int *dest_slot /*nullable*/,
-                         hipStream_t s);
+                         int *img_cnt /*nullable: also record each source atom's images*/, int *img, int img_base, hipStream_t s);
 
 
 
@@ -111,6 +111,10 @@ struct NveArgs {
     float4 *coord4_next, *veloc4_next;
     double cx, cy, cz;
     uint32_t seed_next;
+    // one rank, small boxes: the atom also writes the merged pair of its periodic images (the per-step ghost refresh without a
+    // k_pack_forward launch).  img_cnt[i] images, img[8 i + m] = destination index | direction << 26; null: disabled
+    const int *img_cnt, *img;
+    const double *img_shift;      // [27][3] period shifts
 };
 NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,
                       float4 *veloc4_next, double cx, double cy, double cz, uint32_t seed_next);

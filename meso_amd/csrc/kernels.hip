@@ -121,6 +121,7 @@ NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, in
     nv.dtf = dtf; nv.dtv = dtv; nv.groupbit = groupbit; nv.merge = merge;
     nv.coord4_next = coord4_next; nv.veloc4_next = veloc4_next;
     nv.cx = cx; nv.cy = cy; nv.cz = cz; nv.seed_next = seed_next;
+    nv.img_cnt = nullptr; nv.img = nullptr; nv.img_shift = nullptr;
     return nv;
 }
 
@@ -528,7 +529,7 @@ void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_
 // gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
 // mg.coord4 != null: the merged float4 pair of the atom's new place is written as well (gpu_merge_xvt folded into the gather:
 // the reorder has x, v, tag and type in registers anyway; 17 us of re-reading them at 64^3)
-struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; int *inverse; };
+struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; int *inverse; int *zero; };
 __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n, int with_f,
                                                        MergeOut mg)
 {
@@ -536,6 +537,7 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
     if (i >= n) return;
     int j = from[i];
     if (mg.inverse) mg.inverse[j] = i;      // old place -> new place (the overlapped rebuild translates its send list with it)
+    if (mg.zero) mg.zero[i] = 0;            // image counters of the new order (filled by the rebuild's k_pack_forward)
     double xx[3], vv[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -578,13 +580,13 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
 }
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s)
 {
-    MergeOut mg = {nullptr, nullptr, 0.0, 0.0, 0.0, 0u, nullptr};
+    MergeOut mg = {nullptr, nullptr, 0.0, 0.0, 0.0, 0u, nullptr, nullptr};
     if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f, mg);
 }
 void launch_permute_merge(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, float4 *coord4,
-                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, int *inverse, hipStream_t s)
+                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed, int *inverse, int *zero, hipStream_t s)
 {
-    MergeOut mg = {coord4, veloc4, cx, cy, cz, seed, inverse};
+    MergeOut mg = {coord4, veloc4, cx, cy, cz, seed, inverse, zero};
     if (n > 0) hipLaunchKernelGGL(k_permute_atoms, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, perm_from, n, with_f, mg);
 }
 
@@ -904,7 +906,8 @@ __global__ void __launch_bounds__(256) k_pack_border(AtomSoA a, const int *__res
 __global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__restrict__ sendlist, int nsend,
                                                       const int *__restrict__ dir_start, Shift27 sh, Center27 ce,
                                                       u32 seed, float4 *__restrict__ dcoord,
-                                                      float4 *__restrict__ dveloc, const int *__restrict__ dest_slot)
+                                                      float4 *__restrict__ dveloc, const int *__restrict__ dest_slot,
+                                                      int *__restrict__ img_cnt, int *__restrict__ img, int img_base)
 {
     __shared__ int ds[28];
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
@@ -919,6 +922,10 @@ __global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__re
         c.w = __uint_as_float((u32)(a.type[j] - 1));
         const int out = dest_slot ? dest_slot[k] : k;
         dcoord[out] = c;
+        if (img_cnt) {     // rebuild: remember where the images of atom j live (the step-boundary epilogue refreshes them)
+            const int slot = atomicAdd(&img_cnt[j], 1);
+            if (slot < 8) img[(size_t)j * 8 + slot] = (img_base + out) | (d << 26);
+        }
         float4 v;
         v.x = (float)a.v[0][j];
         v.y = (float)a.v[1][j];
@@ -941,7 +948,7 @@ void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const 
 
 void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start, const double *shift27,
                          const double *center27, uint32_t seed, float4 *dcoord, float4 *dveloc, const int *dest_slot,
-                         hipStream_t s)
+                         int *img_cnt, int *img, int img_base, hipStream_t s)
 {
     if (nsend <= 0) return;
     Shift27 sh;
@@ -949,7 +956,7 @@ void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const
     for (int d = 0; d < 27; d++)
         for (int k = 0; k < 3; k++) { sh.s[d][k] = shift27[3 * d + k]; ce.c[d][k] = center27[3 * d + k]; }
     hipLaunchKernelGGL(k_pack_forward, dim3(nblk(nsend, 256)), dim3(256), 0, s, a, sendlist, nsend, dir_start, sh, ce,
-                       seed, dcoord, dveloc, dest_slot);
+                       seed, dcoord, dveloc, dest_slot, img_cnt, img, img_base);
 }
 
 // =========================================================================================

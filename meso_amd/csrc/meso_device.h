@@ -339,6 +339,21 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
         v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;
         v.w = __uint_as_float(signature(a.seed_next, a.tag[i], v.x, v.y, v.z));
         a.veloc4_next[i] = v;
+        if (a.img_cnt) {
+            // the ghost refresh of step s+1 for my own periodic images (what k_pack_forward computes: same expression, same bits)
+            const int ni = min(a.img_cnt[i], 8);
+            for (int m = 0; m < ni; m++) {
+                const int e = a.img[(size_t)i * 8 + m];
+                const int d = e >> 26, dest = e & 0x03FFFFFF;
+                float4 g;
+                g.x = (float)((x + a.img_shift[3 * d]) - a.cx);
+                g.y = (float)((y + a.img_shift[3 * d + 1]) - a.cy);
+                g.z = (float)((z + a.img_shift[3 * d + 2]) - a.cz);
+                g.w = c.w;
+                a.coord4_next[dest] = g;
+                a.veloc4_next[dest] = v;
+            }
+        }
     }
 }
 

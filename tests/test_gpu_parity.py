@@ -626,8 +626,9 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
     forces after 23 steps (4 rebuilds) are bit-identical (fixed-point force sums do not depend on entry order)."""
     res = []
     # (async_grid_scale 0.05: the ghost kernels' grids are sized for a twentieth of the ghosts and have to loop)
-    for opts in ((("async_counts", 0),), (), (("overlap_rebuild", 1),), (("async_grid_scale", 0.05),),
-                 (("overlap_rebuild", 1), ("async_grid_scale", 0.05))):
+    # ghost_epilogue: the per-step ghost refresh done by the force kernel's step-boundary epilogue (on by default at this size)
+    for opts in ((("async_counts", 0), ("ghost_epilogue", 0)), (), (("overlap_rebuild", 1),), (("async_grid_scale", 0.05),),
+                 (("overlap_rebuild", 1), ("async_grid_scale", 0.05)), (("ghost_epilogue", 0),), (("ghost_epilogue", 1), ("async_counts", 0))):
         m, _ = _engine(Meso, 16, style=style, opts=opts)
         m.run(23)
         res.append(m.gather())
