@@ -638,3 +638,22 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
     for other in res[1:]:
         for a, b in zip(res[0][:3], other[:3]):
             assert np.array_equal(a, b)
+
+
+def test_neigh_modify_check_yes_rebuilds_on_displacement_only(Meso):
+    """neigh_modify delay 0 every 1 check yes (Neighbor::decide + check_distance, src/neighbor.cpp:1216-1300): the list is
+    rebuilt only when some atom has moved half the skin - far fewer rebuilds than `check no`, the same sigma = 0 trajectory
+    (the lists stay valid; positions differ only by the fp32 rounding of wrapped vs unwrapped merged coordinates)."""
+    x, v, lo, hi = make_box(10)
+    res = {}
+    for check in (False, True):
+        m = Meso()
+        m.read_atoms(x, v, lo, hi); m.neighbor(0.3); m.neigh_modify(delay=0, every=1, check=check)
+        m.pair_style("dpd/meso", 1.0, DP_RUN["seed"]); m.pair_coeff(1, 1, 15.0, 4.5, 0.0, 1.0, 1.0); m.timestep(0.005)
+        m.setup(); m.run(40)
+        res[check] = (m.gather(), m.neigh_info()["nbuild"])
+        m.close()
+    assert res[False][1] == 40 and 1 <= res[True][1] <= 12
+    d = res[True][0][0] - res[False][0][0]
+    d -= np.round(d / (hi - lo)) * (hi - lo)
+    assert np.abs(d).max() < 2e-6 and np.abs(res[True][0][1] - res[False][0][1]).max() < 2e-5
