@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
         return;
     }
     if (tid == 0) { hdr[0] = nh; hdr[1] = o0; hdr[2] = n0; hdr[3] = o1; hdr[4] = n1; }
+    if (tid == 0 && nh * 8 > g.maxh * 7) atomicMax(overflow + 5, nh);      // high-water mark: the engine grows the capacity ahead of an overflow
     for (int t = tid; t <= BRK_NHB; t += 256) g.hoff[(size_t)slot * BRK_HOFF_PITCH + t] = hoff[t];
     if (tid < BRK_NHB) g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + tid] = hl0[tid] + hl1[tid];
     // halo slot -> global (cell-order) atom index
@@ -230,6 +231,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             if (tid == 0) atomicMax(overflow, 100000 + nh);
             return;
         }
+        if (tid == 0 && nh * 8 > g.maxh * 7) atomicMax(overflow + 5, nh);      // high-water mark (see k_brick_plan)
         for (int h = tid; h < nh; h += BRK_THREADS) {
             int lo = 0, hi = BRK_NHB;            // largest halo bin with hoff[bin] <= h
             while (hi - lo > 1) {

@@ -273,6 +273,7 @@ private:
     bool permute_forces = true;     // the reorder carries the forces along (not needed for the rebuilds inside run())
     bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
     double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)
+    double brick_margin_auto = 1.0; // grown by the engine when the fullest brick neighbourhood comes close to the capacity
     size_t estart_cap = 0;
     BrickArgs bargs{};
     int l1bits = 0;

@@ -900,13 +900,13 @@ int Engine::init_params()
         // lane-per-atom builder when even one workgroup per CU could not hold the neighbourhood.
         {
             const double binvol = geom.binsize[0] * geom.binsize[1] * geom.binsize[2];
-            const double mean = density * 216.0 * binvol * brick_margin;
+            const double mean = density * 216.0 * binvol * brick_margin * brick_margin_auto;
             int want = ((int)std::ceil(mean + 6.5 * std::sqrt(mean)) + 63) / 64 * 64;
             if (want < brick_static_maxh()) want = brick_static_maxh();
             tile_fits = want <= tile_build_maxh_limit(n_col, have_bonds && msp > 0 ? 1 : 0);
             bargs.maxh = want;
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
-            const double m128 = density * 128.0 * binvol * brick_margin;
+            const double m128 = density * 128.0 * binvol * brick_margin * brick_margin_auto;
             reorder_cap = std::min(7680, std::max(2048, ((int)std::ceil(m128 + 6.5 * std::sqrt(m128)) + 63) / 64 * 64));
             if (reorder_cap_user > 0) reorder_cap = reorder_cap_user;
             bargs.maxown = 0;
@@ -1276,7 +1276,7 @@ int Engine::resolve_counts()
 
 int Engine::check_overflow()
 {
-    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 5 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 6 * sizeof(int), hipMemcpyDeviceToHost, stream));      // [5]: fullest brick neighbourhood so far
     HIPCHK(hipStreamSynchronize(stream));
     if (have_bonds && h_flags[4]) {
         HIPCHK(hipMemsetAsync(d_flags + 4, 0, sizeof(int), stream));
@@ -1304,8 +1304,19 @@ int Engine::check_overflow()
 
 int Engine::reneighbor()
 {
-    TRY(init_params());
     TRY(resolve_counts());       // the previous rebuild's counts (long since arrived) size this one
+    {
+        // denser than expected (chains, phase separation): the LDS stage of a brick neighbourhood grows BEFORE it overflows - the
+        // high-water mark of the earlier list builds came with the count report (or with the last check_overflow)
+        const int hwm = std::max(h_flags[5], h_flags[10]);
+        if (params_ready && neigh_kernel == 1 && (long)hwm * 100 > (long)bargs.maxh * 93) {
+            brick_margin_auto *= 1.12;
+            params_ready = false;
+            h_flags[5] = h_flags[10] = 0;
+            HIPCHK(hipMemsetAsync(d_flags + 5, 0, sizeof(int), stream));
+        }
+    }
+    TRY(init_params());
     // one rank: nothing happens between the wrap and the reorder, which reads the coordinates anyway - wrapped there
     wrap_in_reorder = nranks == 1 && !reorder_sort && nlocal > 0;
     if (!wrap_in_reorder) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
@@ -1433,7 +1444,17 @@ int Engine::setup()
     if ((pair_rng || pair_poly || pair_ftab) && !ring_selected())
         return fail(3, "pair styles dpd/mini/meso, dpd/polyforce/meso and dpd/tableforce/meso run on the default force kernel only (pair_kernel=2)");
     TRY(init_params());
-    TRY(reneighbor());
+    for (int attempt = 0;; attempt++) {
+        TRY(reneighbor());
+        // the first list build sizes the brick stage from the mean density: a start configuration denser than that somewhere
+        // (polymer decks) gets a larger stage and a second build instead of an error
+        HIPCHK(hipMemcpyAsync(h_flags, d_flags, 6 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (h_flags[0] < 100000 || h_flags[0] >= 200000 || attempt >= 8) break;
+        brick_margin_auto *= std::max(1.1, 1.08 * (h_flags[0] - 100000) / (double)bargs.maxh);
+        params_ready = false;
+        HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+    }
     nbuild = 0;
     if (restart_forces) {
         // continuing from a restart file: the forces of the interrupted step came with the atoms (restart.hip) and were

@@ -842,6 +842,7 @@ __global__ void __launch_bounds__(1024) k_border_scan(const int *__restrict__ cn
         if (f) flags[0] = f;
         report[8] = f;
         report[9] = *n_bulk;
+        report[10] = flags[5];       // fullest brick neighbourhood of the previous list build
     }
 }
 // send list built on the pre-reorder order -> indices of the new order; also the last word of the host report (n_bulk)

@@ -657,3 +657,37 @@ def test_neigh_modify_check_yes_rebuilds_on_displacement_only(Meso):
     d = res[True][0][0] - res[False][0][0]
     d -= np.round(d / (hi - lo)) * (hi - lo)
     assert np.abs(d).max() < 2e-6 and np.abs(res[True][0][1] - res[False][0][1]).max() < 2e-5
+
+
+def test_dense_region_grows_the_brick_stage_instead_of_failing(Meso):
+    """A box whose density is far from uniform (rho = 4 everywhere, a 6^3 corner at rho = 10): the LDS stage of the tile
+    builder's brick neighbourhoods is sized from the MEAN density, so the first build overflows it.  The engine must
+    grow the stage and build again (the reference has no such capacity: neigh_build_meso.cu:20-119 reads bins from global
+    memory), and the lists and forces must equal those of the capacity-free cell builder."""
+    L = 16
+    x, v, lo, hi = make_box(L)
+    rng = np.random.default_rng(5)
+    extra = rng.random((6 * 6 * 6 * 6, 3)) * 6.0 + 1.0
+    x = np.concatenate([x, extra])
+    v = np.concatenate([v, rng.normal(size=extra.shape)])
+    out = {}
+    for name, nk in (("tile", 1), ("cell", 0)):
+        m = Meso()
+        m.set_option("neigh_kernel", nk)
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style("dpd/fast/meso", 1.0, 12345)
+        m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+        m.timestep(0.001)
+        m.setup()                                   # raised "Brick halo overflow" before
+        info = m.neigh_info()
+        f0 = m.gather()[2]
+        m.run(10)
+        out[name] = (info, f0, m.gather())
+        m.close()
+    assert out["tile"][0]["max_count"] > 100                      # the dense corner really is dense
+    assert out["tile"][0] == out["cell"][0]
+    assert np.array_equal(out["tile"][1], out["cell"][1])         # integer force sums: independent of the row order
+    for a, b in zip(out["tile"][2], out["cell"][2]):
+        assert np.array_equal(a, b)
