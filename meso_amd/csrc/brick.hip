@@ -10,6 +10,7 @@
 //
 // Replaces gpu_build_neighbor_list + gpu_join/transpose (neigh_build_meso.cu:20-240).  (Round 1 also kept a force kernel
 // and a 16-bit-row builder on this layout - `layout=1`; retired in round 2, the cell-ordered ring kernel is faster.)
+#include <type_traits>
 #include "kernels.h"
 #include "meso_device.h"
 
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
 
         // candidates of the first 4 batches (256 atoms: the usual stencil holds ~237) stay in registers for all groups
         // of this bin; later batches (denser systems) are reloaded per group
-        auto load_cand = [&](int b, int &cs, float &cx, float &cy, float &cz, int &ctag) {
+        auto load_cand = [&](int b, int &cs, float &cx, float &cy, float &cz) {
             const int id = (b << 6) + lane;
             int base = rstart[0];
 #pragma unroll
@@ -303,15 +304,13 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             cs = valid ? id + base : 0;
             cx = valid ? hx[cs] : 1.0e18f;       // never inside the cutoff
             cy = hy[cs]; cz = hz[cs];
-            ctag = 0;
-            if (EXCL) ctag = htag[cs];          // (staged with the neighbourhood: a gather from global memory per candidate before)
         };
-        int cs4[4], ct4[4];
+        int cs4[4];
         float cx4[4], cy4[4], cz4[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            cs4[b] = 0; ct4[b] = 0; cx4[b] = 1.0e18f; cy4[b] = cz4[b] = 0.f;
-            if (b < nbatch) load_cand(b, cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+            cs4[b] = 0; cx4[b] = 1.0e18f; cy4[b] = cz4[b] = 0.f;
+            if (b < nbatch) load_cand(b, cs4[b], cx4[b], cy4[b], cz4[b]);
         }
 
         for (int g0 = 0; g0 < na; g0 += TB_G) {
@@ -338,47 +337,32 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             int nrow[TB_G];
 #pragma unroll
             for (int t = 0; t < TB_G; t++) nrow[t] = 0;
-
-            auto scan = [&](const int cs, const float cx, const float cy, const float cz, const int ctag) {
-#pragma unroll
-                for (int t = 0; t < TB_G; t++) {
-                    if (t < ng) {
-                        const float dx = ox[t] - cx, dy = oy[t] - cy, dz = oz[t] - cz;
-                        const float d = dx * dx + dy * dy + dz * dz;
-                        bool hit = (d <= rc2) & (cs != own0 + g0 + t);
-                        if (EXCL) {
-                            // gpu_filter_exclusion (neigh_build_meso.cu:497-544): drop special partners by tag
-                            const int nsp = ex.nspecial[gi[t]];
-                            for (int sp = 0; sp < nsp; sp++) hit = hit & (ex.special[(size_t)gi[t] * ex.msp + sp] != ctag);
-                        }
-                        // no "any hit?" branch: a batch of 64 candidates almost always holds one, and straight-line code lets
-                        // the chains of the group's atoms overlap
-                        // lane mask straight from the compares (LLVM predicates: 5 = OLE, 33 = NE) unless exclusions apply
-                        const u64 m = EXCL ? __builtin_amdgcn_ballot_w64(hit)
-                                           : (__builtin_amdgcn_fcmpf(d, rc2, 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33));
-                        const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
-                        if (hit) myrow(t)[min(pos, (u32)(n_col - 1))] = (unsigned short)cs;
-                        nrow[t] += __popcll(m);
-                    }
+            // special-bond partners of the group's own atoms, 16 lanes per atom: requested here, used when the rows are written
+            // out (the scan in between hides the latency); an atom with more than 16 reads the rest from global memory there
+            int nsp_l = 0, sp_l = -1;
+            if (EXCL) {
+                const int tq = lane >> 4, kq = lane & 15;
+                if (tq < ng) {
+                    const int gq = (int)hgi[own0 + g0 + tq];
+                    nsp_l = ex.nspecial[gq];
+                    if (kq < nsp_l) sp_l = ex.special[(size_t)gq * ex.msp + kq];
                 }
-            };
-            auto scan_full = [&](const int cs, const float cx, const float cy, const float cz, const int ctag) {
-                // (two own atoms per packed fp32 instruction - v_pk_add/mul/fma_f32 with the own coordinates as SGPR pairs - was
-                // measured: 307 -> 312 us; the scan is not bound by the number of distance instructions)
+            }
+
+            // one (own atom, 64-candidate batch) step: distance, lane mask straight from the compares (LLVM predicates: 5 = OLE,
+            // 33 = NE), slot of every hit in the atom's LDS row.  No "any hit?" branch: a batch almost always holds one, and
+            // straight-line code lets the chains of the group's atoms overlap.  FULL: all TB_G own atoms present (no branches
+            // at all: 16 independent chains for 4 batches).  Special-bond partners are dropped when the row is written out.
+            // (two own atoms per packed fp32 instruction - v_pk_add/mul/fma_f32 with the own coordinates as SGPR pairs - was
+            // measured: 307 -> 312 us; the scan is not bound by the number of distance instructions)
+            auto scan = [&](auto full, const int cs, const float cx, const float cy, const float cz) {
 #pragma unroll
                 for (int t = 0; t < TB_G; t++) {
-                    {
+                    if (decltype(full)::value || t < ng) {
                         const float dx = ox[t] - cx, dy = oy[t] - cy, dz = oz[t] - cz;
                         const float d = dx * dx + dy * dy + dz * dz;
-                        bool hit = (d <= rc2) & (cs != own0 + g0 + t);
-                        if (EXCL) {
-                            // gpu_filter_exclusion (neigh_build_meso.cu:497-544): drop special partners by tag
-                            const int nsp = ex.nspecial[gi[t]];
-                            for (int sp = 0; sp < nsp; sp++) hit = hit & (ex.special[(size_t)gi[t] * ex.msp + sp] != ctag);
-                        }
-                        // lane mask straight from the compares (LLVM predicates: 5 = OLE, 33 = NE) unless exclusions apply
-                        const u64 m = EXCL ? __builtin_amdgcn_ballot_w64(hit)
-                                           : (__builtin_amdgcn_fcmpf(d, rc2, 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33));
+                        const bool hit = (d <= rc2) & (cs != own0 + g0 + t);
+                        const u64 m = __builtin_amdgcn_fcmpf(d, rc2, 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33);
                         const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
                         if (hit) myrow(t)[min(pos, (u32)(n_col - 1))] = (unsigned short)cs;
                         nrow[t] += __popcll(m);
@@ -388,17 +372,17 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             if (nbatch >= 4 && ng == TB_G && dbg != 3) {
                 // the common case (4 full batches, 4 own atoms) without a single branch: 16 independent chains
 #pragma unroll
-                for (int b = 0; b < 4; b++) scan_full(cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+                for (int b = 0; b < 4; b++) scan(std::true_type{}, cs4[b], cx4[b], cy4[b], cz4[b]);
             } else {
 #pragma unroll
                 for (int b = 0; b < 4; b++)
-                    if (b < nbatch && dbg != 3) scan(cs4[b], cx4[b], cy4[b], cz4[b], ct4[b]);
+                    if (b < nbatch && dbg != 3) scan(std::false_type{}, cs4[b], cx4[b], cy4[b], cz4[b]);
             }
             for (int b = 4; b < nbatch; b++) {
-                int cs, ctag;
+                int cs;
                 float cx, cy, cz;
-                load_cand(b, cs, cx, cy, cz, ctag);
-                scan(cs, cx, cy, cz, ctag);
+                load_cand(b, cs, cx, cy, cz);
+                scan(std::false_type{}, cs, cx, cy, cz);
             }
             // rows out, lane = entry: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become global
             // indices, the tail of the last chunk is padded with the atom itself
@@ -406,16 +390,39 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             for (int t = 0; t < TB_G; t++) {
                 if (t < ng) {
                     const int n = nrow[t], i = gi[t];
-                    if (lane == 0) {
-                        if (n > n_col) atomicMax(overflow, n);
-                        count[i] = min(n, n_col);
-                    }
                     const int nn = dbg == 2 ? 0 : min(n, n_col);
                     int *dst = table + row_word8(i, 0, n_col) * 8;
-                    for (int e = lane; e < ((nn + 7) & ~7); e += 64) {
-                        int val = i;
-                        if (e < nn) val = (int)hgi[myrow(t)[e]];
-                        dst[(size_t)(e >> 3) * 512 + (e & 7)] = val;
+                    int nout = nn;
+                    if (!EXCL) {
+                        for (int e = lane; e < ((nn + 7) & ~7); e += 64) {
+                            int val = i;
+                            if (e < nn) val = (int)hgi[myrow(t)[e]];
+                            dst[(size_t)(e >> 3) * 512 + (e & 7)] = val;
+                        }
+                    } else {
+                        // gpu_filter_exclusion (neigh_build_meso.cu:497-544): special partners are dropped by tag - here, once per
+                        // row ENTRY (the scan tests 6-7 times as many candidates), the atom's special list through v_readlane
+                        const int nsp = __builtin_amdgcn_readlane(nsp_l, t * 16);
+                        const int *spl = ex.special + (size_t)i * ex.msp;
+                        nout = 0;
+                        for (int e0 = 0; e0 < nn; e0 += 64) {
+                            const int e = e0 + lane;
+                            const u32 slot = e < nn ? myrow(t)[e] : 0u;
+                            const int tg = htag[slot];
+                            bool keep = e < nn;
+                            for (int sp = 0; sp < min(nsp, 16); sp++) keep = keep & (__builtin_amdgcn_readlane(sp_l, t * 16 + sp) != tg);
+                            for (int sp = 16; sp < nsp; sp++) keep = keep & (spl[sp] != tg);
+                            const u64 m = __builtin_amdgcn_ballot_w64(keep);
+                            const int pos = nout + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                            if (keep) dst[(size_t)(pos >> 3) * 512 + (pos & 7)] = (int)hgi[slot];
+                            nout += __popcll(m);
+                        }
+                        const int e = nout + lane;
+                        if (e < ((nout + 7) & ~7)) dst[(size_t)(e >> 3) * 512 + (e & 7)] = i;
+                    }
+                    if (lane == 0) {
+                        if (n > n_col) atomicMax(overflow, n);      // (before exclusions: the LDS row holds every hit)
+                        count[i] = nout;
                     }
                 }
             }

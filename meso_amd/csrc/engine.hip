@@ -1401,6 +1401,8 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.all_expw_one = 1;
     p.share = (pair_share && (p.end == nlocal || (p.end & (pair_ring_group() - 1)) == 0)) ? 1 : 0;
     for (int t = 0; t < ntypes * ntypes; t++) p.all_expw_one &= coeff[(size_t)t * 7 + 3] == 1.0 ? 1 : 0;
+    p.uniform_cut = 1;
+    for (int t = 0; t < ntypes * ntypes; t++) p.uniform_cut &= coeff[(size_t)t * 7 + P_CUT] == coeff[P_CUT] ? 1 : 0;
     // two kernels: the ring kernel (both styles) and the lane-per-atom kernel that also books energy and virial
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
     else launch_pair_dpd_ring(p, pair_style, stream);

@@ -137,6 +137,7 @@ struct PairArgs {
     int debug;            // timing ablations only (0 in production): 1 stop after halo copy, 2 skip phase B
     int nall;             // atoms in coord4/veloc4 (locals + ghosts): bound of the buffer-addressed gathers
     int all_expw_one;     // every pair type has weight exponent 1 (no pow() in the kernel)
+    int uniform_cut;      // every pair type has the cutoff of cf1 (the cutoff test needs no table)
     const float *ftab;    // dpd/tableforce/meso: [ntypes^2][ftab_len] conservative-force tables over r/rc in [0,1]; null otherwise
     int ftab_len;
     const float *poly;    // dpd/polyforce/meso: [ntypes^2][MESO_POLY_PITCH] conservative-force polynomials; null otherwise

@@ -53,26 +53,34 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 // EW1: every pair type has weight exponent s = 1 (the usual DPD choice): w_R = w_C, no pow()
 // FAST: dpd/fast/meso (fp32 arithmetic, contracted); otherwise dpd/meso (fp64 arithmetic on the fp32 operands through the
 // uncontracted functions of meso_device.h, 36-fractional-bit fixed-point sums)
-template <bool FAST, bool NT1, bool EW1, bool SHARE, int NPART>
+// TY: 0 one atom type (coefficients are kernel-argument constants), 1 several types with ONE cutoff (the cutoff test stays scalar),
+// 2 several types, cutoff per type pair
+template <bool FAST, int TY, bool EW1, bool SHARE, int NPART>
 __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
     extern __shared__ double smem[];
     float *cf32 = (float *)smem;
     double *cf64 = smem;
-    const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * N_COEFF;
+    constexpr bool NT1 = TY == 0, UCUT = TY <= 1;
+    // fp32 style: rows of 8 floats (a0, gamma, sigma, s | 1/rc, rc^2, rc, -): one 16-byte LDS read per evaluated pair
+    constexpr int CFP = FAST ? 8 : N_COEFF;
+    const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * CFP;
     for (int p = threadIdx.x; p < ncf; p += blockDim.x) {
-        if (FAST) cf32[p] = a.coeff32[p];
-        else cf64[p] = a.coeff64[p];
+        if (FAST) {
+            const int src[8] = {P_A0, P_GAMMA, P_SIGMA, P_EXPW, P_CUTINV, P_CUTSQ, P_CUT, P_CUT};
+            cf32[p] = a.coeff32[(p >> 3) * N_COEFF + src[p & 7]];
+        } else cf64[p] = a.coeff64[p];
     }
     const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16;
+    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (NT1 ? 0 : RG_RING);
     u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
     char *wb = (char *)smem + off + 3 * 64 * RG_WAVES * 8 + (size_t)w * per_wave;      // (accumulator area sized for NPART = 1)
     float4 *own_c = (float4 *)wb;
     float4 *own_v = own_c + 64;
     float4 *ring = own_v + 64;          // (partner x, y, z, record word): the coordinate is not gathered twice
+    unsigned char *ringt = (unsigned char *)(ring + RG_RING);     // several types: the partner's type next to its record
 
     const int nbk = gridDim.x;
     const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
@@ -125,8 +133,10 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                         c_cutinv = (float)a.cf1[P_CUTINV]; c_ew = (float)a.cf1[P_EXPW]; c_a0 = (float)a.cf1[P_A0];
                         c_gamma = (float)a.cf1[P_GAMMA]; c_sigma = (float)a.cf1[P_SIGMA];
                     } else {
-                        const float *cf = cf32 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * N_COEFF;
-                        c_cutinv = cf[P_CUTINV]; c_ew = cf[P_EXPW]; c_a0 = cf[P_A0]; c_gamma = cf[P_GAMMA]; c_sigma = cf[P_SIGMA];
+                        const float *cf = cf32 + (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * 8;
+                        const float4 cq = *(const float4 *)cf;
+                        c_a0 = cq.x; c_gamma = cq.y; c_sigma = cq.z; c_ew = cq.w;
+                        c_cutinv = UCUT ? (float)a.cf1[P_CUTINV] : cf[4];
                     }
                     const float dx = ci.x - pc2.x, dy = ci.y - pc2.y, dz = ci.z - pc2.z;
                     const float rsq = dx * dx + dy * dy + dz * dz;
@@ -181,7 +191,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
             pe = __float_as_uint(rec.w);
             pc2 = make_float4(rec.x, rec.y, rec.z, 0.f);
             const u32 joff = (pe & RG_INDEX_MASK) << 4;
-            if (!NT1) pc2.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, (int)joff + 12, 0, 0));   // partner type
+            if (!NT1) pc2.w = __uint_as_float((u32)ringt[(qhead + lane) & (RG_RING - 1)]);     // (a fourth gather per hit before)
             pv2 = buf_load4(rv, joff);
         }
         pn = nb;
@@ -225,17 +235,20 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
             if (FAST) {
                 const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
                 const float rsq = dx * dx + dy * dy + dz * dz;
-                const float cutsq = NT1 ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
+                const float cutsq = UCUT ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * 8 + 5];
                 m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) & usem[q];
                 hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & use[q];
             } else {
                 const double rsq = rsq_f64(c1, c2[q]);
-                const double cutsq = NT1 ? a.cf1[P_CUTSQ] : cf64[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
+                const double cutsq = UCUT ? a.cf1[P_CUTSQ] : cf64[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
                 m = __builtin_amdgcn_fcmp(rsq, cutsq, 4) & __builtin_amdgcn_fcmp(rsq, MESO_EPSILON_SQ, 3) & usem[q];
                 hit = (rsq < cutsq) & (rsq >= MESO_EPSILON_SQ) & use[q];
             }
-            if (hit) ring[__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1)] =
-                    make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float((u32)j[q] | ((SHARE && shb[q]) ? lanehi | RG_SHARED_BIT : lanehi)));   // record word last
+            if (hit) {
+                const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1);
+                ring[pos] = make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float((u32)j[q] | ((SHARE && shb[q]) ? lanehi | RG_SHARED_BIT : lanehi)));   // record word last
+                if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(c2[q].w);
+            }
             qtail += __popcll(m);
             if (q & 1) {
                 while (qtail - qhead >= 64) { compute(); issue(64); }
@@ -264,8 +277,9 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     int n = p.end - p.beg;
     if (n <= 0) return;
     const bool nt1 = p.ntypes == 1;
-    size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * N_COEFF * (fast ? 4 : 8);
-    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
+    if (p.ntypes > 255) { fprintf(stderr, "meso: the force kernel keeps atom types in 8 bits (ntypes <= 255)\n"); abort(); }
+    size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * (fast ? 8 * 4 : N_COEFF * 8);
+    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (nt1 ? 0 : RG_RING) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
     // small launches: 2 lanes per atom, so that the same atoms fill twice as many waves (a 32^3 box is 2048 waves for 1024
     // SIMDs otherwise, and each wave walks 7 row chunks and ~11 hit batches one after the other)
@@ -291,20 +305,23 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
         else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2>), grid, block, sm, s, p);       \
         else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1>), grid, block, sm, s, p);                       \
     } while (0)
+#define RG_TYPES(F, B, C)                                      \
+    do {                                                       \
+        if (nt1) RG_LAUNCH(F, 0, B, C);                        \
+        else if (p.uniform_cut) RG_LAUNCH(F, 1, B, C);         \
+        else RG_LAUNCH(F, 2, B, C);                            \
+    } while (0)
 #define RG_PICK(F)                                        \
     if (share) {                                          \
-        if (nt1 && ew1) RG_LAUNCH(F, true, true, true);   \
-        else if (nt1) RG_LAUNCH(F, true, false, true);    \
-        else if (ew1) RG_LAUNCH(F, false, true, true);    \
-        else RG_LAUNCH(F, false, false, true);            \
+        if (ew1) RG_TYPES(F, true, true);                 \
+        else RG_TYPES(F, false, true);                    \
     } else {                                              \
-        if (nt1 && ew1) RG_LAUNCH(F, true, true, false);  \
-        else if (nt1) RG_LAUNCH(F, true, false, false);   \
-        else if (ew1) RG_LAUNCH(F, false, true, false);   \
-        else RG_LAUNCH(F, false, false, false);           \
+        if (ew1) RG_TYPES(F, true, false);                \
+        else RG_TYPES(F, false, false);                   \
     }
     if (fast) { RG_PICK(true) } else { RG_PICK(false) }
 #undef RG_PICK
+#undef RG_TYPES
 #undef RG_LAUNCH
 }
 
