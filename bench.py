@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="multi-rank transport: rccl (production) or host (gloo point-to-point through host buffers: lets several "
                          "ranks share one GPU, for rehearsing the multi-process flow on a one-GPU box)")
+    ap.add_argument("--special-12", type=float, default=0.0, help="--polymer: special_bonds weight of bonded neighbours (1.0: no exclusions; timing ablation)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     return ap.parse_args()
 
@@ -192,7 +193,7 @@ def main():
     else:
         # configs[4] (build-defined deck): amphiphilic A2B4 chains, harmonic bonds k = 50, r0 = 0.5, a_AB = 40
         m.read_atoms(x, v, lo, hi, types=types, ntypes=2)
-        m.special_bonds(0.0, 1.0, 1.0)
+        m.special_bonds(a.special_12, 1.0, 1.0)
         m.read_bonds(bonds)
         m.bond_style("harmonic/meso", 1)
         m.bond_coeff(1, 50.0, 0.5)
