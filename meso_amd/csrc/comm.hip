@@ -176,7 +176,15 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
             const LocalPost &src = local->post[peer[k]];
             const void *from = nullptr;
             for (int q = 0; q < src.npeer; q++)
-                if (src.peer[q] == rank) { from = src.sbuf[q]; if (src.sbytes[q] != rbytes[k]) return fail(5, "local transport: size mismatch"); }
+                if (src.peer[q] == rank) {
+                    from = src.sbuf[q];
+                    if (src.sbytes[q] != rbytes[k]) {
+                        char msg[160];
+                        snprintf(msg, sizeof msg, "local transport: size mismatch in the %s exchange (rank %d sends %zu bytes, rank %d expects %zu)",
+                                 xchg_what, peer[k], src.sbytes[q], rank, rbytes[k]);
+                        return fail(5, msg);
+                    }
+                }
             if (!from) return fail(5, "local transport: peer did not post a message");
             HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k], hipMemcpyDeviceToDevice, stream));
         }
@@ -483,28 +491,45 @@ void Engine::build_peer_tables()
     }
 }
 
-// counts[d] (my direction-major segments) -> per-peer send counts, exchange, per-peer/per-direction recv counts
-int Engine::exchange_counts(const int *dir_count, std::vector<int> &send_n, std::vector<int> &recv_n,
+// per-peer count messages straight from the device-side direction starts: row p holds the sizes of the directions that go to
+// peer p (27 ints each; skip_stay: direction 13 is the atoms that stay)
+struct PeerIndex27 { int p[27]; };
+__global__ void __launch_bounds__(64) k_counts_to_peers(const int *__restrict__ dir_start, PeerIndex27 pi, int np, int skip_stay,
+                                                        int *__restrict__ sendv)
+{
+    for (int k = threadIdx.x; k < np * 27; k += blockDim.x) {
+        const int p = k / 27, d = k - 27 * p;
+        sendv[k] = (pi.p[d] == p && !(skip_stay && d == 13)) ? dir_start[d + 1] - dir_start[d] : 0;
+    }
+}
+
+// Sizes of my direction-major segments (d_dir_start, still on the device) -> per-peer counts, exchanged device to device; ONE
+// host round trip then delivers my own direction starts (h_ds[28]), the counts the peers announced and whatever else the caller
+// queued for the host before (comm_meso.cu:136-137 is the count swap this replaces)
+int Engine::exchange_counts(int skip_stay, int *h_ds, std::vector<int> &send_n, std::vector<int> &recv_n,
                             std::vector<int> &recv_dir /* np*27 */)
 {
     int np = (int)peers.size();
-    std::vector<int> sendv((size_t)np * 27, 0);
-    send_n.assign(np, 0);
-    for (int d = 0; d < 27; d++) {
-        int p = peer_index[d];
-        if (p < 0) continue;
-        sendv[(size_t)p * 27 + d] = dir_count[d];
-        send_n[p] += dir_count[d];
-    }
     int *dbuf = sendlist_aux;   // device scratch: 2 * np * 27 ints
-    HIPCHK(hipMemcpyAsync(dbuf, sendv.data(), sendv.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    PeerIndex27 pi;
+    for (int d = 0; d < 27; d++) pi.p[d] = d == 13 ? -1 : peer_index[d];
+    if (np > 0) hipLaunchKernelGGL(k_counts_to_peers, dim3(1), dim3(64), 0, stream, d_dir_start, pi, np, skip_stay, dbuf);
     std::vector<void *> sb(np), rb(np);
     std::vector<size_t> nb(np, 27 * sizeof(int));
     for (int p = 0; p < np; p++) { sb[p] = dbuf + (size_t)p * 27; rb[p] = dbuf + (size_t)(np + p) * 27; }
+    xchg_what = "count";
     TRY(xchg(np, peers.data(), sb.data(), nb.data(), rb.data(), nb.data()));
     recv_dir.assign((size_t)np * 27, 0);
-    HIPCHK(hipMemcpyAsync(recv_dir.data(), dbuf + (size_t)np * 27, recv_dir.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (np > 0) HIPCHK(hipMemcpyAsync(recv_dir.data(), dbuf + (size_t)np * 27, recv_dir.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    for (int k = 0; k < 28; k++) h_ds[k] = h_flags[16 + k];
+    send_n.assign(np, 0);
+    for (int d = 0; d < 27; d++) {
+        if (d == 13 && skip_stay) continue;
+        int p = d == 13 ? -1 : peer_index[d];
+        if (p >= 0) send_n[p] += h_ds[d + 1] - h_ds[d];
+    }
     recv_n.assign(np, 0);
     for (int p = 0; p < np; p++)
         for (int d = 0; d < 27; d++) recv_n[p] += recv_dir[(size_t)p * 27 + d];
@@ -554,20 +579,16 @@ int Engine::migrate()
     } else {
         HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
     }
-    HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    // one host round trip: the "lost atoms" flag, my direction starts and the counts the peers announce arrive together
     HIPCHK(hipMemcpyAsync(h_flags + 3, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    if (h_flags[3]) return fail(5, "Atoms moved further than one sub-domain between rebuilds (lost atoms)");
     int ds[28], cnt[27];
-    for (int k = 0; k < 28; k++) ds[k] = h_flags[16 + k];
+    std::vector<int> send_n, recv_n, recv_dir;
+    TRY(exchange_counts(1, ds, send_n, recv_n, recv_dir));
+    if (h_flags[3]) return fail(5, "Atoms moved further than one sub-domain between rebuilds (lost atoms)");
     for (int d = 0; d < 27; d++) cnt[d] = ds[d + 1] - ds[d];
     int nstay = cnt[13];
-    int cnt_send[27];
-    for (int d = 0; d < 27; d++) cnt_send[d] = (d == 13) ? 0 : cnt[d];
     for (int d = 0; d < 27; d++)
         if (d != 13 && cnt[d] && peer_index[d] < 0) return fail(5, "Atom left the box through a non-periodic boundary");
-    std::vector<int> send_n, recv_n, recv_dir;
-    TRY(exchange_counts(cnt_send, send_n, recv_n, recv_dir));
     int np = (int)peers.size(), nsend_tot = 0, nrecv_tot = 0;
     std::vector<int> sbase(np, 0), rbase(np, 0);
     for (int p = 0; p < np; p++) { sbase[p] = nsend_tot; nsend_tot += send_n[p]; rbase[p] = nrecv_tot; nrecv_tot += recv_n[p]; }
@@ -606,6 +627,7 @@ int Engine::migrate()
         sb[p] = (double *)stage_send + (size_t)ms * sbase[p]; sn[p] = (size_t)send_n[p] * ms * sizeof(double);
         rb[p] = (double *)stage_recv + (size_t)ms * rbase[p]; rn[p] = (size_t)recv_n[p] * ms * sizeof(double);
     }
+    xchg_what = "migration";
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
     if (nrecv_tot > 0)
         hipLaunchKernelGGL(k_unpack_migrate, dim3((nrecv_tot + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
@@ -619,27 +641,28 @@ int Engine::migrate()
 int Engine::halo_borders_multi()
 {
     tbegin("halo");
-    int beg = n_bulk, end = nlocal;
+    // (bulk_pending: the reorder left the bulk count on its way to the host - the scan then covers every local atom, bulk atoms
+    // carry no border flags, and the count arrives with the round trip below)
+    int beg = bulk_pending ? 0 : n_bulk, end = nlocal;
     int nchunk = (end - beg + 255) / 256;
-    for (int k = 0; k < 28; k++) h_dir_start[k] = 0;
     if (nchunk > 0) {
         launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
         HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
         launch_dir_starts(chunk_offset, nchunk, d_dir_start, stream);
-        HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];
     } else {
         HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
     }
-    nsend = h_dir_start[27];
-    int cnt[27];
-    for (int d = 0; d < 27; d++) {
-        cnt[d] = h_dir_start[d + 1] - h_dir_start[d];
-        if (cnt[d] && peer_index[d] < 0) return fail(5, "border list for an inactive direction");
-    }
+    // one host round trip for my direction starts and the peers' counts (the counts go device to device)
     std::vector<int> recv_dir;
-    TRY(exchange_counts(cnt, peer_send_n, peer_recv_n, recv_dir));
+    TRY(exchange_counts(0, h_dir_start, peer_send_n, peer_recv_n, recv_dir));
+    if (bulk_pending) {
+        bulk_pending = false;
+        if (h_flags[0]) return check_overflow();
+        n_bulk = h_flags[1];
+    }
+    nsend = h_dir_start[27];
+    for (int d = 0; d < 27; d++)
+        if (h_dir_start[d + 1] - h_dir_start[d] && peer_index[d] < 0) return fail(5, "border list for an inactive direction");
     int np = (int)peers.size();
     peer_send_base.assign(np, 0); peer_recv_base.assign(np + 1, 0);
     int stot = 0, rtot = 0;
@@ -672,6 +695,7 @@ int Engine::halo_borders_multi()
         sb[p] = (double *)stage_send + 5 * (size_t)peer_send_base[p]; sn[p] = (size_t)peer_send_n[p] * 5 * sizeof(double);
         rb[p] = (double *)stage_recv + 5 * (size_t)peer_recv_base[p]; rn[p] = (size_t)peer_recv_n[p] * 5 * sizeof(double);
     }
+    xchg_what = "border";
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
     if (nghost > 0)
         hipLaunchKernelGGL(k_unpack_border, dim3((nghost + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
@@ -714,6 +738,7 @@ int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
     HIPCHK(hipEventRecord(ev_pack, stream));
     HIPCHK(hipStreamWaitEvent(side, ev_pack, 0));
     xs = side;
+    xchg_what = "ghost refresh";
     int rc = xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data());
     xs = nullptr;
     if (rc) return rc;

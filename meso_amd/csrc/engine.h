@@ -135,7 +135,7 @@ private:
     double reduce_global_sum(double v);
     // multi-rank (comm.hip)
     int xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf, const size_t *rbytes);
-    int exchange_counts(const int *dir_count, std::vector<int> &send_n, std::vector<int> &recv_n, std::vector<int> &recv_dir);
+    int exchange_counts(int skip_stay, int *h_ds, std::vector<int> &send_n, std::vector<int> &recv_n, std::vector<int> &recv_dir);
     void build_peer_tables();
     int halo_borders_multi();
     int halo_forward_multi_begin(uint32_t seed, bool async);
@@ -168,6 +168,7 @@ private:
     void *stage_send = nullptr, *stage_recv = nullptr;
     size_t stage_send_bytes = 0, stage_recv_bytes = 0;
     int *sendlist_aux = nullptr;
+    const char *xchg_what = "ghost refresh";     // names the exchange in transport error messages
     DirTab *fwd_tab = nullptr;
     hipStream_t xs = nullptr;       // stream used by xchg (nullptr: the main stream)
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
@@ -273,6 +274,7 @@ private:
     bool permute_forces = true;     // the reorder carries the forces along (not needed for the rebuilds inside run())
     bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
     double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)
+    bool regrow_only = false;       // init_params re-run for a larger brick stage on this rank alone (no collective)
     double brick_margin_auto = 1.0; // grown by the engine when the fullest brick neighbourhood comes close to the capacity
     size_t estart_cap = 0;
     BrickArgs bargs{};

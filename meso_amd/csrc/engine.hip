@@ -945,7 +945,9 @@ int Engine::init_params()
     }
     HIPCHK(hipMemcpy(d_mass_type, mass_type.data(), mass_type.size() * sizeof(double), hipMemcpyHostToDevice));
     launch_unpack_mass(cur.type, d_mass_type, ntypes, cur.mass, 0, nlocal, stream);
-    natoms_total = (long)reduce_global_sum((double)nlocal);
+    // (a capacity regrowth re-runs this on the ranks that need it only: no collective then - the atom count is conserved)
+    if (!regrow_only || natoms_total == 0) natoms_total = (long)reduce_global_sum((double)nlocal);
+    regrow_only = false;
     params_ready = true;
     return 0;
 }
@@ -1003,7 +1005,7 @@ int Engine::reorder_locals()
     std::swap(cur, alt);
     if (!(nranks == 1 && async_ok())) HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
-    if (nranks == 1 && (nlocal <= 524288 || async_ok())) {
+    if ((nranks == 1 && (nlocal <= 524288 || async_ok())) || (nranks > 1 && nlocal <= 524288)) {
         // one rank, small box: the ghost-list pass below scans every local atom (bulk atoms have no flags), so the bulk
         // count is not needed yet; it arrives with that pass's own host round trip - one synchronisation per rebuild,
         // not two (+4 % at 25^3-32^3; above ~0.5 M atoms the longer scan costs more than the round trip).  With
@@ -1312,6 +1314,7 @@ int Engine::reneighbor()
         if (params_ready && neigh_kernel == 1 && (long)hwm * 100 > (long)bargs.maxh * 93) {
             brick_margin_auto *= 1.12;
             params_ready = false;
+            regrow_only = true;
             h_flags[5] = h_flags[10] = 0;
             HIPCHK(hipMemsetAsync(d_flags + 5, 0, sizeof(int), stream));
         }
@@ -1452,10 +1455,15 @@ int Engine::setup()
         // (polymer decks) gets a larger stage and a second build instead of an error
         HIPCHK(hipMemcpyAsync(h_flags, d_flags, 6 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        if (h_flags[0] < 100000 || h_flags[0] >= 200000 || attempt >= 8) break;
-        brick_margin_auto *= std::max(1.1, 1.08 * (h_flags[0] - 100000) / (double)bargs.maxh);
-        params_ready = false;
-        HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+        const bool grow = h_flags[0] >= 100000 && h_flags[0] < 200000 && attempt < 8;
+        // (the rebuild exchanges atoms and ghosts: every rank repeats it when one has to)
+        if (reduce_global_sum(grow ? 1.0 : 0.0) == 0.0) break;
+        if (grow) {
+            brick_margin_auto *= std::max(1.1, 1.08 * (h_flags[0] - 100000) / (double)bargs.maxh);
+            params_ready = false;
+            regrow_only = true;
+            HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+        }
     }
     nbuild = 0;
     if (restart_forces) {

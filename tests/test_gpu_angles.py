@@ -3,6 +3,7 @@ neighbor_meso.cu:161-182) against the CPU oracle, on one rank and decomposed ove
 import threading
 
 import numpy as np
+from conftest import join_ranks
 import pytest
 
 from meso_amd.datagen import chain_angles, make_polymer_box
@@ -122,9 +123,9 @@ def test_angles_survive_decomposition():
                 m.close()
             except Exception as e:   # noqa: BLE001
                 errs.append((r, repr(e)))
-        th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nranks)]
         [t.start() for t in th]
-        [t.join(timeout=300) for t in th]
+        join_ranks(th, errs, 300)
         assert not errs, errs
         return out
 
@@ -168,9 +169,9 @@ def test_a_partner_outside_the_ghost_shell_is_reported():
         except MesoError as e:
             errs[r] = str(e)
         m.close()
-    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(2)]
     [t.start() for t in th]
-    [t.join(timeout=120) for t in th]
+    join_ranks(th, errs, 120)
     assert any(e and "missing" in e for e in errs), errs
 
 

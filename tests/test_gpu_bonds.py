@@ -3,6 +3,7 @@ the CPU oracle, on one rank and decomposed over 8 ranks of one GPU."""
 import threading
 
 import numpy as np
+from conftest import join_ranks
 import pytest
 
 from meso_amd.datagen import make_polymer_box
@@ -141,9 +142,9 @@ def test_chains_survive_decomposition():
                 m.close()
             except Exception as e:   # noqa: BLE001
                 errs.append((r, repr(e)))
-        th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nranks)]
         [t.start() for t in th]
-        [t.join(timeout=300) for t in th]
+        join_ranks(th, errs, 300)
         assert not errs, errs
         return out
 

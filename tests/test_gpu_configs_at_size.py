@@ -10,6 +10,7 @@ test_gpu_multirank.py / test_gpu_bonds.py."""
 import threading
 
 import numpy as np
+from conftest import join_ranks
 import pytest
 
 from meso_amd.datagen import make_box, make_polymer_box
@@ -74,7 +75,7 @@ def _ranks(nranks, grid, deck, style, steps, sigma=3.0, want=("setup", "end"), s
 
     th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nranks)]
     [t.start() for t in th]
-    [t.join(timeout=timeout) for t in th]
+    join_ranks(th, errs, timeout)
     assert not errs, errs
     assert all(o is not None for o in out), "a rank did not finish"
 

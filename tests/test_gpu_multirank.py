@@ -6,6 +6,8 @@ differs).  Decomposition invariance is the property the reference's TEA signatur
 import threading
 
 import numpy as np
+import torch  # noqa: F401  (before libmeso_hip.so is loaded: torch ships its own HIP runtime, and the one loaded first serves both)
+from conftest import join_ranks
 import pytest
 
 from meso_amd.datagen import make_box
@@ -40,9 +42,9 @@ def _run_ranks(nranks, grid, L, style, sigma, steps, every=5, overlap=1):
         except Exception as e:   # noqa: BLE001
             errs.append((r, repr(e)))
 
-    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nranks)]
     [t.start() for t in th]
-    [t.join(timeout=300) for t in th]
+    join_ranks(th, errs, 300)
     assert not errs, errs
     assert all(o is not None for o in out), "a rank did not finish"
 

@@ -5,6 +5,7 @@ positions round differently in the fp32 merged coordinates once setup has wrappe
 import threading
 
 import numpy as np
+from conftest import join_ranks
 import pytest
 
 from meso_amd.datagen import chain_angles, make_box, make_polymer_box
@@ -115,9 +116,9 @@ def test_restart_over_two_ranks(tmp_path):
         m.close()
 
     for phase in (0, 1):
-        th = [threading.Thread(target=work, args=(r, phase)) for r in range(2)]
+        th = [threading.Thread(target=work, args=(r, phase), daemon=True) for r in range(2)]
         [t.start() for t in th]
-        [t.join(timeout=200) for t in th]
+        join_ranks(th, None, 200)
     assert (tmp_path / "two.rst.0").exists() and (tmp_path / "two.rst.1").exists()
 
     def by_tag(phase):
@@ -161,9 +162,9 @@ def test_two_rank_restart_between_rebuilds_keeps_migrant_forces(tmp_path):
         m.close()
 
     for phase in (0, 1):
-        th = [threading.Thread(target=work, args=(r, phase)) for r in range(2)]
+        th = [threading.Thread(target=work, args=(r, phase), daemon=True) for r in range(2)]
         [t.start() for t in th]
-        [t.join(timeout=200) for t in th]
+        join_ranks(th, None, 200)
 
     def by_tag(phase):
         tag = np.concatenate([out[phase, r][3] for r in range(2)])
