@@ -69,6 +69,14 @@ int meso_comm_init(meso_ctx *ctx, int nranks, int rank, const int procgrid[3], i
 int meso_comm_get_unique_id(void *uid, size_t uid_bytes);
 /* brick processor grid of minimal surface for the box (Comm::set_procs, src/comm.cpp); host only, no GPU needed */
 int meso_decomp_procgrid(int nranks, const double prd[3], int procgrid[3]);
+/* the decomposition rank `rank` (x fastest in the grid) works with - sub-box (Domain::set_local_box, src/domain.cpp), slabs within
+ * cutghost of the faces that have a neighbour, and per direction dir = (sx+1) + 3(sy+1) + 9(sz+1): owner of the neighbouring sub-box,
+ * whether anything is sent that way, the periodic shift applied on the way and the centre of the neighbour's sub-box
+ * (Comm::setup, src/comm.cpp; MesoComm::borders comm_meso.cu:41-186 walks the same table).  The engine uses this very function;
+ * host only, no GPU needed */
+int meso_decomp_plan(const double boxlo[3], const double boxhi[3], const int periodic[3], const int procgrid[3], int rank,
+                     double cutghost, double sublo[3], double subhi[3], double slab_lo[3], double slab_hi[3], int peer27[27],
+                     int active27[27], double shift27[81], double center27[81]);
 /* ranks the transport really connects: ncclCommCount for RCCL (bench.py's n_ranks_seen), the configured count otherwise */
 int meso_comm_count(meso_ctx *ctx, int *nranks_seen);
 /* host-staged transport (tests: several ranks sharing one GPU): exchange(user, npeer, peer[], sendbuf[],

@@ -30,6 +30,7 @@ SIGNATURES = {
     "meso_comm_init": (_i, [_vp, _i, _i, _vp, _i, _vp, _sz]),
     "meso_comm_get_unique_id": (_i, [_vp, _sz]),
     "meso_decomp_procgrid": (_i, [_i, _vp, _vp]),
+    "meso_decomp_plan": (_i, [_vp, _vp, _vp, _vp, _i, _d] + [_vp] * 8),
     "meso_comm_count": (_i, [_vp, C.POINTER(_i)]),
     "meso_membw_probe": (_i, [_vp, _sz, _i, C.POINTER(_d)]),
     "meso_comm_set_host_exchange": (_i, [_vp, HOST_EXCHANGE_FN, _vp]),

@@ -36,6 +36,22 @@ def procgrid(nranks, prd):
     return tuple(int(v) for v in out)
 
 
+def decomp_plan(lo, hi, grid, rank, cutghost, periodic=(1, 1, 1)):
+    """The engine's own decomposition tables for `rank` of a brick grid (host-only helper; no GPU needed): dict with sublo,
+    subhi, slab_lo, slab_hi (3), peer, active (27), shift, center (27, 3); direction d = (sx+1) + 3(sy+1) + 9(sz+1)."""
+    lib = _lib.load()
+    lo = np.ascontiguousarray(lo, np.float64); hi = np.ascontiguousarray(hi, np.float64)
+    per = np.ascontiguousarray(periodic, np.int32); pg = np.ascontiguousarray(grid, np.int32)
+    out = {k: np.zeros(3) for k in ("sublo", "subhi", "slab_lo", "slab_hi")}
+    out["peer"] = np.zeros(27, np.int32); out["active"] = np.zeros(27, np.int32)
+    out["shift"] = np.zeros((27, 3)); out["center"] = np.zeros((27, 3))
+    if lib.meso_decomp_plan(_p(lo), _p(hi), _p(per), _p(pg), int(rank), float(cutghost), _p(out["sublo"]), _p(out["subhi"]),
+                            _p(out["slab_lo"]), _p(out["slab_hi"]), _p(out["peer"]), _p(out["active"]), _p(out["shift"]),
+                            _p(out["center"])):
+        raise MesoError(lib.meso_last_error().decode())
+    return out
+
+
 def nccl_unique_id():
     """128-byte RCCL unique id (call on rank 0, broadcast to the other ranks)."""
     lib = _lib.load()

@@ -111,6 +111,21 @@ int meso_decomp_procgrid(int nranks, const double prd[3], int procgrid[3])
     return MESO_OK;
 }
 
+int meso_decomp_plan(const double boxlo[3], const double boxhi[3], const int periodic[3], const int procgrid[3], int rank,
+                     double cutghost, double sublo[3], double subhi[3], double slab_lo[3], double slab_hi[3], int peer27[27],
+                     int active27[27], double shift27[81], double center27[81])
+{
+    if (!boxlo || !boxhi || !periodic || !procgrid || !sublo || !subhi || !slab_lo || !slab_hi || !peer27 || !active27 || !shift27 || !center27)
+        return set_err(MESO_ERR_ARG, "invalid decomposition-plan arguments");
+    const int n = procgrid[0] * procgrid[1] * procgrid[2];
+    if (procgrid[0] < 1 || procgrid[1] < 1 || procgrid[2] < 1 || rank < 0 || rank >= n) return set_err(MESO_ERR_ARG, "rank outside the processor grid");
+    // rank -> grid location, x fastest (what meso_comm_init assumes)
+    const int myloc[3] = {rank % procgrid[0], (rank / procgrid[0]) % procgrid[1], rank / (procgrid[0] * procgrid[1])};
+    if (meso::decomp_plan(boxlo, boxhi, periodic, procgrid, myloc, cutghost, sublo, subhi, slab_lo, slab_hi, peer27, active27, shift27, center27))
+        return set_err(MESO_ERR_ARG, "Sub-domain smaller than the ghost cutoff is not supported");
+    return MESO_OK;
+}
+
 int meso_comm_set_host_exchange(meso_ctx *ctx, meso_host_exchange_fn fn, void *user)
 {
     CTX(ctx);

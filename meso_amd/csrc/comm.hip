@@ -92,6 +92,47 @@ void decomp_procgrid(int nranks, const double *prd, int *pg)
     }
 }
 
+// The decomposition a rank works with (Comm::setup / Domain::set_local_box, src/comm.cpp, src/domain.cpp): its sub-box, the
+// slabs within cutghost of the faces that have a neighbour, and for each of the 26 directions (dir = (sx+1) + 3(sy+1) + 9(sz+1)) the
+// rank that owns the neighbouring sub-box, the periodic shift an atom gets on the way there and the centre of that sub-box (the
+// origin of the receiver's fp32 coordinates).  Host only; returns 1 when a sub-box is thinner than the ghost cutoff.
+int decomp_plan(const double *boxlo, const double *boxhi, const int *periodic, const int *procgrid, const int *myloc, double cutghost,
+                double *sublo, double *subhi, double *slab_lo, double *slab_hi, int *peer27, int *active27, double *shift27,
+                double *center27)
+{
+    const double BIG = 1.0e20;
+    double prd[3];
+    for (int d = 0; d < 3; d++) prd[d] = boxhi[d] - boxlo[d];
+    for (int d = 0; d < 3; d++) {
+        sublo[d] = boxlo[d] + prd[d] * myloc[d] / procgrid[d];
+        subhi[d] = (myloc[d] == procgrid[d] - 1) ? boxhi[d] : boxlo[d] + prd[d] * (myloc[d] + 1) / procgrid[d];
+        if (subhi[d] - sublo[d] < cutghost) return 1;
+        bool has_lo = periodic[d] || myloc[d] > 0, has_hi = periodic[d] || myloc[d] < procgrid[d] - 1;
+        slab_lo[d] = has_lo ? sublo[d] + cutghost : -BIG;
+        slab_hi[d] = has_hi ? subhi[d] - cutghost : BIG;
+    }
+    for (int dir = 0; dir < 27; dir++) {
+        int s[3] = {dir % 3 - 1, (dir / 3) % 3 - 1, dir / 9 - 1};
+        bool active = dir != 13;
+        int loc[3];
+        for (int d = 0; d < 3; d++) {
+            shift27[3 * dir + d] = 0.0;
+            loc[d] = myloc[d] + s[d];
+            if (loc[d] < 0 || loc[d] >= procgrid[d]) {
+                if (!periodic[d]) active = false;
+                shift27[3 * dir + d] = -s[d] * prd[d];
+                loc[d] = (loc[d] + procgrid[d]) % procgrid[d];
+            }
+            double lo = boxlo[d] + prd[d] * loc[d] / procgrid[d];
+            double hi = (loc[d] == procgrid[d] - 1) ? boxhi[d] : boxlo[d] + prd[d] * (loc[d] + 1) / procgrid[d];
+            center27[3 * dir + d] = 0.5 * (hi + lo);
+        }
+        active27[dir] = active ? 1 : 0;
+        peer27[dir] = loc[0] + procgrid[0] * (loc[1] + procgrid[1] * loc[2]);
+    }
+    return 0;
+}
+
 int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *uid, size_t uid_bytes)
 {
     if (nr < 1 || rk < 0 || rk >= nr) return fail(1, "Invalid rank layout");

@@ -324,6 +324,9 @@ private:
 
 int comm_unique_id(void *uid, size_t uid_bytes);
 void decomp_procgrid(int nranks, const double *prd, int *pg);
+int decomp_plan(const double *boxlo, const double *boxhi, const int *periodic, const int *procgrid, const int *myloc, double cutghost,
+                double *sublo, double *subhi, double *slab_lo, double *slab_hi, int *peer27, int *active27, double *shift27,
+                double *center27);
 int script_run(Engine &E, const char *path, const char *var_name, const char *var_value, std::string &out);
 
 } // namespace meso

@@ -805,33 +805,13 @@ int Engine::init_params()
     cutghost = cutmax + skin;
     const double cutneighmax = cutmax + skin;
 
-    for (int d = 0; d < 3; d++) {
-        sublo[d] = boxlo[d] + prd[d] * myloc[d] / procgrid[d];
-        subhi[d] = (myloc[d] == procgrid[d] - 1) ? boxhi[d] : boxlo[d] + prd[d] * (myloc[d] + 1) / procgrid[d];
-        if (subhi[d] - sublo[d] < cutghost)
+    {
+        // sub-box, border slabs and the 26 neighbours (rank, periodic shift, centre of its sub-box): decomp_plan (comm.hip), the
+        // same host function the C ABI exports as meso_decomp_plan for the CPU-side decomposition tests
+        int act[27];
+        if (decomp_plan(boxlo, boxhi, periodic, procgrid, myloc, cutghost, sublo, subhi, slab_lo, slab_hi, peer27, act, shift27, center27))
             return fail(1, "Sub-domain smaller than the ghost cutoff is not supported");
-        bool has_lo = periodic[d] || myloc[d] > 0, has_hi = periodic[d] || myloc[d] < procgrid[d] - 1;
-        slab_lo[d] = has_lo ? sublo[d] + cutghost : -BIG;
-        slab_hi[d] = has_hi ? subhi[d] - cutghost : BIG;
-    }
-    for (int dir = 0; dir < 27; dir++) {
-        int s[3] = {dir % 3 - 1, (dir / 3) % 3 - 1, dir / 9 - 1};
-        bool active = dir != 13;
-        int loc[3];
-        for (int d = 0; d < 3; d++) {
-            shift27[3 * dir + d] = 0.0;
-            loc[d] = myloc[d] + s[d];
-            if (loc[d] < 0 || loc[d] >= procgrid[d]) {
-                if (!periodic[d]) active = false;
-                shift27[3 * dir + d] = -s[d] * prd[d];
-                loc[d] = (loc[d] + procgrid[d]) % procgrid[d];
-            }
-            double lo = boxlo[d] + prd[d] * loc[d] / procgrid[d];
-            double hi = (loc[d] == procgrid[d] - 1) ? boxhi[d] : boxlo[d] + prd[d] * (loc[d] + 1) / procgrid[d];
-            center27[3 * dir + d] = 0.5 * (hi + lo);
-        }
-        send_active[dir] = active;
-        peer27[dir] = loc[0] + procgrid[0] * (loc[1] + procgrid[1] * loc[2]);
+        for (int dir = 0; dir < 27; dir++) send_active[dir] = act[dir] != 0;
     }
     build_peer_tables();
     if (!d_shift27) HIPCHK(dalloc(d_shift27, 81));

@@ -1,8 +1,10 @@
 """World-size-2 (gloo, CPU) check of the decomposed ghost scheme the engine implements in comm.hip:
 each rank owns a brick of the box, sends the atoms within cutghost of its faces to the brick neighbour in each
 of the 26 directions (shifted by the period where the message crosses the periodic boundary), and the forces
-computed from owned + ghost atoms with the CPU oracle equal the single-rank oracle forces.  The processor grid
-comes from the library's host-only helper (meso_decomp_procgrid), so this runs without a GPU."""
+computed from owned + ghost atoms with the CPU oracle equal the single-rank oracle forces.  The processor grid and
+the whole per-direction table (neighbour rank, shift, slabs, centres) come from the library's host-only functions
+(meso_decomp_procgrid, meso_decomp_plan - the code Engine::init_params runs), so a break in the engine's decomposition
+logic turns this test red, and it runs without a GPU."""
 import os
 import sys
 
@@ -15,32 +17,27 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _ghosts_for(rank, grid, lo, hi, cut, x_own, loc_of):
-    """messages {dest_rank: (src_idx, shift)} built exactly like Engine::init_params / k_border_count."""
-    prd = hi - lo
-    pg = np.array(grid)
-    myloc = np.array(loc_of(rank))
-    sublo = lo + prd * myloc / pg
-    subhi = np.where(myloc == pg - 1, hi, lo + prd * (myloc + 1) / pg)
-    near_lo = x_own <= sublo + cut
-    near_hi = x_own >= subhi - cut
+def _ghosts_for(rank, grid, lo, hi, cut, x_own):
+    """messages {dest_rank: (src_idx, shift)} from the ENGINE's decomposition tables (meso_decomp_plan = the host function
+    Engine::init_params calls: neighbour rank, periodic shift, active flag, border slabs); what stays in numpy is the
+    per-atom slab test of k_border_count (kernels.hip): coordinate <= slab_lo / >= slab_hi in every shifted dimension."""
+    from meso_amd.api import decomp_plan
+    P = decomp_plan(lo, hi, grid, rank, cut)
+    near_lo = x_own <= P["slab_lo"]
+    near_hi = x_own >= P["slab_hi"]
     out = {}
     for d in range(27):
-        if d == 13:
+        if not P["active"][d]:
             continue
-        s = np.array([d % 3 - 1, (d // 3) % 3 - 1, d // 9 - 1])
+        s = (d % 3 - 1, (d // 3) % 3 - 1, d // 9 - 1)
         sel = np.ones(len(x_own), bool)
         for k in range(3):
             if s[k] < 0:
                 sel &= near_lo[:, k]
             elif s[k] > 0:
                 sel &= near_hi[:, k]
-        loc = myloc + s
-        shift = np.where((loc < 0) | (loc >= pg), -s * prd, 0.0)
-        loc = (loc + pg) % pg
-        dest = int(loc[0] + pg[0] * (loc[1] + pg[1] * loc[2]))
-        out.setdefault(dest, []).append((np.nonzero(sel)[0], shift))
-    return out, 0.5 * (sublo + subhi)
+        out.setdefault(int(P["peer"][d]), []).append((np.nonzero(sel)[0], P["shift"][d]))
+    return out, 0.5 * (P["sublo"] + P["subhi"]), P
 
 
 def _worker(rank, world, port, L, q):
@@ -63,7 +60,14 @@ def _worker(rank, world, port, L, q):
         owner = cell[:, 0] + pg[0] * (cell[:, 1] + pg[1] * cell[:, 2])
         mine = np.nonzero(owner == rank)[0]
         cut = 1.3
-        msgs, center = _ghosts_for(rank, grid, lo, hi, cut, x[mine], loc_of)
+        msgs, center, plan = _ghosts_for(rank, grid, lo, hi, cut, x[mine])
+        # the plan's sub-box is the region whose atoms this rank was handed
+        assert ((x[mine] >= plan["sublo"]) & (x[mine] < plan["subhi"])).all()
+        # a message to rank p is received with the receiver's centre: the sender's table must name the receiver's own centre
+        for d in range(27):
+            if plan["active"][d]:
+                other = _ghosts_for(int(plan["peer"][d]), grid, lo, hi, cut, x[:0])[1]
+                assert np.array_equal(plan["center"][d], other)
         payload = {dest: [(x[mine][idx] + sh, v[mine][idx], tags[mine][idx]) for idx, sh in lst] for dest, lst in msgs.items()}
         box = [None] * world
         dist.all_gather_object(box, payload)
