@@ -50,7 +50,8 @@ int meso_device_sync(meso_ctx *ctx);
  *   pair_npart    0  ring kernel: lanes per atom; 0 = by launch size (2 up to 163 840 atoms, else 1) | 1 | 2 | 4
  *   fuse_clear    1  force kernel writes f instead of clear + accumulate
  *   overlap       1  several ranks: ghost refresh on a side stream under the bulk force kernel
- *   brick_margin  1  multiplier on the expected brick-neighbourhood population (raise for strongly inhomogeneous systems)
+ *   brick_margin  1  multiplier on the expected brick-neighbourhood population (the LDS stage of the tile list builder; the engine
+ *                    also grows it by itself: a first build that overflows is repeated, later ones grow from the high-water mark)
  *   async_counts  1  one rank: a rebuild does not wait for the host - launch bounds come from the previous rebuild's counts,
  *                    kernels mask with the device-side counts, the host reads them (pinned memory) when it next needs them
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
