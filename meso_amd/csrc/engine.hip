@@ -798,6 +798,7 @@ int Engine::init_params()
     if (!have_box) return fail(3, "Box has not been set");
     if (!have_pair || !have_coeff) return fail(3, "Pair style/coefficients have not been set");
     if (ntypes < 1 || (int)mass_type.size() != ntypes + 1) return fail(3, "Masses have not been set");
+    if (ntypes > 255) return fail(1, "More than 255 atom types are not supported (the force kernel queues partner types as bytes)");
     for (int i = 0; i < ntypes * ntypes; i++)
         if (!coeff_set[i]) return fail(3, "All pair coeffs are not set");
     cutmax = 0.0;

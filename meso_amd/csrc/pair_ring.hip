@@ -277,7 +277,6 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     int n = p.end - p.beg;
     if (n <= 0) return;
     const bool nt1 = p.ntypes == 1;
-    if (p.ntypes > 255) { fprintf(stderr, "meso: the force kernel keeps atom types in 8 bits (ntypes <= 255)\n"); abort(); }
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * (fast ? 8 * 4 : N_COEFF * 8);
     size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (nt1 ? 0 : RG_RING) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
