@@ -396,9 +396,11 @@ __device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i
 // word (exact for every fp32 x with |x| < 2^31 down to 2^-32 resolution)
 __device__ inline u64 to_fixed(float x)
 {
-    const int hi = (int)__builtin_floorf(x);
-    const u32 lo = (u32)(__builtin_amdgcn_fractf(x) * 4294967296.0f);
-    return ((u64)(u32)hi << 32) | lo;
+    // x + 1.5 * 2^20 as a double has x * 2^32 (rounded to nearest, two's complement) in its low 52 bits; taking the exponent and
+    // the 1.5 off the high word leaves the 64-bit fixed-point number (|x| < 2^19): cvt, add, one integer add
+    const double y = (double)x + 1572864.0;
+    const u64 b = (u64)__double_as_longlong(y);
+    return ((u64)((u32)(b >> 32) - 0x41380000u) << 32) | (u32)b;
 }
 __device__ inline double from_fixed(u64 a) { return (double)(long long)a * (1.0 / 4294967296.0); }
 

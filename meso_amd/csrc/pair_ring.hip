@@ -176,9 +176,9 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                     // the partner is one of this workgroup's atoms: it receives the opposite force now and skips its own
                     // (mirrored) row entry
                     const u32 pj = (pe & RG_INDEX_MASK) - (u32)blockbase;
-                    __hip_atomic_fetch_add(&facc[pj], 0ull - qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&facc[NB + pj], 0ull - qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&facc[2 * NB + pj], 0ull - qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_sub(&facc[pj], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_sub(&facc[NB + pj], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_sub(&facc[2 * NB + pj], qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             pn = 0;
