@@ -18,20 +18,24 @@ static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 
 // cell-order tags: locals as stored, ghosts scattered to their Morton(bin) slots
 __global__ void __launch_bounds__(256) k_tag_cell(const int *__restrict__ tag, const int *__restrict__ gslot, int nlocal,
-                                                  int nghost, int *__restrict__ tagc)
+                                                  int nghost, const int *__restrict__ nghost_dev, int *__restrict__ tagc)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nlocal + nghost) return;
-    if (i < nlocal) tagc[i] = tag[i];
-    else tagc[nlocal + (gslot ? gslot[i - nlocal] : i - nlocal)] = tag[i];
+    // nghost_dev: nghost only sized the grid (an estimate); the count is on the device and the loop covers whatever it turns out to be
+    if (nghost_dev) nghost = *nghost_dev;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nlocal + nghost; i += gridDim.x * blockDim.x) {
+        if (i < nlocal) tagc[i] = tag[i];
+        else tagc[nlocal + (gslot ? gslot[i - nlocal] : i - nlocal)] = tag[i];
+    }
 }
 
-__global__ void __launch_bounds__(256) k_set_map(const int *__restrict__ tagc, int nall, int maxtag, int *__restrict__ map)
+__global__ void __launch_bounds__(256) k_set_map(const int *__restrict__ tagc, int nall, int nlocal, const int *__restrict__ nghost_dev, int maxtag,
+                                                 int *__restrict__ map)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nall) return;
-    int t = tagc[i];
-    if (t >= 0 && t <= maxtag) atomicMin(map + t, i);
+    if (nghost_dev) nall = nlocal + *nghost_dev;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nall; i += gridDim.x * blockDim.x) {
+        int t = tagc[i];
+        if (t >= 0 && t <= maxtag) atomicMin(map + t, i);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_map_bonds(const int *__restrict__ nbond, const int *__restrict__ bond_tag, int bpa,
@@ -208,14 +212,15 @@ void launch_angle_harmonic(const float4 *coord4, const int *nangle, const int *a
                            prd[0], prd[1], prd[2], nlocal, fx, fy, fz, e_angle);
 }
 
-void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, int *tagc, hipStream_t s)
+void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, const int *nghost_dev, int *tagc, hipStream_t s)
 {
     if (nlocal + nghost > 0)
-        hipLaunchKernelGGL(k_tag_cell, dim3(nblk(nlocal + nghost, 256)), dim3(256), 0, s, tag, gslot, nlocal, nghost, tagc);
+        hipLaunchKernelGGL(k_tag_cell, dim3(nblk(nlocal + nghost, 256)), dim3(256), 0, s, tag, gslot, nlocal, nghost, nghost_dev, tagc);
 }
-void launch_set_map(const int *tagc, int nall, int maxtag, int *map, hipStream_t s)
+void launch_set_map(const int *tagc, int nlocal, int nghost, const int *nghost_dev, int maxtag, int *map, hipStream_t s)
 {
-    if (nall > 0) hipLaunchKernelGGL(k_set_map, dim3(nblk(nall, 256)), dim3(256), 0, s, tagc, nall, maxtag, map);
+    if (nlocal + nghost > 0)
+        hipLaunchKernelGGL(k_set_map, dim3(nblk(nlocal + nghost, 256)), dim3(256), 0, s, tagc, nlocal + nghost, nlocal, nghost_dev, maxtag, map);
 }
 void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int *map, int maxtag, int nlocal, int *bond_idx,
                       int *missing, hipStream_t s)

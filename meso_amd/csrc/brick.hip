@@ -10,6 +10,8 @@
 //
 // Replaces gpu_build_neighbor_list + gpu_join/transpose (neigh_build_meso.cu:20-240).  (Round 1 also kept a force kernel
 // and a 16-bit-row builder on this layout - `layout=1`; retired in round 2, the cell-ordered ring kernel is faster.)
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
 #include "meso_device.h"
@@ -168,10 +170,9 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 #define TB_G 4
 #define TB_ROWCAP_MAX 1024         // rows are staged in LDS at their full capacity n_col (2 bytes per entry)
 
-template <bool EXCL>
 __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
                                                               int n_col, int *__restrict__ count, int *__restrict__ table,
-                                                              int *__restrict__ overflow, ExclArgs ex, int split, int dbg)
+                                                              int *__restrict__ overflow, int split, int dbg)
 {
 #pragma clang fp contract(fast)
     // staged neighbourhood, SoA (candidate reads are consecutive slots); sized at launch for g.maxh halo atoms, so denser
@@ -179,8 +180,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     extern __shared__ float tb_dyn[];
     float *hx = tb_dyn, *hy = hx + g.maxh, *hz = hy + g.maxh;
     u32 *hgi = (u32 *)(hz + g.maxh);
-    int *htag = (int *)(hgi + g.maxh);                                   // EXCL only: tags of the staged atoms
-    unsigned short *rowbuf = (unsigned short *)(EXCL ? (u32 *)(htag + g.maxh) : hgi + g.maxh);          // [wave][TB_G][n_col]
+    unsigned short *rowbuf = (unsigned short *)(hgi + g.maxh);          // [wave][TB_G][n_col]
     __shared__ int hoff[BRK_NHB + 1];
     __shared__ int hloc[BRK_NHB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -245,7 +245,6 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             else if ((off -= hl0[lo]) < hl1[lo]) src = (u32)(hs1[lo] + off);
             else src = (u32)(hs2[lo] + (off - hl1[lo]));
             hgi[h] = src;
-            if (EXCL) htag[h] = ex.tagc[src];
             const float4 c = coord4[src];
             hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
         }
@@ -258,7 +257,6 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
         for (int h = tid; h < nh; h += BRK_THREADS) {
             const u32 src = g.hmap[(size_t)slot * g.maxh + h];
             hgi[h] = src;
-            if (EXCL) htag[h] = ex.tagc[src];
             const float4 c = coord4[src];
             hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
         }
@@ -275,12 +273,14 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
         // wave-uniform values are forced into SGPRs: counters, branches and the own coordinates then stay scalar
         const int own0 = __builtin_amdgcn_readfirstlane(hoff[hb]), na = __builtin_amdgcn_readfirstlane(hloc[hb]);
         if (na == 0) continue;
-        // the 9 candidate runs and their prefix
-        int rstart[9], pre[10];
-        pre[0] = 0;
-        {
-            // lanes 0..8 read the two offsets of "their" run in one LDS round trip; the 18 values then move to SGPRs with
-            // v_readlane (18 dependent LDS reads + readfirstlane before)
+        // the 9 candidate runs of the bin's stencil and their prefix: lanes 0..8 read the two offsets of "their" run in one LDS
+        // round trip, v_readlane moves the 18 values to SGPRs (18 dependent LDS reads + readfirstlane before).  The table lives
+        // only while candidates are loaded - 19 SGPRs that the scan must not pay for with spills (the special-bond variant of
+        // this kernel lost 50 us per build to v_writelane/v_readlane traffic when it stayed alive) - and is rebuilt for the
+        // rare bin with more than 4 batches
+        auto load_cand = [&](int b0, int nb, int *cs, float *cx, float *cy, float *cz) {
+            int rstart[9], pre[10];
+            pre[0] = 0;
             const int rl = lane < 9 ? lane : 0;
             const int hrow_l = hb + (rl % 3 - 1) * BRK_H + (rl / 3 - 1) * BRK_H * BRK_H;
             const int lo_l = hoff[hrow_l - 1], hi_l = hoff[hrow_l + 2];
@@ -289,29 +289,30 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                 rstart[r] = __builtin_amdgcn_readlane(lo_l, r);
                 pre[r + 1] = pre[r] + (__builtin_amdgcn_readlane(hi_l, r) - rstart[r]);
             }
-        }
-        const int ncand = pre[9];
-        const int nbatch = (ncand + 63) >> 6;
-
+            const int ncand_ = pre[9];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q < nb) {
+                    const int id = ((b0 + q) << 6) + lane;
+                    int base = rstart[0];
+#pragma unroll
+                    for (int r = 1; r < 9; r++) base = id >= pre[r] ? rstart[r] - pre[r] : base;
+                    const bool valid = id < ncand_;
+                    cs[q] = valid ? id + base : 0;
+                    cx[q] = valid ? hx[cs[q]] : 1.0e18f;       // never inside the cutoff
+                    cy[q] = hy[cs[q]]; cz[q] = hz[cs[q]];
+                }
+            }
+            return ncand_;
+        };
         // candidates of the first 4 batches (256 atoms: the usual stencil holds ~237) stay in registers for all groups
         // of this bin; later batches (denser systems) are reloaded per group
-        auto load_cand = [&](int b, int &cs, float &cx, float &cy, float &cz) {
-            const int id = (b << 6) + lane;
-            int base = rstart[0];
-#pragma unroll
-            for (int r = 1; r < 9; r++) base = id >= pre[r] ? rstart[r] - pre[r] : base;
-            const bool valid = id < ncand;
-            cs = valid ? id + base : 0;
-            cx = valid ? hx[cs] : 1.0e18f;       // never inside the cutoff
-            cy = hy[cs]; cz = hz[cs];
-        };
         int cs4[4];
         float cx4[4], cy4[4], cz4[4];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            cs4[b] = 0; cx4[b] = 1.0e18f; cy4[b] = cz4[b] = 0.f;
-            if (b < nbatch) load_cand(b, cs4[b], cx4[b], cy4[b], cz4[b]);
-        }
+        for (int b = 0; b < 4; b++) { cs4[b] = 0; cx4[b] = 1.0e18f; cy4[b] = cz4[b] = 0.f; }
+        const int ncand = __builtin_amdgcn_readfirstlane(load_cand(0, 4, cs4, cx4, cy4, cz4));
+        const int nbatch = (ncand + 63) >> 6;
 
         for (int g0 = 0; g0 < na; g0 += TB_G) {
             const int ng = min(TB_G, na - g0);
@@ -337,22 +338,10 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             int nrow[TB_G];
 #pragma unroll
             for (int t = 0; t < TB_G; t++) nrow[t] = 0;
-            // special-bond partners of the group's own atoms, 16 lanes per atom: requested here, used when the rows are written
-            // out (the scan in between hides the latency); an atom with more than 16 reads the rest from global memory there
-            int nsp_l = 0, sp_l = -1;
-            if (EXCL) {
-                const int tq = lane >> 4, kq = lane & 15;
-                if (tq < ng) {
-                    const int gq = (int)hgi[own0 + g0 + tq];
-                    nsp_l = ex.nspecial[gq];
-                    if (kq < nsp_l) sp_l = ex.special[(size_t)gq * ex.msp + kq];
-                }
-            }
-
             // one (own atom, 64-candidate batch) step: distance, lane mask straight from the compares (LLVM predicates: 5 = OLE,
             // 33 = NE), slot of every hit in the atom's LDS row.  No "any hit?" branch: a batch almost always holds one, and
             // straight-line code lets the chains of the group's atoms overlap.  FULL: all TB_G own atoms present (no branches
-            // at all: 16 independent chains for 4 batches).  Special-bond partners are dropped when the row is written out.
+            // at all: 16 independent chains for 4 batches).  Special-bond partners are dropped by k_filter_exclusion afterwards.
             // (two own atoms per packed fp32 instruction - v_pk_add/mul/fma_f32 with the own coordinates as SGPR pairs - was
             // measured: 307 -> 312 us; the scan is not bound by the number of distance instructions)
             auto scan = [&](auto full, const int cs, const float cx, const float cy, const float cz) {
@@ -379,10 +368,10 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                     if (b < nbatch && dbg != 3) scan(std::false_type{}, cs4[b], cx4[b], cy4[b], cz4[b]);
             }
             for (int b = 4; b < nbatch; b++) {
-                int cs;
-                float cx, cy, cz;
-                load_cand(b, cs, cx, cy, cz);
-                scan(std::false_type{}, cs, cx, cy, cz);
+                int cs[4];
+                float cx[4], cy[4], cz[4];
+                load_cand(b, 1, cs, cx, cy, cz);
+                scan(std::false_type{}, cs[0], cx[0], cy[0], cz[0]);
             }
             // rows out, lane = entry: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become global
             // indices, the tail of the last chunk is padded with the atom itself
@@ -392,37 +381,14 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
                     const int n = nrow[t], i = gi[t];
                     const int nn = dbg == 2 ? 0 : min(n, n_col);
                     int *dst = table + row_word8(i, 0, n_col) * 8;
-                    int nout = nn;
-                    if (!EXCL) {
-                        for (int e = lane; e < ((nn + 7) & ~7); e += 64) {
-                            int val = i;
-                            if (e < nn) val = (int)hgi[myrow(t)[e]];
-                            dst[(size_t)(e >> 3) * 512 + (e & 7)] = val;
-                        }
-                    } else {
-                        // gpu_filter_exclusion (neigh_build_meso.cu:497-544): special partners are dropped by tag - here, once per
-                        // row ENTRY (the scan tests 6-7 times as many candidates), the atom's special list through v_readlane
-                        const int nsp = __builtin_amdgcn_readlane(nsp_l, t * 16);
-                        const int *spl = ex.special + (size_t)i * ex.msp;
-                        nout = 0;
-                        for (int e0 = 0; e0 < nn; e0 += 64) {
-                            const int e = e0 + lane;
-                            const u32 slot = e < nn ? myrow(t)[e] : 0u;
-                            const int tg = htag[slot];
-                            bool keep = e < nn;
-                            for (int sp = 0; sp < min(nsp, 16); sp++) keep = keep & (__builtin_amdgcn_readlane(sp_l, t * 16 + sp) != tg);
-                            for (int sp = 16; sp < nsp; sp++) keep = keep & (spl[sp] != tg);
-                            const u64 m = __builtin_amdgcn_ballot_w64(keep);
-                            const int pos = nout + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                            if (keep) dst[(size_t)(pos >> 3) * 512 + (pos & 7)] = (int)hgi[slot];
-                            nout += __popcll(m);
-                        }
-                        const int e = nout + lane;
-                        if (e < ((nout + 7) & ~7)) dst[(size_t)(e >> 3) * 512 + (e & 7)] = i;
+                    for (int e = lane; e < ((nn + 7) & ~7); e += 64) {
+                        int val = i;
+                        if (e < nn) val = (int)hgi[myrow(t)[e]];
+                        dst[(size_t)(e >> 3) * 512 + (e & 7)] = val;
                     }
                     if (lane == 0) {
-                        if (n > n_col) atomicMax(overflow, n);      // (before exclusions: the LDS row holds every hit)
-                        count[i] = nout;
+                        if (n > n_col) atomicMax(overflow, n);
+                        count[i] = nn;
                     }
                 }
             }
@@ -511,7 +477,7 @@ int brick_codes() { return BRK_CODES; }
 int brick_static_maxh() { return BRK_MAXH; }        // capacity of the brick-layout kernels (static LDS arrays)
 int brick_static_maxown() { return BRK_MAXOWN; }
 // largest halo the tile builder can stage: 160 KB of LDS minus its static part (row staging, bin offsets), 16 B per atom
-int tile_build_maxh_limit(int n_col, int with_tags) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / (with_tags ? 20 : 16)); }
+int tile_build_maxh_limit(int n_col, int) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / 16); }
 size_t brick_hoff_pitch() { return BRK_HOFF_PITCH; }
 size_t brick_hdr_pitch() { return BRK_HDR_PITCH; }
 
@@ -534,6 +500,72 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
                            nghost, key, val);
 }
 
+// gpu_filter_exclusion (neigh_build_meso.cu:497-544): special-bond partners leave the rows by TAG (an atom and its periodic
+// images carry the same tag).  A pass of its own over the finished rows, like the reference's: a wave looks at 64 consecutive
+// atoms, and for each one that has special partners (most atoms of a solution have none) its row is read lane = entry, the
+// entry's tag comes from the cell-ordered tag array, the atom's special list sits in the first lanes of its 16-lane group and
+// is handed out with a lane shuffle, kept entries are compacted in place with ballot + popcount (writes never pass the reads of
+// a later batch) and the tail of the last chunk is padded with the atom itself again.  Inside the list builder the same filter cost 50 us per build
+// even on a deck without a single exclusion (scalar-register spills of the larger kernel) and a third of its occupancy
+// while the tags of the neighbourhood were staged in LDS.
+__global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nlocal, int n_col, int *__restrict__ count,
+                                                          int *__restrict__ table)
+{
+    // FOUR atoms at a time per wave, 16 lanes each: the filter is a chain of dependent memory round trips per atom (special
+    // list and count, row entries, their tags), so its speed is the number of atoms in flight (one atom per wave: 250 us on a
+    // melt of 1 M chain beads, four: see profiles/r02_notes.md)
+    __shared__ unsigned char todo_s[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x * 4 + w) * 64;
+    if (i0 >= nlocal) return;
+    const int il = i0 + lane;
+    const int nsp_own = il < nlocal ? ex.nspecial[il] : 0;
+    const int cnt_own = il < nlocal ? count[il] : 0;       // (loaded for all 64 atoms at once: one round trip less per atom below)
+    const u64 todo = __builtin_amdgcn_ballot_w64(nsp_own > 0);
+    const int ntodo = __popcll(todo);
+    if (ntodo == 0) return;
+    // the atoms that have special partners, in order: slot k of todo_s = lane offset of the k-th one
+    if (nsp_own > 0) todo_s[w][__builtin_amdgcn_mbcnt_hi((u32)(todo >> 32), __builtin_amdgcn_mbcnt_lo((u32)todo, 0u))] = (unsigned char)lane;
+    const int g = lane >> 4, l16 = lane & 15;
+    const u32 below = (1u << l16) - 1u;
+    for (int r = 0; r < ntodo; r += 4) {
+        const bool on = r + g < ntodo;
+        const int al = on ? (int)todo_s[w][r + g] : 0;
+        const int i = i0 + al;
+        // (shuffles outside any branch: a lane that is switched off hands out nothing)
+        const int nsp_a = __shfl(nsp_own, al, 64), n_a = __shfl(cnt_own, al, 64);
+        const int nsp = on ? nsp_a : 0;
+        const int n = on ? n_a : 0;
+        // (requested together with the row entries: the list load does not wait for anything; lists longer than 16: rest from memory)
+        int sp_l = (on && l16 < ex.msp) ? ex.special[(size_t)i * ex.msp + l16] : -1;
+        if (l16 >= nsp) sp_l = -1;
+        int nspmax = nsp, nmax = n;
+#pragma unroll
+        for (int o = 32; o >= 16; o >>= 1) { nspmax = max(nspmax, __shfl_xor(nspmax, o, 64)); nmax = max(nmax, __shfl_xor(nmax, o, 64)); }
+        nspmax = __builtin_amdgcn_readfirstlane(nspmax); nmax = __builtin_amdgcn_readfirstlane(nmax);
+        int *row = table + row_word8(i, 0, n_col) * 8;
+        int nout = 0;
+        for (int e0 = 0; e0 < nmax; e0 += 16) {
+            const int e = e0 + l16;
+            const bool in = e < n;
+            const int j = in ? row[(size_t)(e >> 3) * 512 + (e & 7)] : i;
+            const int tg = ex.tagc[j];
+            bool keep = in;
+            for (int sp = 0; sp < min(nspmax, 16); sp++) keep = keep & (__shfl(sp_l, (lane & 48) + sp, 64) != tg);
+            for (int sp = 16; sp < nsp; sp++) keep = keep & (ex.special[(size_t)i * ex.msp + sp] != tg);
+            const u32 m16 = (u32)(__builtin_amdgcn_ballot_w64(keep) >> (16 * g)) & 0xffffu;
+            const int pos = nout + __popc(m16 & below);
+            if (keep) row[(size_t)(pos >> 3) * 512 + (pos & 7)] = j;
+            nout += __popc(m16);
+        }
+        if (on) {
+            const int e = nout + l16;
+            if (e < ((nout + 7) & ~7)) row[(size_t)(e >> 3) * 512 + (e & 7)] = i;
+            if (l16 == 0) count[i] = nout;
+        }
+    }
+}
+
 void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s)
 {
     if (g.nactive <= 0) return;
@@ -541,7 +573,7 @@ void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s)
 }
 
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
-                       const ExclArgs *excl, int dbg, hipStream_t s)
+                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s)
 {
     if (g.nactive <= 0) return;
     // few bricks (small boxes, sub-boxes of many ranks): several workgroups share a brick as long as all of them still fit the
@@ -552,22 +584,16 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     while (split < 4 && occupied * split * 2 <= 900) split *= 2;
     if (dbg >= 100) { split = dbg - 100; dbg = 0; }     // timing experiments: pair_debug 110 + split
     const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
-    ExclArgs ex = {nullptr, nullptr, nullptr, 0};
-    const bool with_tags = excl && excl->tagc;
-    const size_t dyn = (size_t)g.maxh * (with_tags ? 20 : 16) + (size_t)BRK_WAVES * TB_G * n_col * 2;
-    if (dyn > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)k_tile_build<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        (void)hipFuncSetAttribute((const void *)k_tile_build<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    }
-    if (excl && excl->tagc) {
-        ex = *excl;
-        hipLaunchKernelGGL((k_tile_build<true>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
-                           overflow, ex, split, dbg);
-    } else {
-        hipLaunchKernelGGL((k_tile_build<false>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table,
-                           overflow, ex, split, dbg);
+    const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2;
+    if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
+    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(k_tile_build, tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg);
+    if (excl && excl->tagc && nlocal > 0) {
+        const int nw = (nlocal + 63) / 64;                                  // one wave per 64 consecutive atoms
+        hipLaunchKernelGGL(k_filter_exclusion, dim3((nw + 3) / 4), dim3(256), 0, s, *excl, nlocal, n_col, count, table);
     }
 }
+
 int tile_build_rowcap() { return TB_ROWCAP_MAX; }
 
 } // namespace meso

@@ -275,7 +275,7 @@ private:
     bool tile_fits = true;          // the tile builder can stage a brick neighbourhood of this density in LDS
     double brick_margin = 1.0;      // multiplier on the expected halo population (inhomogeneous systems)
     bool regrow_only = false;       // init_params re-run for a larger brick stage on this rank alone (no collective)
-    double brick_margin_auto = 1.0; // grown by the engine when the fullest brick neighbourhood comes close to the capacity
+    int brick_maxh_floor = 0;       // fullest brick neighbourhood seen + 8 %: the engine grows the LDS stage of the tile builder to it
     size_t estart_cap = 0;
     BrickArgs bargs{};
     int l1bits = 0;

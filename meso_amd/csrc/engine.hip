@@ -572,10 +572,10 @@ int Engine::bonds_upload(int nb, const int *ti, const int *tj, const int *bt)
 int Engine::rebuild_topology()
 {
     if (!have_bonds) return 0;
-    int nall = nlocal + nghost;
-    launch_tag_cell(cur.tag, gslot, nlocal, nghost, tagc, stream);
+    const int *ng_dev = counts_pending ? d_dir_start + 27 : nullptr;     // nghost is a launch bound while the counts travel
+    launch_tag_cell(cur.tag, gslot, nlocal, nghost, ng_dev, tagc, stream);
     HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
-    launch_set_map(tagc, nall, maxtag, tagmap, stream);
+    launch_set_map(tagc, nlocal, nghost, ng_dev, maxtag, tagmap, stream);
     // (d_flags[4] counts partners that are neither local nor ghost; it stays set until check_overflow reports it)
     launch_map_bonds(cur.nbond, cur.bond_tag, bpa, tagmap, maxtag, nlocal, bond_idx, d_flags + 4, stream);
     if (have_angles)
@@ -881,13 +881,15 @@ int Engine::init_params()
         // lane-per-atom builder when even one workgroup per CU could not hold the neighbourhood.
         {
             const double binvol = geom.binsize[0] * geom.binsize[1] * geom.binsize[2];
-            const double mean = density * 216.0 * binvol * brick_margin * brick_margin_auto;
+            const double mean = density * 216.0 * binvol * brick_margin;
             int want = ((int)std::ceil(mean + 6.5 * std::sqrt(mean)) + 63) / 64 * 64;
             if (want < brick_static_maxh()) want = brick_static_maxh();
+            // the fullest neighbourhood seen so far + 8 % (every 2.5 KB of LDS beyond the need can cost the third workgroup per CU)
+            if (want < brick_maxh_floor) want = brick_maxh_floor;
             tile_fits = want <= tile_build_maxh_limit(n_col, have_bonds && msp > 0 ? 1 : 0);
             bargs.maxh = want;
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
-            const double m128 = density * 128.0 * binvol * brick_margin * brick_margin_auto;
+            const double m128 = density * 128.0 * binvol * brick_margin * std::max(1.0, (double)brick_maxh_floor / std::max(1.0, mean + 6.5 * std::sqrt(mean)));
             reorder_cap = std::min(7680, std::max(2048, ((int)std::ceil(m128 + 6.5 * std::sqrt(m128)) + 63) / 64 * 64));
             if (reorder_cap_user > 0) reorder_cap = reorder_cap_user;
             bargs.maxown = 0;
@@ -1217,7 +1219,7 @@ int Engine::build_cells_and_table()
                 // (the inline plan borrows the row stage for its run tables: 5 x 216 ints)
                 bargs.plan_inline = (tile_plan == 0 && bargs.active == nullptr && n_col >= 64) ? 1 : 0;
                 if (!bargs.plan_inline) launch_brick_plan(bargs, d_flags, stream);
-                launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr,
+                launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,
                                   pair_debug >= 10 ? pair_debug - 10 : 0, stream);
                 tend("neigh");
                 nbuild++;
@@ -1238,7 +1240,7 @@ int Engine::ensure_table32() { return 0; }
 
 bool Engine::async_ok() const
 {
-    return async_counts && nranks == 1 && !ghost_sort && !reorder_sort && !have_bonds && nghost_prev >= 0 &&
+    return async_counts && nranks == 1 && !ghost_sort && !reorder_sort && nghost_prev >= 0 &&
            neigh_kernel == 1 && tile_fits;
 }
 
@@ -1293,7 +1295,7 @@ int Engine::reneighbor()
         // high-water mark of the earlier list builds came with the count report (or with the last check_overflow)
         const int hwm = std::max(h_flags[5], h_flags[10]);
         if (params_ready && neigh_kernel == 1 && (long)hwm * 100 > (long)bargs.maxh * 93) {
-            brick_margin_auto *= 1.12;
+            brick_maxh_floor = ((int)(hwm * 1.08) + 63) / 64 * 64;
             params_ready = false;
             regrow_only = true;
             h_flags[5] = h_flags[10] = 0;
@@ -1440,7 +1442,7 @@ int Engine::setup()
         // (the rebuild exchanges atoms and ghosts: every rank repeats it when one has to)
         if (reduce_global_sum(grow ? 1.0 : 0.0) == 0.0) break;
         if (grow) {
-            brick_margin_auto *= std::max(1.1, 1.08 * (h_flags[0] - 100000) / (double)bargs.maxh);
+            brick_maxh_floor = ((int)((h_flags[0] - 100000) * 1.08) + 63) / 64 * 64;
             params_ready = false;
             regrow_only = true;
             HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));

@@ -196,7 +196,7 @@ void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int ngho
 struct ExclArgs;
 // cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
-                       const ExclArgs *excl, int dbg, hipStream_t s);
+                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s);
 int tile_build_rowcap();
 void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s);
 void launch_code_starts_u32(const uint32_t *sorted_key, int n, int ncodes, int *start, hipStream_t s);
@@ -204,8 +204,8 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
                          hipStream_t s);
 
 // ---- bonded topology (bond.hip) -----------------------------------------------------------------------
-void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, int *tagc, hipStream_t s);
-void launch_set_map(const int *tagc, int nall, int maxtag, int *map, hipStream_t s);
+void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, const int *nghost_dev, int *tagc, hipStream_t s);
+void launch_set_map(const int *tagc, int nlocal, int nghost, const int *nghost_dev, int maxtag, int *map, hipStream_t s);
 void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int *map, int maxtag, int nlocal,
                       int *bond_idx, int *missing, hipStream_t s);
 // gpu_map_angle (neighbor_meso.cu:161-182): tags -> indices, the atom's own tag -> itself
