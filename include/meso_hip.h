@@ -49,6 +49,8 @@ int meso_device_sync(meso_ctx *ctx);
  *   ghost_sort    0  ghosts binned by counting per Morton code | 1 by sorting them (former path, same storage order)
  *   pair_npart    0  ring kernel: lanes per atom; 0 = by launch size (2 up to 163 840 atoms, else 1) | 1 | 2 | 4
  *   fuse_clear    1  force kernel writes f instead of clear + accumulate
+ *   fuse_bonds    1  systems with bonds and no angles: the bonds of an atom are evaluated in the force kernel's step-boundary
+ *                    epilogue (no bond kernel launch between rebuild-free steps); 0 = bond kernel first, epilogue adds its forces
  *   overlap       1  several ranks: ghost refresh on a side stream under the bulk force kernel
  *   brick_margin  1  multiplier on the expected brick-neighbourhood population (the LDS stage of the tile list builder; the engine
  *                    also grows it by itself: a first build that overflows is repeated, later ones grow from the high-water mark)

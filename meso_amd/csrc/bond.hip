@@ -53,12 +53,6 @@ __global__ void __launch_bounds__(256) k_map_bonds(const int *__restrict__ nbond
     }
 }
 
-__host__ __device__ inline double min_image(double dr, double p)   // math_meso.h:148-152
-{
-    double ph = p * 0.5;
-    return dr + (dr > -ph ? (dr < ph ? 0.0 : -p) : p);
-}
-
 // STYLE 0: harmonic (coefficient table [k][r0]); STYLE 1: FENE ([k][r0][epsilon][sigma]), bond_fene_meso.cu:82-147 ==
 // BondFENE::compute src/MOLECULE/bond_fene.cpp:48-124 with the warning/abort branches replaced by the clamp the
 // reference's kernel applies
@@ -73,7 +67,6 @@ __global__ void __launch_bounds__(256) k_bond(const float4 *__restrict__ coord4,
     const int ncf = (STYLE == 1 ? 4 : 2) * (nbt + 1);
     for (int t = threadIdx.x; t < ncf; t += blockDim.x) sh[t] = cf[t];
     __syncthreads();
-    const double *k = sh, *r0 = sh + nbt + 1, *eps = sh + 2 * (nbt + 1), *sig = sh + 3 * (nbt + 1);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nlocal; i += gridDim.x * blockDim.x) {
         const int n = nbond[i];
         if (n == 0) {
@@ -82,39 +75,8 @@ __global__ void __launch_bounds__(256) k_bond(const float4 *__restrict__ coord4,
             continue;
         }
         const float4 c1 = coord4[i];
-        double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
-        for (int b = 0; b < n; b++) {
-            const int j = bond_idx[(size_t)i * bpa + b], type = bond_type[(size_t)i * bpa + b];
-            const float4 c2 = coord4[j];
-            if (STYLE == 0) {
-                double dx = min_image((double)c2.x - (double)c1.x, px);
-                double dy = min_image((double)c2.y - (double)c1.y, py);
-                double dz = min_image((double)c2.z - (double)c1.z, pz);
-                double rsq = dx * dx + dy * dy + dz * dz;
-                double rinv = rsqrt(rsq);
-                double r = rinv * rsq;
-                double fbond = 2.0 * k[type] * (r - r0[type]) * rinv;
-                fx += dx * fbond; fy += dy * fbond; fz += dz * fbond;
-                if (EV) e += k[type] * (r - r0[type]) * (r - r0[type]);
-            } else {
-                double dx = min_image((double)c1.x - (double)c2.x, px);
-                double dy = min_image((double)c1.y - (double)c2.y, py);
-                double dz = min_image((double)c1.z - (double)c2.z, pz);
-                double rsq = dx * dx + dy * dy + dz * dz;
-                double r0sq = r0[type] * r0[type];
-                double rlogarg = fmax(0.1, 1.0 - rsq / r0sq);
-                double fbond = -k[type] / rlogarg;
-                if (EV) e += -0.5 * k[type] * r0sq * log(rlogarg);
-                const double s2 = sig[type] * sig[type];
-                if (rsq < 1.25992104989487316477 * s2) {      // 2^(1/3) sigma^2: the WCA part
-                    double sr2 = s2 / rsq;
-                    double sr6 = sr2 * sr2 * sr2;
-                    fbond += 48.0 * eps[type] * sr6 * (sr6 - 0.5) / rsq;
-                    if (EV) e += 4.0 * eps[type] * sr6 * (sr6 - 1.0) + eps[type];
-                }
-                fx += dx * fbond; fy += dy * fbond; fz += dz * fbond;
-            }
-        }
+        double fx, fy, fz, e;
+        bond_forces_of_atom<STYLE, EV>(coord4, c1, n, bond_idx + (size_t)i * bpa, bond_type + (size_t)i * bpa, sh, nbt, px, py, pz, fx, fy, fz, e);
         if (fx_) {   // null: energy-only pass (compute_ebond)
             if (store) { fx_[i] = fx; fy_[i] = fy; fz_[i] = fz; }
             else { fx_[i] += fx; fy_[i] += fy; fz_[i] += fz; }

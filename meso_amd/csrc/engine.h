@@ -209,6 +209,7 @@ private:
     int pair_kernel = 2;            // 0 lane-per-atom, 1 tile/brick, 2 auto (fp32 on cell rows: ring, fp64: MLP + compaction),
                                     // 3 MLP + ballot compaction, 4 MLP only
     int pair_debug = 0;             // timing ablations (bench only)
+    int fuse_bonds = 1;             // option: bond forces inside the force kernel's step-boundary epilogue (systems without angles)
     int pair_share = 1;             // fp32 ring kernel: pairs inside one aligned 256-atom group are evaluated once
     int fuse_pair = 1;              // step boundary in the epilogue of the fp32 ring kernel (no separate NVE pass, forces not stored)
     int fuse_step = 1;              // final(s)+initial(s+1)(+merge) in one kernel between steps of one run()

@@ -330,6 +330,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "reorder_cap") { reorder_cap_user = (int)val; return 0; }      // tests: force the ordering pass off its LDS stage
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "async_counts") { async_counts = (int)val; return 0; }
+    if (key == "fuse_bonds") { fuse_bonds = (int)val; return 0; }
     if (key == "overlap_rebuild") { overlap_rebuild = (int)val; return 0; }
     if (key == "ghost_epilogue") { ghost_epilogue = (int)val; return 0; }
     if (key == "async_grid_scale") { async_grid_scale = val; return 0; }      // tests: under-sized grids must still cover every ghost
@@ -1403,6 +1404,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     int beg, end;
     range(r, beg, end);
     PairArgs p;
+    p.bond.nbond = nullptr;
     p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
     for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
     int ev = (eflag || vflag) ? 1 : 0;
@@ -1496,6 +1498,8 @@ int Engine::run(int nsteps)
         if (!ghosts_fresh && !ghosts_by_epilogue) TRY(halo_forward_seed(sd, split));
         ghosts_by_epilogue = false;
         PairArgs p;
+        p.bond.nbond = nullptr;
+    p.bond.nbond = nullptr;
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
         for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
         p.e_pair = nullptr;
@@ -1518,9 +1522,21 @@ int Engine::run(int nsteps)
         const bool boundary_in_pair = fuse_pair && fuse_step && it + 1 < nsteps && (!have_bonds || bonded_first) && ring_selected();
         p.fuse_nve = boundary_in_pair ? 1 : 0;
         if (boundary_in_pair && bonded_first) {
-            TRY(bond_compute(0, 1));
-            TRY(angle_compute(0));
-            p.accumulate = 1;
+            if (fuse_bonds && !have_angles) {
+                // ... or, without angles, inside the force kernel's epilogue: each atom's few bonds are evaluated there (the same
+                // device function the bond kernel calls) - no bond launch, no force arrays written and read back
+                if (!d_bond_kr0) {
+                    HIPCHK(dalloc(d_bond_kr0, bond_kr0.size()));
+                    HIPCHK(hipMemcpy(d_bond_kr0, bond_kr0.data(), bond_kr0.size() * sizeof(double), hipMemcpyHostToDevice));
+                }
+                p.bond.nbond = cur.nbond; p.bond.bond_idx = bond_idx; p.bond.bond_type = cur.bond_type;
+                p.bond.bpa = bpa; p.bond.nbt = nbondtypes; p.bond.style = bond_kind; p.bond.cf = d_bond_kr0;
+                for (int d = 0; d < 3; d++) p.bond.prd[d] = prd[d];
+            } else {
+                TRY(bond_compute(0, 1));
+                TRY(angle_compute(0));
+                p.accumulate = 1;
+            }
         }
         if (boundary_in_pair)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,

@@ -119,6 +119,13 @@ struct NveArgs {
 NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,
                       float4 *veloc4_next, double cx, double cy, double cz, uint32_t seed_next);
 
+// bonds evaluated by the force kernel's epilogue (nbond null: none)
+struct BondArgs {
+    const int *nbond, *bond_idx, *bond_type;
+    int bpa, nbt, style;
+    const double *cf;
+    double prd[3];
+};
 struct PairArgs {
     const float4 *coord4, *veloc4;
     const int *count, *table;
@@ -147,6 +154,7 @@ struct PairArgs {
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;
     NveArgs nve;
+    BondArgs bond;        // with fuse_nve: this atom's bond forces are computed in the epilogue and added before the step boundary
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // fp32 style on chunked-8 rows: light cutoff scan per lane, hits compacted into a per-wave LDS ring of 4-byte

@@ -404,4 +404,57 @@ __device__ inline u64 to_fixed(float x)
 }
 __device__ inline double from_fixed(u64 a) { return (double)(long long)a * (1.0 / 4294967296.0); }
 
+__host__ __device__ inline double min_image(double dr, double p)   // math_meso.h:148-152
+{
+    double ph = p * 0.5;
+    return dr + (dr > -ph ? (dr < ph ? 0.0 : -p) : p);
+}
+
+// Bond forces (and energy) of one atom from its bond list; shared by k_bond (bond.hip) and by the force kernel's step-boundary
+// epilogue (pair_ring.hip), so that both give the same bits: compiled uncontracted whatever the caller's setting.
+// STYLE 0: harmonic (coefficient table [k][r0], gpu_bond_harmonic bond_harmonic_meso.cu:46-117); STYLE 1: FENE
+// ([k][r0][epsilon][sigma]), bond_fene_meso.cu:82-147 == BondFENE::compute src/MOLECULE/bond_fene.cpp:48-124 with the
+// warning/abort branches replaced by the clamp the reference's kernel applies.  cf: nbt + 1 entries per coefficient.
+template <int STYLE, bool EV>
+__device__ inline void bond_forces_of_atom(const float4 *__restrict__ coord4, const float4 c1, int n, const int *__restrict__ idx,
+                                           const int *__restrict__ types, const double *cf, int nbt, double px, double py,
+                                           double pz, double &fx, double &fy, double &fz, double &e)
+{
+#pragma clang fp contract(off)
+    const double *k = cf, *r0 = cf + nbt + 1, *eps = cf + 2 * (nbt + 1), *sig = cf + 3 * (nbt + 1);
+    fx = 0.0; fy = 0.0; fz = 0.0; e = 0.0;
+    for (int b = 0; b < n; b++) {
+        const int j = idx[b], type = types[b];
+        const float4 c2 = coord4[j];
+        if (STYLE == 0) {
+            double dx = min_image((double)c2.x - (double)c1.x, px);
+            double dy = min_image((double)c2.y - (double)c1.y, py);
+            double dz = min_image((double)c2.z - (double)c1.z, pz);
+            double rsq = dx * dx + dy * dy + dz * dz;
+            double rinv = rsqrt(rsq);
+            double r = rinv * rsq;
+            double fbond = 2.0 * k[type] * (r - r0[type]) * rinv;
+            fx += dx * fbond; fy += dy * fbond; fz += dz * fbond;
+            if (EV) e += k[type] * (r - r0[type]) * (r - r0[type]);
+        } else {
+            double dx = min_image((double)c1.x - (double)c2.x, px);
+            double dy = min_image((double)c1.y - (double)c2.y, py);
+            double dz = min_image((double)c1.z - (double)c2.z, pz);
+            double rsq = dx * dx + dy * dy + dz * dz;
+            double r0sq = r0[type] * r0[type];
+            double rlogarg = fmax(0.1, 1.0 - rsq / r0sq);
+            double fbond = -k[type] / rlogarg;
+            if (EV) e += -0.5 * k[type] * r0sq * log(rlogarg);
+            const double s2 = sig[type] * sig[type];
+            if (rsq < 1.25992104989487316477 * s2) {      // 2^(1/3) sigma^2: the WCA part
+                double sr2 = s2 / rsq;
+                double sr6 = sr2 * sr2 * sr2;
+                fbond += 48.0 * eps[type] * sr6 * (sr6 - 0.5) / rsq;
+                if (EV) e += 4.0 * eps[type] * sr6 * (sr6 - 1.0) + eps[type];
+            }
+            fx += dx * fbond; fy += dy * fbond; fz += dz * fbond;
+        }
+    }
+}
+
 } // namespace meso

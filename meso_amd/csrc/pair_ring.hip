@@ -266,6 +266,19 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
         if (a.fuse_nve) {
             // final(s) + initial(s+1) (+ merge for s+1 into the other merged buffer: this step's is still being read)
             if (a.accumulate) { fx += a.f[0][i]; fy += a.f[1][i]; fz += a.f[2][i]; }
+            if (a.bond.nbond) {
+                // bonds of this atom (Bond::compute of the same step): the same uncontracted function the bond kernel calls
+                const int nb = a.bond.nbond[i];
+                if (nb > 0) {
+                    double bx, by, bz, be;
+                    const int *bi = a.bond.bond_idx + (size_t)i * a.bond.bpa, *bt = a.bond.bond_type + (size_t)i * a.bond.bpa;
+                    if (a.bond.style == 1)
+                        bond_forces_of_atom<1, false>(a.coord4, c1, nb, bi, bt, a.bond.cf, a.bond.nbt, a.bond.prd[0], a.bond.prd[1], a.bond.prd[2], bx, by, bz, be);
+                    else
+                        bond_forces_of_atom<0, false>(a.coord4, c1, nb, bi, bt, a.bond.cf, a.bond.nbt, a.bond.prd[0], a.bond.prd[1], a.bond.prd[2], bx, by, bz, be);
+                    fx += bx; fy += by; fz += bz;
+                }
+            }
             nve_boundary_atom(a.nve, i, fx, fy, fz);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }

@@ -230,3 +230,23 @@ def test_bonded_rebuild_without_host_round_trip_gives_the_same_trajectory():
     for other in res[1:]:
         for a, b in zip(res[0][:3], other[:3]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("bond", ["harmonic", "fene"])
+def test_bonds_in_the_force_kernel_epilogue_give_the_same_trajectory(bond):
+    """fuse_bonds (default): on steps whose step boundary runs in the force kernel's epilogue the bonds of an atom are
+    evaluated there too, with the device function the bond kernel calls - 23 steps are bit-identical to the run that launches
+    the bond kernel first (fuse_bonds 0) and to the run with every kernel on its own (fuse_pair 0)."""
+    from meso_amd.api import Meso
+    x, v, types, bonds, lo, hi = make_polymer_box(12, frac=0.4)
+    res = []
+    for opts in ((("fuse_bonds", 0),), (), (("fuse_pair", 0),)):
+        with Meso() as m:
+            for k, val in opts:
+                m.set_option(k, val)
+            _setup(m, x, v, types, bonds, lo, hi, sigma=3.0, special=(0.0, 1.0, 1.0), style="dpd/fast/meso", bond=bond)
+            m.run(23)
+            res.append(m.gather())
+    for other in res[1:]:
+        for a, b in zip(res[0][:3], other[:3]):
+            assert np.array_equal(a, b)
