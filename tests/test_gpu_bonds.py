@@ -6,7 +6,7 @@ import numpy as np
 from conftest import join_ranks
 import pytest
 
-from meso_amd.datagen import make_polymer_box
+from meso_amd.datagen import make_box, make_polymer_box
 
 pytestmark = pytest.mark.gpu
 
@@ -250,3 +250,35 @@ def test_bonds_in_the_force_kernel_epilogue_give_the_same_trajectory(bond):
     for other in res[1:]:
         for a, b in zip(res[0][:3], other[:3]):
             assert np.array_equal(a, b)
+
+
+def test_star_molecule_with_long_special_lists(oracle):
+    """A hub bead bonded to 20 arms: with special_bonds 0 0 0 the hub has 20 special partners and every arm has 20 too (the hub
+    and the 19 other arms) - longer than the 16 the exclusion filter keeps in registers, so the rest of the list is read from
+    memory (k_filter_exclusion, brick.hip).  Rows and forces against the oracle."""
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(8)
+    x = x.copy()
+    rng = np.random.default_rng(11)
+    hub = 100
+    arms = np.arange(200, 220)
+    d = rng.normal(size=(20, 3))
+    x[arms] = x[hub] + 0.45 * d / np.linalg.norm(d, axis=1)[:, None]
+    x = lo + np.mod(x - lo, hi - lo)
+    types = np.ones(len(x), np.int32)
+    types[arms] = 2
+    bonds = np.array([(hub + 1, a + 1, 1) for a in arms], np.int32)
+    s = _oracle(x, v, types, bonds, lo, hi, special=(0.0, 0.0, 0.0))
+    with Meso() as m:
+        _setup(m, x, v, types, bonds, lo, hi, special=(0.0, 0.0, 0.0))
+        xg, vg, fg, tag, typ = m.gather()
+        count, _ = m.neigh_table()
+        tag_dev = m.gather(by_tag=False)[3]
+        cnt = count[np.argsort(tag_dev)]
+        assert np.array_equal(cnt, s.count)
+        assert np.abs(fg - s.f).max() < 1e-9 * np.abs(s.f).max()
+        m.run(7)          # a rebuild with the long lists on the way
+        assert np.isfinite(m.gather()[0]).all()
+    # the arms sit within 0.9 of each other: without the filter each of them would list the other 20 beads of the star
+    s_none = _oracle(x, v, types, bonds, lo, hi, special=(1.0, 1.0, 1.0))
+    assert (s_none.count[arms] - s.count[arms]).min() >= 19
