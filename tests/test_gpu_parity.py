@@ -691,3 +691,31 @@ def test_dense_region_grows_the_brick_stage_instead_of_failing(Meso):
     assert np.array_equal(out["tile"][1], out["cell"][1])         # integer force sums: independent of the row order
     for a, b in zip(out["tile"][2], out["cell"][2]):
         assert np.array_equal(a, b)
+
+
+def test_brick_stage_grows_during_a_run_before_it_overflows(Meso):
+    """Two halves of the box driven against each other: the density around the mid-plane rises by a third within 60 steps.  The
+    tile builder's LDS stage (sized from the mean density at setup) would overflow; the engine has to notice the high-water
+    mark that the plan reports and enlarge the stage at a later rebuild - the run must finish and agree bit for bit with the
+    capacity-free cell builder."""
+    L = 16
+    x, v, lo, hi = make_box(L)
+    v = v.copy()
+    v[:, 0] += np.where(x[:, 0] < 0.5 * L, 9.0, -9.0)
+    out = {}
+    for name, nk in (("tile", 1), ("cell", 0)):
+        m = Meso()
+        m.set_option("neigh_kernel", nk)
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=2, check=False)
+        m.pair_style("dpd/fast/meso", 1.0, 12345)
+        m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+        m.timestep(0.005)
+        m.setup()
+        m.run(60)
+        out[name] = (m.gather(), m.neigh_info())
+        m.close()
+    assert out["tile"][1]["max_count"] > 75                    # really compressed (uniform rho = 4: about 65)
+    for a, b in zip(out["tile"][0][:3], out["cell"][0][:3]):
+        assert np.array_equal(a, b)
