@@ -22,7 +22,6 @@ namespace meso {
         if (_rc) return _rc;                                              \
     } while (0)
 
-static const double BIG = 1.0e20;
 
 int Engine::fail(int code, const std::string &msg)
 {
