@@ -421,33 +421,58 @@ __device__ inline int dir_of(const DirTab &T, int k)
     return d;
 }
 
-// 5 doubles per new ghost: x,y,z (shift applied), (tag,type), (mask,0)  [pack_border_vel without the velocities:
-// they follow with the first forward refresh]
+// 8 doubles per new ghost: x,y,z (shift applied), vx,vy,vz, (tag,type), (mask,0) [pack_border_vel]: with the velocities on board
+// the receiver builds the ghosts' merged float4 pairs itself (k_merge_ghosts) and a rebuild needs no ghost refresh exchange
+#define BORDER_DOUBLES 8
 __global__ void __launch_bounds__(256) k_pack_border_multi(AtomSoA a, const int *__restrict__ list, int n, DirTab T,
                                                            double *__restrict__ buf)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int d = dir_of(T, k), j = list[k];
-    double *o = buf + 5 * (size_t)(T.dst[d] + (k - T.start[d]));
+    double *o = buf + BORDER_DOUBLES * (size_t)(T.dst[d] + (k - T.start[d]));
     o[0] = a.x[0][j] + T.shift[d][0];
     o[1] = a.x[1][j] + T.shift[d][1];
     o[2] = a.x[2][j] + T.shift[d][2];
+    o[3] = a.v[0][j]; o[4] = a.v[1][j]; o[5] = a.v[2][j];
     int2 p = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], 0);
-    o[3] = *reinterpret_cast<double *>(&p);
-    o[4] = *reinterpret_cast<double *>(&r);
+    o[6] = *reinterpret_cast<double *>(&p);
+    o[7] = *reinterpret_cast<double *>(&r);
 }
 
 __global__ void __launch_bounds__(256) k_unpack_border(AtomSoA a, const double *__restrict__ buf, int base, int n)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    const double *o = buf + 5 * (size_t)g;
+    const double *o = buf + BORDER_DOUBLES * (size_t)g;
     int i = base + g;
     a.x[0][i] = o[0]; a.x[1][i] = o[1]; a.x[2][i] = o[2];
-    double t3 = o[3], t4 = o[4];
+    a.v[0][i] = o[3]; a.v[1][i] = o[4]; a.v[2][i] = o[5];
+    double t3 = o[6], t4 = o[7];
     int2 p = *reinterpret_cast<int2 *>(&t3), r = *reinterpret_cast<int2 *>(&t4);
     a.tag[i] = p.x; a.type[i] = p.y; a.mask[i] = r.x;
+}
+
+// merged float4 pairs of the ghosts a rebuild has just created, into their Morton(bin) slots: the values the sender's
+// k_pack_forward_multi would deliver (the ghost's fp64 position already carries the periodic shift, and the centre the sender
+// uses for this rank is this rank's own: same doubles, same roundings)
+__global__ void __launch_bounds__(256) k_merge_ghosts(AtomSoA a, int nlocal, int nghost, const int *__restrict__ gslot, double cx,
+                                                      double cy, double cz, u32 seed, float4 *__restrict__ coord4,
+                                                      float4 *__restrict__ veloc4)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nghost) return;
+    const int i = nlocal + g, out = gslot ? gslot[g] : g;
+    float4 c;
+    c.x = (float)(a.x[0][i] - cx);
+    c.y = (float)(a.x[1][i] - cy);
+    c.z = (float)(a.x[2][i] - cz);
+    c.w = __uint_as_float((u32)(a.type[i] - 1));
+    coord4[out] = c;
+    float4 v;
+    v.x = (float)a.v[0][i]; v.y = (float)a.v[1][i]; v.z = (float)a.v[2][i];
+    v.w = __uint_as_float(signature(seed, a.tag[i], v.x, v.y, v.z));
+    veloc4[out] = v;
 }
 
 // per-step payload into the peer-major staging: [coords of peer p][velocities of peer p] ...
@@ -722,8 +747,8 @@ int Engine::halo_borders_multi()
         }
     }
     if (nsend > send_cap) return fail(4, "send list capacity exceeded");
-    TRY(ensure_stage((size_t)std::max(std::max(stot, 1) * 5 * sizeof(double), (size_t)std::max(stot, 1) * 2 * sizeof(float4)),
-                     (size_t)std::max(std::max(rtot, 1) * 5 * sizeof(double), (size_t)std::max(rtot, 1) * 2 * sizeof(float4))));
+    TRY(ensure_stage((size_t)std::max(std::max(stot, 1) * BORDER_DOUBLES * sizeof(double), (size_t)std::max(stot, 1) * 2 * sizeof(float4)),
+                     (size_t)std::max(std::max(rtot, 1) * BORDER_DOUBLES * sizeof(double), (size_t)std::max(rtot, 1) * 2 * sizeof(float4))));
     if (nsend > 0) launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
     DirTab T;
     fill_dirtab(T, h_dir_start, peer_send_base, peer_index, peer_send_n, shift27, center27, false);
@@ -733,8 +758,8 @@ int Engine::halo_borders_multi()
     std::vector<void *> sb(np), rb(np);
     std::vector<size_t> sn(np), rn(np);
     for (int p = 0; p < np; p++) {
-        sb[p] = (double *)stage_send + 5 * (size_t)peer_send_base[p]; sn[p] = (size_t)peer_send_n[p] * 5 * sizeof(double);
-        rb[p] = (double *)stage_recv + 5 * (size_t)peer_recv_base[p]; rn[p] = (size_t)peer_recv_n[p] * 5 * sizeof(double);
+        sb[p] = (double *)stage_send + BORDER_DOUBLES * (size_t)peer_send_base[p]; sn[p] = (size_t)peer_send_n[p] * BORDER_DOUBLES * sizeof(double);
+        rb[p] = (double *)stage_recv + BORDER_DOUBLES * (size_t)peer_recv_base[p]; rn[p] = (size_t)peer_recv_n[p] * BORDER_DOUBLES * sizeof(double);
     }
     xchg_what = "border";
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
@@ -792,6 +817,17 @@ int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
     }
     HIPCHK(hipEventRecord(ev_halo, side));
     if (!async) HIPCHK(hipStreamWaitEvent(stream, ev_halo, 0));
+    tend("halo");
+    return 0;
+}
+
+// the ghosts of a rebuild as merged float4 pairs (several ranks): local, no exchange - their velocities came with the border message
+int Engine::merge_new_ghosts(uint32_t sd)
+{
+    if (nghost <= 0) return 0;
+    tbegin("halo");
+    hipLaunchKernelGGL(k_merge_ghosts, dim3((nghost + 255) / 256), dim3(256), 0, stream, cur, nlocal, nghost, layout >= 1 ? gslot : nullptr,
+                       0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), sd, coord4 + nlocal, veloc4 + nlocal);
     tend("halo");
     return 0;
 }

@@ -135,6 +135,7 @@ private:
     double reduce_global_sum(double v);
     // multi-rank (comm.hip)
     int xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf, const size_t *rbytes);
+    int merge_new_ghosts(uint32_t sd);
     int exchange_counts(int skip_stay, int *h_ds, std::vector<int> &send_n, std::vector<int> &recv_n, std::vector<int> &recv_dir);
     void build_peer_tables();
     int halo_borders_multi();

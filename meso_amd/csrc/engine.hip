@@ -1204,7 +1204,8 @@ int Engine::build_cells_and_table()
         if (!merged_in_reorder) TRY(merge_locals(sd_now));
         merged_in_reorder = false;
         {
-            const int rc_fwd = halo_forward_seed(sd_now);
+            // (several ranks: the border message carried the velocities, the ghosts' merged pairs are built locally)
+            const int rc_fwd = nranks > 1 ? merge_new_ghosts(sd_now) : halo_forward_seed(sd_now);
             build_images_now = false;
             if (rc_fwd) return rc_fwd;
         }
