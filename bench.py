@@ -214,21 +214,11 @@ def main():
         m.sync()
         torch.cuda.synchronize()
 
-    m.run(a.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    m.run(a.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda" if a.transport == "rccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    steps_per_s = a.steps / elapsed
-
     # ---- dominant kernel: pair force.  Average launch duration from HIP events recorded on the engine's
-    # stream around every launch of a second, profiled pass (events perturb the whole-step time, so they
-    # are kept out of the pass that produces `value`).
+    # stream around every launch of a separate, profiled pass (events perturb the whole-step time, so they
+    # are kept out of the pass that produces `value`).  The instrumented passes run BEFORE the timed region: it then
+    # starts on a device that has been busy for a while (steady clocks) - a cold 20-step sample reads ~5 % lower than the
+    # sustained rate (tools/run_overhead.py: the fixed cost of a run() call is only ~45 us).
     info = m.neigh_info()
     m.set_option("profile", 1)
     m.timer_reset()
@@ -275,6 +265,19 @@ def main():
     achieved = b_pair_only / t_alone / 1e9
     # measured peak beside the nominal one: a 1 GiB float4 copy on the same device (read + write bytes)
     copy_gbs = m.membw_probe(1 << 30, 5)
+    # ---- the timed region: W untimed warm-up steps, then exactly K steps between barriers
+    m.run(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    m.run(a.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda" if a.transport == "rccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps_per_s = a.steps / elapsed
+
     T = m.temperature()
     # the thermostat overshoots to ~1.5 in the first ~100 steps of a cold start and has relaxed to 1 by ~300
     settled = a.warmup + a.steps + a.profile_steps >= 500
