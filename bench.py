@@ -220,6 +220,7 @@ def main():
     # starts on a device that has been busy for a while (steady clocks) - a cold 20-step sample reads ~5 % lower than the
     # sustained rate (tools/run_overhead.py: the fixed cost of a run() call is only ~45 us).
     info = m.neigh_info()
+    m.run(100)          # (the instrumented passes want steady clocks too; not part of W or K)
     m.set_option("profile", 1)
     m.timer_reset()
     m.run(a.profile_steps)

@@ -29,12 +29,13 @@ __global__ void __launch_bounds__(256) k_tag_cell(const int *__restrict__ tag, c
 }
 
 __global__ void __launch_bounds__(256) k_set_map(const int *__restrict__ tagc, int nall, int nlocal, const int *__restrict__ nghost_dev, int maxtag,
-                                                 int *__restrict__ map)
+                                                 const u32 *__restrict__ bits, int *__restrict__ map)
 {
     if (nghost_dev) nall = nlocal + *nghost_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nall; i += gridDim.x * blockDim.x) {
         int t = tagc[i];
-        if (t >= 0 && t <= maxtag) atomicMin(map + t, i);
+        // (bits: only tags that a bond or an angle names are ever looked up - one scattered atomic per chain bead, not per atom)
+        if (t >= 0 && t <= maxtag && (!bits || ((bits[t >> 5] >> (t & 31)) & 1u))) atomicMin(map + t, i);
     }
 }
 
@@ -179,10 +180,10 @@ void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, c
     if (nlocal + nghost > 0)
         hipLaunchKernelGGL(k_tag_cell, dim3(nblk(nlocal + nghost, 256)), dim3(256), 0, s, tag, gslot, nlocal, nghost, nghost_dev, tagc);
 }
-void launch_set_map(const int *tagc, int nlocal, int nghost, const int *nghost_dev, int maxtag, int *map, hipStream_t s)
+void launch_set_map(const int *tagc, int nlocal, int nghost, const int *nghost_dev, int maxtag, const uint32_t *tagbits, int *map, hipStream_t s)
 {
     if (nlocal + nghost > 0)
-        hipLaunchKernelGGL(k_set_map, dim3(nblk(nlocal + nghost, 256)), dim3(256), 0, s, tagc, nlocal + nghost, nlocal, nghost_dev, maxtag, map);
+        hipLaunchKernelGGL(k_set_map, dim3(nblk(nlocal + nghost, 256)), dim3(256), 0, s, tagc, nlocal + nghost, nlocal, nghost_dev, maxtag, tagbits, map);
 }
 void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int *map, int maxtag, int nlocal, int *bond_idx,
                       int *missing, hipStream_t s)

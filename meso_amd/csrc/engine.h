@@ -310,6 +310,10 @@ private:
     std::vector<int> h_tags;                 // tags of the atoms kept at upload (topology is attached by tag)
     double *d_bond_kr0 = nullptr, *e_bond = nullptr;
     int *bond_idx = nullptr, *tagmap = nullptr, *tagc = nullptr;
+    // one bit per tag: referenced by a bond or an angle (only those enter the tag map of a rebuild); null: every tag does
+    uint32_t *tagbits = nullptr;
+    std::vector<uint32_t> h_tagbits;
+    int upload_tagbits();
     bool have_bonds = false;
     int alloc_topology(AtomSoA &a, int cap, int keep);
     int rebuild_topology();

@@ -77,7 +77,7 @@ void Engine::free_all()
     free_soa(cur); free_soa(alt);
     dfree(coord4); dfree(veloc4); dfree(coord4_next); dfree(veloc4_next);
     for (int k = 0; k < 6; k++) dfree(virial[k]);
-    dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc);
+    dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc); dfree(tagbits);
     dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
     dfree(pair_count); dfree(pair_table);
@@ -563,8 +563,21 @@ int Engine::bonds_upload(int nb, const int *ti, const int *tj, const int *bt)
     }
     dfree(tagmap);
     HIPCHK(dalloc(tagmap, (size_t)maxtag + 2));
+    // the tags a rebuild has to find: the ends of the bonds (angles add theirs); every rank holds the whole list
+    h_tagbits.assign(((size_t)maxtag + 32) / 32, 0u);
+    for (int b = 0; b < nb; b++) { h_tagbits[ti[b] >> 5] |= 1u << (ti[b] & 31); h_tagbits[tj[b] >> 5] |= 1u << (tj[b] & 31); }
+    TRY(upload_tagbits());
     have_bonds = true;
     is_setup = false;
+    return 0;
+}
+
+int Engine::upload_tagbits()
+{
+    dfree(tagbits);
+    if (h_tagbits.empty()) return 0;
+    HIPCHK(dalloc(tagbits, h_tagbits.size()));
+    HIPCHK(hipMemcpy(tagbits, h_tagbits.data(), h_tagbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -575,7 +588,7 @@ int Engine::rebuild_topology()
     const int *ng_dev = counts_pending ? d_dir_start + 27 : nullptr;     // nghost is a launch bound while the counts travel
     launch_tag_cell(cur.tag, gslot, nlocal, nghost, ng_dev, tagc, stream);
     HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
-    launch_set_map(tagc, nlocal, nghost, ng_dev, maxtag, tagmap, stream);
+    launch_set_map(tagc, nlocal, nghost, ng_dev, maxtag, tagbits, tagmap, stream);
     // (d_flags[4] counts partners that are neither local nor ghost; it stays set until check_overflow reports it)
     launch_map_bonds(cur.nbond, cur.bond_tag, bpa, tagmap, maxtag, nlocal, bond_idx, d_flags + 4, stream);
     if (have_angles)
@@ -628,7 +641,9 @@ int Engine::angles_upload(int na, const int *t1, const int *t2, const int *t3, c
         if (t[0] == t[1] || t[1] == t[2] || t[0] == t[2]) return fail(1, "Invalid atom ID in Angles section of data file");
         if (nangletypes && (ty[a] < 1 || ty[a] > nangletypes)) return fail(1, "Invalid angle type in Angles section of data file");
         for (int c = 0; c < 3; c++) per[t[c]].push_back(a);
+        if (!h_tagbits.empty()) for (int c = 0; c < 3; c++) h_tagbits[t[c] >> 5] |= 1u << (t[c] & 31);
     }
+    TRY(upload_tagbits());
     int new_apa = 0;
     for (auto &v : per) new_apa = std::max(new_apa, (int)v.size());
     apa = std::max(new_apa, 1);

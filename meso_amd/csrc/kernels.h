@@ -213,7 +213,7 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
 
 // ---- bonded topology (bond.hip) -----------------------------------------------------------------------
 void launch_tag_cell(const int *tag, const int *gslot, int nlocal, int nghost, const int *nghost_dev, int *tagc, hipStream_t s);
-void launch_set_map(const int *tagc, int nlocal, int nghost, const int *nghost_dev, int maxtag, int *map, hipStream_t s);
+void launch_set_map(const int *tagc, int nlocal, int nghost, const int *nghost_dev, int maxtag, const uint32_t *tagbits, int *map, hipStream_t s);
 void launch_map_bonds(const int *nbond, const int *bond_tag, int bpa, const int *map, int maxtag, int nlocal,
                       int *bond_idx, int *missing, hipStream_t s);
 // gpu_map_angle (neighbor_meso.cu:161-182): tags -> indices, the atom's own tag -> itself

@@ -221,6 +221,9 @@ int Engine::read_restart(const std::string &path)
         }
         dfree(tagmap);
         HIPCHK(dalloc(tagmap, (size_t)maxtag + 2));
+        // (the file holds this rank's lists only: every tag enters the tag map after a restart)
+        h_tagbits.clear();
+        dfree(tagbits);
         have_bonds = true;
         have_angles = topo[6] != 0;
     }
