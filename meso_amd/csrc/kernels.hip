@@ -562,20 +562,24 @@ __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst,
     dst.mask[i] = src.mask[j];
     dst.image[i] = src.image[j];
     dst.mass[i] = src.mass[j];
+    // topology lists: only the entries in use travel (most atoms of a solution have none)
     if (src.bpa > 0) {
-        dst.nbond[i] = src.nbond[j];
-        for (int b = 0; b < src.bpa; b++) {
+        const int nb = src.nbond[j];
+        dst.nbond[i] = nb;
+        for (int b = 0; b < nb; b++) {
             dst.bond_tag[(size_t)i * src.bpa + b] = src.bond_tag[(size_t)j * src.bpa + b];
             dst.bond_type[(size_t)i * src.bpa + b] = src.bond_type[(size_t)j * src.bpa + b];
         }
     }
     if (src.apa > 0) {
-        dst.nangle[i] = src.nangle[j];
-        for (int a = 0; a < 4 * src.apa; a++) dst.angle_tag[(size_t)i * 4 * src.apa + a] = src.angle_tag[(size_t)j * 4 * src.apa + a];
+        const int na = src.nangle[j];
+        dst.nangle[i] = na;
+        for (int a = 0; a < 4 * na; a++) dst.angle_tag[(size_t)i * 4 * src.apa + a] = src.angle_tag[(size_t)j * 4 * src.apa + a];
     }
     if (src.msp > 0) {
-        dst.nspecial[i] = src.nspecial[j];
-        for (int s = 0; s < src.msp; s++) dst.special[(size_t)i * src.msp + s] = src.special[(size_t)j * src.msp + s];
+        const int ns = src.nspecial[j];
+        dst.nspecial[i] = ns;
+        for (int s = 0; s < ns; s++) dst.special[(size_t)i * src.msp + s] = src.special[(size_t)j * src.msp + s];
     }
 }
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s)
