@@ -45,6 +45,7 @@ struct LocalGroup {
     std::mutex m;
     std::condition_variable cv;
     int n = 0, arrived = 0;
+    int joined = 0;          // contexts that have taken their place (a full group is never joined again)
     long gen = 0;
     std::vector<LocalPost> post;
     void barrier()
@@ -62,8 +63,12 @@ static std::map<long, LocalGroup *> g_groups;
 static LocalGroup *local_group(long id, int n)
 {
     std::lock_guard<std::mutex> lk(g_groups_mutex);
+    // a group id names the NEXT n contexts that ask for it: once a group is complete a later run with the same id (or one that
+    // follows a run which ended with a rank stuck in a barrier) starts a fresh group instead of inheriting stale barrier state
+    // (complete groups stay allocated for their members; they are a few hundred bytes)
     LocalGroup *&g = g_groups[id];
-    if (!g) { g = new LocalGroup; g->n = n; g->post.resize(n); }
+    if (!g || g->joined >= g->n || g->n != n) { g = new LocalGroup; g->n = n; g->post.resize(n); }
+    g->joined++;
     return g;
 }
 
@@ -453,15 +458,125 @@ __global__ void __launch_bounds__(256) k_unpack_border(AtomSoA a, const double *
     a.tag[i] = p.x; a.type[i] = p.y; a.mask[i] = r.x;
 }
 
+// ------------------------------------------------------------------------------------------------
+// borders of several ranks WITHOUT a host round trip (option async_counts): fixed-capacity messages with the counts in band
+// ------------------------------------------------------------------------------------------------
+// A border message to peer p is [header: the 27 per-direction counts as ints][payload: cap_s[p] ghosts of 8 doubles].  The
+// capacity is a function of the count the two ranks exchanged at the PREVIOUS rebuild (c + c/4 + 256) - the sender knows what it
+// sent, the receiver what it received, so both sides size the message alike without talking, and RCCL gets its host-side sizes
+// without the host ever reading this rebuild's counts.  Offsets on both sides are computed on the device (k_border_hdr,
+// k_border_unpack_hdr); the counts reach the host through pinned memory behind an event and are read when the next per-step
+// ghost refresh needs its tables (Engine::resolve_counts).  A count beyond the capacity is an error reported at the end of
+// run(), never a truncated ghost list.
+#define MR_HDR_DOUBLES 16
+struct MrPlan {
+    int np;
+    int pidx[27];                  // peer index of each direction (-1: nothing goes that way)
+    int cap_s[26], cap_r[26];      // atoms
+    long base_s[26], base_r[26];   // first double of each peer's block in stage_send / stage_recv
+};
+// d_mr (ints): [0..26] slot of each direction's segment inside its peer's payload, [32..57] my count per peer, [64] ghosts
+// received, [65..91] first ghost of each peer (arrival order), [65 + np] = [64]
+#define MR_NGHOST 64
+#define MR_GBASE 65
+
+__global__ void __launch_bounds__(64) k_border_hdr(const int *__restrict__ ds, MrPlan P, int *__restrict__ d_mr, double *__restrict__ stage_send,
+                                                   int *__restrict__ flags, int *__restrict__ report)
+{
+    __shared__ int cnt[27];
+    const int t = threadIdx.x;
+    if (t < 27) cnt[t] = ds[t + 1] - ds[t];
+    __syncthreads();
+    if (t < P.np) {
+        int fill = 0;
+        int *hdr = reinterpret_cast<int *>(stage_send + P.base_s[t]);
+        for (int d = 0; d < 27; d++) {
+            const bool mine = P.pidx[d] == t;
+            hdr[d] = mine ? cnt[d] : 0;
+            if (mine) { d_mr[d] = fill; fill += cnt[d]; }
+        }
+        d_mr[32 + t] = fill;
+        report[32 + t] = fill;
+        if (fill > P.cap_s[t]) flags[0] = 200002;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack_border_fixed(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
+                                                           MrPlan P, Shift27 sh, const int *__restrict__ d_mr, double *__restrict__ stage_send)
+{
+    __shared__ int ds[28], dst[27];
+    if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
+    if (threadIdx.x < 27) dst[threadIdx.x] = d_mr[threadIdx.x];
+    __syncthreads();
+    for (int k = blockDim.x * blockIdx.x + threadIdx.x; k < ds[27]; k += gridDim.x * blockDim.x) {      // (the grid is an estimate)
+        const int d = dir_of_entry(ds, k), p = P.pidx[d], j = list[k];
+        if (p < 0) continue;
+        const int q = dst[d] + (k - ds[d]);
+        if (q >= P.cap_s[p]) continue;                      // (flagged by k_border_hdr)
+        double *o = stage_send + P.base_s[p] + MR_HDR_DOUBLES + BORDER_DOUBLES * (size_t)q;
+        o[0] = a.x[0][j] + sh.s[d][0];
+        o[1] = a.x[1][j] + sh.s[d][1];
+        o[2] = a.x[2][j] + sh.s[d][2];
+        o[3] = a.v[0][j]; o[4] = a.v[1][j]; o[5] = a.v[2][j];
+        int2 pp = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], 0);
+        o[6] = *reinterpret_cast<double *>(&pp);
+        o[7] = *reinterpret_cast<double *>(&r);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_border_unpack_hdr(const double *__restrict__ stage_recv, MrPlan P, int room, int *__restrict__ d_mr,
+                                                          int *__restrict__ flags, int *__restrict__ report)
+{
+    __shared__ int c[27];
+    const int t = threadIdx.x;
+    if (t < P.np) {
+        const int *hdr = reinterpret_cast<const int *>(stage_recv + P.base_r[t]);
+        int n = 0;
+        for (int d = 0; d < 27; d++) n += hdr[d];
+        if (n > P.cap_r[t] || n < 0) { flags[0] = 200002; n = 0; }
+        c[t] = n;
+        report[t] = n;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int p = 0; p < P.np; p++) { d_mr[MR_GBASE + p] = run; run += c[p]; }
+        if (run > room) { flags[0] = 200002; run = 0; }
+        d_mr[MR_GBASE + P.np] = run;
+        d_mr[MR_NGHOST] = run;
+        report[31] = run;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_unpack_border_fixed(AtomSoA a, const double *__restrict__ stage_recv, MrPlan P,
+                                                             const int *__restrict__ d_mr, int nlocal)
+{
+    __shared__ int gb[28];
+    if ((int)threadIdx.x <= P.np) gb[threadIdx.x] = d_mr[MR_GBASE + threadIdx.x];
+    __syncthreads();
+    const int ng = gb[P.np];
+    for (int g = blockDim.x * blockIdx.x + threadIdx.x; g < ng; g += gridDim.x * blockDim.x) {
+        int p = 0;
+        for (int t = 1; t < P.np; t++) p += (g >= gb[t]) ? 1 : 0;
+        const double *o = stage_recv + P.base_r[p] + MR_HDR_DOUBLES + BORDER_DOUBLES * (size_t)(g - gb[p]);
+        const int i = nlocal + g;
+        a.x[0][i] = o[0]; a.x[1][i] = o[1]; a.x[2][i] = o[2];
+        a.v[0][i] = o[3]; a.v[1][i] = o[4]; a.v[2][i] = o[5];
+        double t3 = o[6], t4 = o[7];
+        int2 pp = *reinterpret_cast<int2 *>(&t3), r = *reinterpret_cast<int2 *>(&t4);
+        a.tag[i] = pp.x; a.type[i] = pp.y; a.mask[i] = r.x;
+    }
+}
+
 // merged float4 pairs of the ghosts a rebuild has just created, into their Morton(bin) slots: the values the sender's
 // k_pack_forward_multi would deliver (the ghost's fp64 position already carries the periodic shift, and the centre the sender
 // uses for this rank is this rank's own: same doubles, same roundings)
-__global__ void __launch_bounds__(256) k_merge_ghosts(AtomSoA a, int nlocal, int nghost, const int *__restrict__ gslot, double cx,
-                                                      double cy, double cz, u32 seed, float4 *__restrict__ coord4,
-                                                      float4 *__restrict__ veloc4)
+__global__ void __launch_bounds__(256) k_merge_ghosts(AtomSoA a, int nlocal, int nghost, const int *__restrict__ nghost_dev,
+                                                      const int *__restrict__ gslot, double cx, double cy, double cz, u32 seed,
+                                                      float4 *__restrict__ coord4, float4 *__restrict__ veloc4)
 {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nghost) return;
+    if (nghost_dev) nghost = *nghost_dev;          // (nghost only sized the grid while the counts are on their way to the host)
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < nghost; g += gridDim.x * blockDim.x) {
     const int i = nlocal + g, out = gslot ? gslot[g] : g;
     float4 c;
     c.x = (float)(a.x[0][i] - cx);
@@ -473,6 +588,7 @@ __global__ void __launch_bounds__(256) k_merge_ghosts(AtomSoA a, int nlocal, int
     v.x = (float)a.v[0][i]; v.y = (float)a.v[1][i]; v.z = (float)a.v[2][i];
     v.w = __uint_as_float(signature(seed, a.tag[i], v.x, v.y, v.z));
     veloc4[out] = v;
+    }
 }
 
 // per-step payload into the peer-major staging: [coords of peer p][velocities of peer p] ...
@@ -706,6 +822,7 @@ int Engine::migrate()
 // MesoComm::borders (comm_meso.cu:41-186) for nranks > 1
 int Engine::halo_borders_multi()
 {
+    if (mr_async_ok()) return halo_borders_multi_async();
     tbegin("halo");
     // (bulk_pending: the reorder left the bulk count on its way to the host - the scan then covers every local atom, bulk atoms
     // carry no border flags, and the count arrives with the round trip below)
@@ -768,7 +885,130 @@ int Engine::halo_borders_multi()
                            nlocal, nghost);
     // tables of the per-step refresh
     fill_dirtab(fwd_tab_host(), h_dir_start, peer_send_base, peer_index, peer_send_n, shift27, center27, true);
+    mr_update_caps();
     tend("halo");
+    return 0;
+}
+
+// ---- the same stage with its counts left on the device (see the kernels above)
+bool Engine::mr_async_ok() const
+{
+    // (every term is the same on all ranks: the two sides of a message must choose the same format)
+    return async_counts && nranks > 1 && mr_caps_ready && !have_bonds && !ghost_sort && !reorder_sort;
+}
+
+void Engine::mr_update_caps()
+{
+    const int np = (int)peers.size();
+    mr_cap_s.assign(np, 0); mr_cap_r.assign(np, 0);
+    for (int p = 0; p < np; p++) {
+        // (integer arithmetic on the same inputs: both sides of a message get the same number)
+        const long m1024 = (long)(mr_cap_margin * 1024.0);
+        mr_cap_s[p] = (int)std::max(1L, peer_send_n[p] + peer_send_n[p] * m1024 / 1024 + (mr_cap_margin < 0 ? 0 : 256));
+        mr_cap_r[p] = (int)std::max(1L, peer_recv_n[p] + peer_recv_n[p] * m1024 / 1024 + (mr_cap_margin < 0 ? 0 : 256));
+    }
+    mr_caps_ready = np > 0 && np <= 26;
+}
+
+int Engine::halo_borders_multi_async()
+{
+    if (getenv("MESO_DEBUG_BUILD") && rank == 0) fprintf(stderr, "borders: fixed-capacity exchange, no host round trip (rank 0 caps %d...)\n", mr_cap_s.empty() ? 0 : mr_cap_s[0]);
+    tbegin("halo");
+    const int np = (int)peers.size();
+    MrPlan P;
+    P.np = np;
+    for (int d = 0; d < 27; d++) P.pidx[d] = d == 13 ? -1 : peer_index[d];
+    long bs = 0, br = 0;
+    int bound_s = 0, bound_r = 0;
+    for (int p = 0; p < 26; p++) { P.cap_s[p] = P.cap_r[p] = 0; P.base_s[p] = P.base_r[p] = 0; }
+    for (int p = 0; p < np; p++) {
+        P.cap_s[p] = mr_cap_s[p]; P.cap_r[p] = mr_cap_r[p];
+        P.base_s[p] = bs; bs += MR_HDR_DOUBLES + (long)BORDER_DOUBLES * mr_cap_s[p];
+        P.base_r[p] = br; br += MR_HDR_DOUBLES + (long)BORDER_DOUBLES * mr_cap_r[p];
+        bound_s += mr_cap_s[p]; bound_r += mr_cap_r[p];
+    }
+    // capacities first: nothing below may reallocate (the chunk arrays are regrown with the atoms)
+    TRY(ensure_capacity(nlocal + bound_r + 1));
+    TRY(ensure_stage((size_t)std::max((size_t)bs * sizeof(double), (size_t)std::max(bound_s, 1) * 2 * sizeof(float4)),
+                     (size_t)std::max((size_t)br * sizeof(double), (size_t)std::max(bound_r, 1) * 2 * sizeof(float4))));
+    if (bound_s > send_cap) return fail(4, "send list capacity exceeded");
+    if (!d_mr) { HIPCHK(hipMalloc((void **)&d_mr, 128 * sizeof(int))); HIPCHK(hipMemsetAsync(d_mr, 0, 128 * sizeof(int), stream)); }
+    if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
+    // border lists: every local atom while the bulk count of the reorder is still on the device, the border section otherwise
+    const int beg = bulk_pending ? 0 : n_bulk, end = nlocal;
+    const int nchunk = (end - beg + 255) / 256;
+    const int *nb_dev = estart + bargs.M;
+    if (nchunk > 0) {
+        launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
+        if (!launch_border_scan(chunk_count, chunk_offset, nchunk, d_dir_start, nb_dev, beg, std::min(bound_s, send_cap), d_flags, h_flags_dev, stream)) {
+            HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+            launch_dir_starts_check(chunk_offset, nchunk, d_dir_start, nb_dev, beg, std::min(bound_s, send_cap), d_flags, stream);
+            HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_flags + 8, d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_flags + 9, nb_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+        }
+    } else {
+        HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
+        for (int k = 0; k < 28; k++) h_flags[16 + k] = 0;
+        h_flags[8] = 0; h_flags[9] = n_bulk;
+    }
+    hipLaunchKernelGGL(k_border_hdr, dim3(1), dim3(64), 0, stream, d_dir_start, P, d_mr, (double *)stage_send, d_flags, h_flags_dev + 64);
+    if (nchunk > 0) launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
+    Shift27 sh;
+    for (int d = 0; d < 27; d++) for (int k = 0; k < 3; k++) sh.s[d][k] = shift27[3 * d + k];
+    if (bound_s > 0)
+        hipLaunchKernelGGL(k_pack_border_fixed, dim3((bound_s + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start, P, sh, d_mr,
+                           (double *)stage_send);
+    std::vector<void *> sb(np), rb(np);
+    std::vector<size_t> sn(np), rn(np);
+    for (int p = 0; p < np; p++) {
+        sb[p] = (double *)stage_send + P.base_s[p]; sn[p] = (size_t)(MR_HDR_DOUBLES + BORDER_DOUBLES * mr_cap_s[p]) * sizeof(double);
+        rb[p] = (double *)stage_recv + P.base_r[p]; rn[p] = (size_t)(MR_HDR_DOUBLES + BORDER_DOUBLES * mr_cap_r[p]) * sizeof(double);
+    }
+    xchg_what = "border (fixed capacity)";
+    TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
+    hipLaunchKernelGGL(k_border_unpack_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, nmax - nlocal - 1, d_mr, d_flags,
+                       h_flags_dev + 64);
+    if (bound_r > 0)
+        hipLaunchKernelGGL(k_unpack_border_fixed, dim3((bound_r + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv, P, d_mr,
+                           nlocal);
+    // the report (flag, bulk count, direction starts: k_border_scan; per-peer counts: the two header kernels) is in pinned memory
+    // once this event has passed
+    HIPCHK(hipMemcpyAsync(h_flags + 8, d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_counts, stream));
+    counts_pending = true;
+    mr_pending = true;
+    nsend = bound_s; nghost = bound_r;            // launch bounds until resolve_counts() has the numbers
+    tend("halo");
+    return 0;
+}
+
+// host tables of the exchange whose counts have just arrived (Engine::resolve_counts): what halo_borders_multi computes on the spot
+int Engine::mr_resolve()
+{
+    mr_pending = false;
+    const int np = (int)peers.size();
+    const int *rep = h_flags + 64;
+    nsend = h_dir_start[27];
+    peer_send_n.assign(np, 0); peer_recv_n.assign(np, 0);
+    for (int d = 0; d < 27; d++) {
+        if (h_dir_start[d + 1] - h_dir_start[d] && (d == 13 || peer_index[d] < 0)) return fail(5, "border list for an inactive direction");
+        if (d != 13 && peer_index[d] >= 0) peer_send_n[peer_index[d]] += h_dir_start[d + 1] - h_dir_start[d];
+    }
+    peer_send_base.assign(np, 0); peer_recv_base.assign(np + 1, 0);
+    int stot = 0, rtot = 0;
+    for (int p = 0; p < np; p++) {
+        peer_recv_n[p] = rep[p];
+        if (rep[32 + p] != peer_send_n[p]) return fail(5, "border exchange: the device-side and host-side send counts differ");
+        peer_send_base[p] = stot; stot += peer_send_n[p]; peer_recv_base[p] = rtot; rtot += peer_recv_n[p];
+    }
+    peer_recv_base[np] = rtot;
+    if (rtot != rep[31]) return fail(5, "border exchange: inconsistent ghost count report");
+    nghost = rtot;
+    TRY(ensure_stage((size_t)std::max(stot, 1) * 2 * sizeof(float4), (size_t)std::max(rtot, 1) * 2 * sizeof(float4)));
+    fill_dirtab(fwd_tab_host(), h_dir_start, peer_send_base, peer_index, peer_send_n, shift27, center27, true);
+    mr_update_caps();
     return 0;
 }
 
@@ -787,6 +1027,7 @@ void Engine::free_fwd_tab()
 // Comm::forward_comm for nranks > 1.  Split in two so the engine can run the bulk force kernel between them.
 int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
 {
+    TRY(resolve_counts());      // (the tables of the refresh come from the counts of the last rebuild)
     tbegin("halo");
     int np = (int)peers.size();
     if (nsend > 0)
@@ -826,7 +1067,7 @@ int Engine::merge_new_ghosts(uint32_t sd)
 {
     if (nghost <= 0) return 0;
     tbegin("halo");
-    hipLaunchKernelGGL(k_merge_ghosts, dim3((nghost + 255) / 256), dim3(256), 0, stream, cur, nlocal, nghost, layout >= 1 ? gslot : nullptr,
+    hipLaunchKernelGGL(k_merge_ghosts, dim3((nghost + 255) / 256), dim3(256), 0, stream, cur, nlocal, nghost, pending_nghost_dev(), layout >= 1 ? gslot : nullptr,
                        0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), sd, coord4 + nlocal, veloc4 + nlocal);
     tend("halo");
     return 0;

@@ -136,6 +136,16 @@ private:
     // multi-rank (comm.hip)
     int xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf, const size_t *rbytes);
     int merge_new_ghosts(uint32_t sd);
+    // several ranks, borders without a host round trip (comm.hip): fixed-capacity messages, counts in band
+    std::vector<int> mr_cap_s, mr_cap_r;          // ghosts per peer message, from the counts of the previous rebuild (same on both sides)
+    bool mr_caps_ready = false, mr_pending = false;
+    double mr_cap_margin = 0.25;                  // option: capacity = count * (1 + margin) + 256
+    int *d_mr = nullptr;                          // device-side offsets and counts of the exchange in flight (128 ints)
+    bool mr_async_ok() const;
+    void mr_update_caps();
+    int halo_borders_multi_async();
+    int mr_resolve();
+    const int *pending_nghost_dev() const { return !counts_pending ? nullptr : (mr_pending ? d_mr + 64 : d_dir_start + 27); }
     int exchange_counts(int skip_stay, int *h_ds, std::vector<int> &send_n, std::vector<int> &recv_n, std::vector<int> &recv_dir);
     void build_peer_tables();
     int halo_borders_multi();

@@ -89,7 +89,7 @@ void Engine::free_all()
     dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
-    dfree(d_partial); dfree(d_scalar); dfree(d_flags); dfree(sendlist_aux);
+    dfree(d_partial); dfree(d_scalar); dfree(d_flags); dfree(sendlist_aux); dfree(d_mr);
     if (stage_send) (void)hipFree(stage_send);
     if (stage_recv) (void)hipFree(stage_recv);
     stage_send = stage_recv = nullptr; stage_send_bytes = stage_recv_bytes = 0;
@@ -330,6 +330,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "async_counts") { async_counts = (int)val; return 0; }
     if (key == "fuse_bonds") { fuse_bonds = (int)val; return 0; }
+    if (key == "mr_cap_margin") { mr_cap_margin = val; return 0; }
     if (key == "overlap_rebuild") { overlap_rebuild = (int)val; return 0; }
     if (key == "ghost_epilogue") { ghost_epilogue = (int)val; return 0; }
     if (key == "async_grid_scale") { async_grid_scale = val; return 0; }      // tests: under-sized grids must still cover every ghost
@@ -373,7 +374,7 @@ int Engine::alloc_atoms(int cap)
         HIPCHK(dalloc(d_flags, 16));
         HIPCHK(dalloc(d_dir_start, 32));
         HIPCHK(dalloc(sendlist_aux, 2 * 27 * 27 + 64));
-        HIPCHK(hipHostMalloc((void **)&h_flags, 64 * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&h_flags, 128 * sizeof(int)));      // [64..127]: report of the multi-rank border exchange
         HIPCHK(hipHostMalloc((void **)&h_scalar, 16 * sizeof(double)));
         HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), stream));
     }
@@ -585,7 +586,7 @@ int Engine::upload_tagbits()
 int Engine::rebuild_topology()
 {
     if (!have_bonds) return 0;
-    const int *ng_dev = counts_pending ? d_dir_start + 27 : nullptr;     // nghost is a launch bound while the counts travel
+    const int *ng_dev = pending_nghost_dev();     // nghost is a launch bound while the counts travel
     launch_tag_cell(cur.tag, gslot, nlocal, nghost, ng_dev, tagc, stream);
     HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
     launch_set_map(tagc, nlocal, nghost, ng_dev, maxtag, tagbits, tagmap, stream);
@@ -1190,6 +1191,8 @@ int Engine::build_cells_and_table()
     {
         // locals are already cell-ordered by the reorder; only the ghosts need binning
         tbegin("bin");
+        // (the lane-per-atom builder and the sorting variants want the counts on the host)
+        if (counts_pending && mr_pending && !(neigh_kernel == 1 && n_col <= tile_build_rowcap() && tile_fits && !ghost_sort)) TRY(resolve_counts());
         bargs.active = nullptr;          // every brick, in workgroup-id order (brick_slot)
         bargs.nactive = bargs.nbricks;
         bargs.nactive_dev = nullptr;
@@ -1204,7 +1207,7 @@ int Engine::build_cells_and_table()
             launch_invert_perm(bin_val, gslot, nghost, stream);
         } else {
             // counting instead of sorting: 6 launches instead of ~18 (the ghosts' comparison sort was launch-bound)
-            const int *ng_dev = counts_pending ? d_dir_start + 27 : nullptr;     // nghost is a launch bound while the counts travel
+            const int *ng_dev = pending_nghost_dev();     // nghost is a launch bound while the counts travel
             launch_ghost_count(cur, geom, nlocal, nghost, bin_key, bin_val, gcount, ng_dev, stream);
             HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, gcount, gstart, bargs.M + 1, stream));
             launch_ghost_order(bin_key, bin_val, gstart, bargs.M, nghost, reorder_cap, (int *)bin_key_alt, bin_val_alt, (uint32_t *)rkey_alt, gslot,
@@ -1267,9 +1270,10 @@ int Engine::resolve_counts()
     HIPCHK(hipEventSynchronize(ev_counts));
     counts_pending = false;
     bulk_pending = false;
-    if (h_flags[8]) return check_overflow();
+    if (h_flags[8]) { mr_pending = false; return check_overflow(); }
     n_bulk = h_flags[9];
     for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];
+    if (mr_pending) return mr_resolve();
     nsend = nghost = h_dir_start[27];
     nghost_prev = nghost; n_bulk_prev = n_bulk;
     return 0;
@@ -1285,6 +1289,13 @@ int Engine::check_overflow()
     }
     if (h_flags[0]) {
         char buf[200];
+        if (h_flags[0] == 200002) {
+            HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+            counts_pending = mr_pending = false;
+            mr_caps_ready = false;
+            return fail(4, "A border message outgrew the capacity both ranks derived from the previous rebuild (ghost count up by more than a "
+                           "quarter within one rebuild interval): run again with option async_counts 0");
+        }
         if (h_flags[0] == 200000 || h_flags[0] == 200001) {
             HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
             counts_pending = false;
@@ -1506,10 +1517,12 @@ int Engine::run(int nsteps)
         }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
+        // (several ranks: the counts of the last rebuild have arrived long ago - the split point and the refresh tables need them)
+        if (mr_pending && !rebuild) TRY(resolve_counts());
         // bulk/border split point, rounded down to the force kernel's 256-atom groups (Newton pairing needs whole groups);
         // the few bulk atoms behind it simply wait for the ghosts too
         const int n_split = n_bulk & ~(pair_ring_group() - 1);
-        const bool split = nranks > 1 && overlap && n_split > 0 && n_split < nlocal;
+        const bool split = nranks > 1 && overlap && n_split > 0 && n_split < nlocal && !mr_pending;      // (pending: ghosts are fresh)
         if (!ghosts_fresh && !ghosts_by_epilogue) TRY(halo_forward_seed(sd, split));
         ghosts_by_epilogue = false;
         PairArgs p;

@@ -871,17 +871,6 @@ bool launch_border_scan(const int *cnt, int *off, int nchunk, int *dir_start, co
     return true;
 }
 
-struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0 when not crossing a PBC)
-struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction
-
-__device__ inline int dir_of_entry(const int *__restrict__ dir_start, int k)
-{
-    // dir_start[28]: exclusive offsets of each direction's segment in the send list
-    int d = 0;
-#pragma unroll
-    for (int q = 1; q < 27; q++) d += (k >= dir_start[q]) ? 1 : 0;
-    return d;
-}
 
 // pack_border_vel (atom_vec_dpd_atomic_meso.cu:61-135), device resident: x(+shift), tag, type, mask
 __global__ void __launch_bounds__(256) k_pack_border(AtomSoA a, const int *__restrict__ sendlist, int nsend,

@@ -404,6 +404,18 @@ __device__ inline u64 to_fixed(float x)
 }
 __device__ inline double from_fixed(u64 a) { return (double)(long long)a * (1.0 / 4294967296.0); }
 
+struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0 when not crossing a PBC)
+struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction
+
+__device__ inline int dir_of_entry(const int *__restrict__ dir_start, int k)
+{
+    // dir_start[28]: exclusive offsets of each direction's segment in the send list
+    int d = 0;
+#pragma unroll
+    for (int q = 1; q < 27; q++) d += (k >= dir_start[q]) ? 1 : 0;
+    return d;
+}
+
 __host__ __device__ inline double min_image(double dr, double p)   // math_meso.h:148-152
 {
     double ph = p * 0.5;

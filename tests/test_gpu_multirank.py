@@ -15,7 +15,7 @@ from meso_amd.datagen import make_box
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(nranks, grid, L, style, sigma, steps, every=5, overlap=1):
+def _run_ranks(nranks, grid, L, style, sigma, steps, every=5, overlap=1, opts=()):
     from meso_amd.api import Meso
     x, v, lo, hi = make_box(L)
     gid = np.frombuffer(np.random.default_rng(nranks * 1000 + L).bytes(8), np.uint8)
@@ -25,6 +25,8 @@ def _run_ranks(nranks, grid, L, style, sigma, steps, every=5, overlap=1):
         try:
             m = Meso()
             m.set_option("overlap", overlap)
+            for k, val in opts:
+                m.set_option(k, val)
             if nranks > 1:
                 m.comm_init(nranks, r, grid, "local", gid)
             m.read_atoms(x, v, lo, hi)
@@ -152,3 +154,43 @@ def test_rccl_communicator_next_to_torch_distributed():
         os.environ.pop("MESO_FORCE_RCCL", None)
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("every", [1, 3, 5])
+def test_borders_without_host_round_trip_equal_the_synchronous_path(every):
+    """Several ranks, option async_counts (default): from the second rebuild on the ghost stage sends fixed-capacity messages with
+    their counts in a header and leaves every count on the device until the next ghost refresh needs it.  Same ghosts in the
+    same order as the exact two-phase exchange: 23 steps on 2 x 2 x 2 ranks are bit-identical, for rebuilds on every step too."""
+    a = _run_ranks(8, (2, 2, 2), 12, "dpd/fast/meso", 3.0, 23, every=every, opts=(("async_counts", 0),))
+    b = _run_ranks(8, (2, 2, 2), 12, "dpd/fast/meso", 3.0, 23, every=every)
+    for k in range(3):
+        assert np.array_equal(a[1][k], b[1][k])
+    assert a[2] == b[2]                                   # (nlocal, nghost, nsend) of every rank
+
+
+def test_border_message_capacity_is_checked():
+    """A border message that outgrows the capacity both ranks derived from the previous rebuild must end the run with an error,
+    not with a truncated ghost list: with a negative margin (capacity = 60 % of the previous count) every rank reports it."""
+    from meso_amd.api import Meso, MesoError
+    x, v, lo, hi = make_box(12)
+    gid = np.frombuffer(np.random.default_rng(424242).bytes(8), np.uint8)
+    errs = [None, None]
+
+    def work(r):
+        m = Meso()
+        m.set_option("mr_cap_margin", -0.4)
+        m.comm_init(2, r, (2, 1, 1), "local", gid)
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3); m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style("dpd/fast/meso", 1.0, 419084618); m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0); m.timestep(0.005)
+        try:
+            m.setup()
+            m.run(7)
+        except MesoError as e:
+            errs[r] = str(e)
+        m.close()
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(2)]
+    [t.start() for t in th]
+    join_ranks(th, None, 120)
+    assert all(e and "capacity" in e for e in errs), errs
