@@ -56,7 +56,7 @@ int meso_device_sync(meso_ctx *ctx);
  *                    also grows it by itself: a first build that overflows is repeated, later ones grow from the high-water mark)
  *   async_counts  1  one rank: a rebuild does not wait for the host - launch bounds come from the previous rebuild's counts,
  *                    kernels mask with the device-side counts, the host reads them (pinned memory) when it next needs them;
- *                    several ranks (no bonds): the border messages of a rebuild have a fixed capacity derived from the previous
+ *                    several ranks: the border messages of a rebuild have a fixed capacity derived from the previous
  *                    rebuild's counts (count * (1 + mr_cap_margin) + 256, the same number on both sides) and carry their counts
  *                    in a header, so the ghost stage needs neither a count exchange nor a host round trip
  *   mr_cap_margin 0.25  see async_counts (a message that outgrows its capacity is an error, reported at the end of run())

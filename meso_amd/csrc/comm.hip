@@ -894,7 +894,7 @@ int Engine::halo_borders_multi()
 bool Engine::mr_async_ok() const
 {
     // (every term is the same on all ranks: the two sides of a message must choose the same format)
-    return async_counts && nranks > 1 && mr_caps_ready && !have_bonds && !ghost_sort && !reorder_sort;
+    return async_counts && nranks > 1 && mr_caps_ready && !ghost_sort && !reorder_sort;
 }
 
 void Engine::mr_update_caps()
