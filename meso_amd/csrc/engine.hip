@@ -731,6 +731,8 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
 {
     if (n < 0 || (n > 0 && (!x || !v || !tag || !type))) return fail(1, "Invalid atom arrays");      // a rank may start empty
     if (!have_box) return fail(3, "Box must be set before atoms are created");
+    // a new deck: the estimates and message capacities that earlier rebuilds left behind say nothing about it
+    nghost_prev = -1; n_bulk_prev = -1; mr_caps_ready = false; counts_pending = false; mr_pending = false; bulk_pending = false;
     // capacity: locals + expected ghosts (periodic images within cutghost) with head-room
     double ext = 1.0;
     double cg = (cut_global > 0 ? cut_global : 1.0) + skin;
