@@ -59,6 +59,8 @@ int meso_device_sync(meso_ctx *ctx);
  *                    several ranks: the border messages of a rebuild have a fixed capacity derived from the previous
  *                    rebuild's counts (count * (1 + mr_cap_margin) + 256, the same number on both sides) and carry their counts
  *                    in a header, so the ghost stage needs neither a count exchange nor a host round trip
+ *   mig_cap_floor 64  several ranks, async_counts: a migration message has the capacity 2 * (count of the previous rebuild) + floor and
+ *                    carries its counts in a header (no separate count exchange); one that does not fit is sent again, exactly
  *   mr_cap_margin 0.25  see async_counts (a message that outgrows its capacity is an error, reported at the end of run())
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
  *                    images (no k_pack_forward launch between rebuilds); -1 = for boxes of at most 524 288 local atoms, 0 off, 1 on

@@ -348,27 +348,13 @@ __global__ void __launch_bounds__(256) k_migrate_code(const double *__restrict__
 
 // ms doubles per migrant: x,y,z,vx,vy,vz,(tag,type),(mask,image) [+ nbond, nspecial, bond tags/types, special tags]
 #define MIG_HEAD 11      // doubles of a migration record before the topology words: x, v, (tag,type), (mask,image), f
-__global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
-                                                      const int *__restrict__ dir_dst, int n0, int n, int ms,
-                                                      double *__restrict__ buf)
+__device__ inline void pack_migrant(const AtomSoA &a, int j, int ms, double *o)
 {
-    // entries [n0, n0+n) of the direction-major list, skipping the stay segment handled by the caller
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    int k = n0 + q;
-    int d = 0;
-    for (int t = 1; t < 27; t++) d += (k >= dir_start[t]) ? 1 : 0;
-    int dst = dir_dst[d] + (k - dir_start[d]);
-    int j = list[k];
-    double *o = buf + (size_t)ms * dst;
     o[0] = a.x[0][j]; o[1] = a.x[1][j]; o[2] = a.x[2][j];
     o[3] = a.v[0][j]; o[4] = a.v[1][j]; o[5] = a.v[2][j];
     int2 p = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], a.image[j]);
     o[6] = *reinterpret_cast<double *>(&p);
     o[7] = *reinterpret_cast<double *>(&r);
-    // the forces travel too: the rebuild of setup() after read_restart must hand an atom that crossed a face since the
-    // file's last rebuild to its new owner WITH the force the first half-kick needs (restart_forces); elsewhere they are
-    // overwritten by the force computation that follows every rebuild
     o[8] = a.f[0][j]; o[9] = a.f[1][j]; o[10] = a.f[2][j];
     if (a.bpa > 0 || a.msp > 0) {
         int *t = reinterpret_cast<int *>(o + MIG_HEAD);
@@ -383,13 +369,23 @@ __global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__re
     }
 }
 
-__global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double *__restrict__ buf, const double *__restrict__ mass_type,
-                                                        int base, int n, int ms)
+__global__ void __launch_bounds__(256) k_pack_migrate(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
+                                                      const int *__restrict__ dir_dst, int n0, int n, int ms,
+                                                      double *__restrict__ buf)
 {
+    // entries [n0, n0+n) of the direction-major list, skipping the stay segment handled by the caller
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    const double *o = buf + (size_t)ms * q;
-    int i = base + q;
+    int k = n0 + q;
+    int d = 0;
+    for (int t = 1; t < 27; t++) d += (k >= dir_start[t]) ? 1 : 0;
+    if (dir_dst[d] < 0) return;                 // (resend of single messages: the other directions go nowhere)
+    int dst = dir_dst[d] + (k - dir_start[d]);
+    pack_migrant(a, list[k], ms, buf + (size_t)ms * dst);
+}
+
+__device__ inline void unpack_migrant(AtomSoA &a, int i, const double *o, const double *__restrict__ mass_type)
+{
     a.x[0][i] = o[0]; a.x[1][i] = o[1]; a.x[2][i] = o[2];
     a.v[0][i] = o[3]; a.v[1][i] = o[4]; a.v[2][i] = o[5];
     a.f[0][i] = o[8]; a.f[1][i] = o[9]; a.f[2][i] = o[10];
@@ -408,6 +404,93 @@ __global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double 
             for (int q = 0; q < 4 * a.apa; q++) a.angle_tag[(size_t)i * 4 * a.apa + q] = u[1 + q];
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_unpack_migrate(AtomSoA a, const double *__restrict__ buf, const double *__restrict__ mass_type,
+                                                        int base, int n, int ms)
+{
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    unpack_migrant(a, base + q, buf + (size_t)ms * q, mass_type);
+}
+
+// ---- migration with the counts in band (same scheme as the fixed-capacity border messages further down: header of 27
+// per-direction counts + capacity derived from the previous rebuild's count).  Migration still has its host round trip - the
+// local atom count changes with it - but no separate count exchange any more; a message that outgrows its capacity is simply sent
+// again, exactly, in a second exchange that costs nothing when nobody needs it (zero-size messages are not posted).
+#define MIG_HDR_DOUBLES 16
+struct MigPlan {
+    int np;
+    int pidx[27];                  // peer index of each direction (-1: stays / nothing goes that way)
+    int cap_s[26], cap_r[26];      // atoms
+    long base_s[26], base_r[26];   // first double of each peer's block in stage_send / stage_recv
+};
+
+// header of every peer's block + slot of each direction's segment inside its peer's payload (dst[27])
+__global__ void __launch_bounds__(64) k_mig_hdr(const int *__restrict__ ds, MigPlan P, int *__restrict__ dst, double *__restrict__ stage_send)
+{
+    __shared__ int cnt[27];
+    const int t = threadIdx.x;
+    if (t < 27) cnt[t] = ds[t + 1] - ds[t];
+    __syncthreads();
+    if (t < P.np) {
+        int fill = 0;
+        int *hdr = reinterpret_cast<int *>(stage_send + P.base_s[t]);
+        for (int d = 0; d < 27; d++) {
+            const bool mine = P.pidx[d] == t;
+            hdr[d] = mine ? cnt[d] : 0;
+            if (mine) { dst[d] = fill; fill += cnt[d]; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack_migrate_fixed(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
+                                                            MigPlan P, const int *__restrict__ dst_dev, int ms, double *__restrict__ stage_send)
+{
+    __shared__ int ds[28], dst[27];
+    if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
+    if (threadIdx.x < 27) dst[threadIdx.x] = dst_dev[threadIdx.x];
+    __syncthreads();
+    // the list holds every local atom, direction-major; the segment of direction 13 are the atoms that stay
+    const int nleave = ds[13] + (ds[27] - ds[14]);
+    for (int kk = blockDim.x * blockIdx.x + threadIdx.x; kk < nleave; kk += gridDim.x * blockDim.x) {
+        const int k = kk < ds[13] ? kk : kk - ds[13] + ds[14];
+        const int d = dir_of_entry(ds, k), p = P.pidx[d];
+        if (p < 0) continue;
+        const int q = dst[d] + (k - ds[d]);
+        if (q >= P.cap_s[p]) continue;                      // (the whole message follows in the second exchange)
+        pack_migrant(a, list[k], ms, stage_send + P.base_s[p] + MIG_HDR_DOUBLES + (size_t)ms * q);
+    }
+}
+
+// what each peer announces in its header: report[t] = migrants from peer t (also beyond the capacity)
+__global__ void __launch_bounds__(64) k_mig_read_hdr(const double *__restrict__ stage_recv, MigPlan P, int *__restrict__ report)
+{
+    const int t = threadIdx.x;
+    if (t < P.np) {
+        const int *hdr = reinterpret_cast<const int *>(stage_recv + P.base_r[t]);
+        int n = 0;
+        for (int d = 0; d < 27; d++) n += hdr[d];
+        report[t] = n;
+    }
+}
+
+struct MigSources {                // where each peer's migrants lie after the exchange(s)
+    int np;
+    int gbase[27];                 // first arrival of each peer, gbase[np] = total
+    long src[26];                  // first double of the peer's records (fixed block or the exact resend)
+    int second[26];                // 1: in the buffer of the second exchange
+};
+
+__global__ void __launch_bounds__(256) k_unpack_migrate_from(AtomSoA a, const double *__restrict__ first, const double *__restrict__ second,
+                                                             MigSources S, const double *__restrict__ mass_type, int base, int ms)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= S.gbase[S.np]) return;
+    int p = 0;
+    for (int t = 1; t < S.np; t++) p += (g >= S.gbase[t]) ? 1 : 0;
+    const double *o = (S.second[p] ? second : first) + S.src[p] + (size_t)ms * (g - S.gbase[p]);
+    unpack_migrant(a, base + g, o, mass_type);
 }
 
 struct DirTab {
@@ -761,6 +844,7 @@ int Engine::migrate()
     } else {
         HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
     }
+    if (async_counts && mig_caps_ready) { int rc = migrate_inband(); tend("migrate"); return rc; }
     // one host round trip: the "lost atoms" flag, my direction starts and the counts the peers announce arrive together
     HIPCHK(hipMemcpyAsync(h_flags + 3, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
     int ds[28], cnt[27];
@@ -815,7 +899,157 @@ int Engine::migrate()
         hipLaunchKernelGGL(k_unpack_migrate, dim3((nrecv_tot + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
                            d_mass_type, nstay, nrecv_tot, ms);
     nlocal = nstay + nrecv_tot;
+    mig_update_caps(send_n, recv_n);
     tend("migrate");
+    return 0;
+}
+
+void Engine::mig_update_caps(const std::vector<int> &send_n, const std::vector<int> &recv_n)
+{
+    // (the same number on both sides of a message: what A sent to B is what B received from A)
+    const int np = (int)peers.size();
+    mig_cap_s.assign(np, 0); mig_cap_r.assign(np, 0);
+    for (int p = 0; p < np; p++) { mig_cap_s[p] = 2 * send_n[p] + mig_cap_floor; mig_cap_r[p] = 2 * recv_n[p] + mig_cap_floor; }
+    mig_caps_ready = np > 0 && np <= 26;
+}
+
+// The exchange of migrate() with the counts in the messages (kernels above): fixed-capacity blocks, one host round trip for the
+// counts, and an exact resend in a second exchange for the (rare) message that did not fit - zero-size messages are not posted, so
+// that exchange costs nothing when nobody needs it, and the two ranks of a message decide alike (the sender knows its count, the
+// receiver reads it in the header).  Called with the migration lists built (sendlist, d_dir_start).
+int Engine::migrate_inband()
+{
+    const int np = (int)peers.size();
+    const int ms = mig_stride();
+    MigPlan P;
+    P.np = np;
+    for (int d = 0; d < 27; d++) P.pidx[d] = d == 13 ? -1 : peer_index[d];
+    long bs = 0, br = 0;
+    int bound_s = 0;
+    for (int p = 0; p < 26; p++) { P.cap_s[p] = P.cap_r[p] = 0; P.base_s[p] = P.base_r[p] = 0; }
+    for (int p = 0; p < np; p++) {
+        P.cap_s[p] = mig_cap_s[p]; P.cap_r[p] = mig_cap_r[p];
+        P.base_s[p] = bs; bs += MIG_HDR_DOUBLES + (long)ms * mig_cap_s[p];
+        P.base_r[p] = br; br += MIG_HDR_DOUBLES + (long)ms * mig_cap_r[p];
+        bound_s += mig_cap_s[p];
+    }
+    TRY(ensure_stage((size_t)bs * sizeof(double), (size_t)br * sizeof(double)));
+    if (!d_mr) { HIPCHK(hipMalloc((void **)&d_mr, 128 * sizeof(int))); HIPCHK(hipMemsetAsync(d_mr, 0, 128 * sizeof(int), stream)); }
+    if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
+    int *dst_dev = d_mr + 96;           // [96..122]: slot of each direction's segment inside its peer's payload
+    hipLaunchKernelGGL(k_mig_hdr, dim3(1), dim3(64), 0, stream, d_dir_start, P, dst_dev, (double *)stage_send);
+    if (nlocal > 0)
+        hipLaunchKernelGGL(k_pack_migrate_fixed, dim3(std::max(1, std::min((nlocal + 255) / 256, (bound_s + 255) / 256))), dim3(256), 0, stream,
+                           cur, sendlist, d_dir_start, P, dst_dev, ms, (double *)stage_send);
+    std::vector<void *> sb(np), rb(np);
+    std::vector<size_t> sn(np), rn(np);
+    for (int p = 0; p < np; p++) {
+        sb[p] = (double *)stage_send + P.base_s[p]; sn[p] = (size_t)(MIG_HDR_DOUBLES + (long)ms * mig_cap_s[p]) * sizeof(double);
+        rb[p] = (double *)stage_recv + P.base_r[p]; rn[p] = (size_t)(MIG_HDR_DOUBLES + (long)ms * mig_cap_r[p]) * sizeof(double);
+    }
+    xchg_what = "migration (fixed capacity)";
+    TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
+    // the one host round trip: lost-atom flag, my direction starts, the counts in the peers' headers
+    hipLaunchKernelGGL(k_mig_read_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, h_flags_dev + 96);
+    HIPCHK(hipMemcpyAsync(h_flags + 3, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (h_flags[3]) return fail(5, "Atoms moved further than one sub-domain between rebuilds (lost atoms)");
+    int ds[28], cnt[27];
+    for (int k = 0; k < 28; k++) ds[k] = h_flags[16 + k];
+    for (int d = 0; d < 27; d++) cnt[d] = ds[d + 1] - ds[d];
+    const int nstay = cnt[13];
+    std::vector<int> send_n(np, 0), recv_n(np, 0);
+    for (int d = 0; d < 27; d++) {
+        if (d == 13 || !cnt[d]) continue;
+        if (peer_index[d] < 0) return fail(5, "Atom left the box through a non-periodic boundary");
+        send_n[peer_index[d]] += cnt[d];
+    }
+    int nrecv_tot = 0;
+    bool again_s = false, again_r = false;
+    for (int p = 0; p < np; p++) {
+        recv_n[p] = h_flags[96 + p];
+        if (recv_n[p] < 0) return fail(5, "migration: corrupt message header");
+        nrecv_tot += recv_n[p];
+        again_s |= send_n[p] > mig_cap_s[p];
+        if (send_n[p] > mig_cap_s[p]) mig_resends++;
+        again_r |= recv_n[p] > mig_cap_r[p];
+    }
+    // second exchange: the messages that did not fit, whole and exact (sizes known on both sides now)
+    {
+        std::vector<int> sbase(np, 0), rbase(np, 0);
+        int stot = 0, rtot = 0;
+        for (int p = 0; p < np; p++) {
+            sbase[p] = stot; rbase[p] = rtot;
+            if (send_n[p] > mig_cap_s[p]) stot += send_n[p];
+            if (recv_n[p] > mig_cap_r[p]) rtot += recv_n[p];
+        }
+        if (again_s || again_r) {
+            if ((size_t)std::max(stot, 1) * ms * sizeof(double) > stage2_send_bytes) {
+                if (stage2_send) (void)hipFree(stage2_send);
+                stage2_send = nullptr;
+                stage2_send_bytes = (size_t)std::max(stot, 1) * ms * sizeof(double) * 2;
+                HIPCHK(hipMalloc(&stage2_send, stage2_send_bytes));
+            }
+            if ((size_t)std::max(rtot, 1) * ms * sizeof(double) > stage2_recv_bytes) {
+                if (stage2_recv) (void)hipFree(stage2_recv);
+                stage2_recv = nullptr;
+                stage2_recv_bytes = (size_t)std::max(rtot, 1) * ms * sizeof(double) * 2;
+                HIPCHK(hipMalloc(&stage2_recv, stage2_recv_bytes));
+            }
+        }
+        if (again_s) {
+            // exact pack of the directions whose peer needs the resend (k_pack_migrate over the whole list, others go nowhere)
+            std::vector<int> fill(sbase);
+            int h_dst[27];
+            for (int d = 0; d < 27; d++) {
+                h_dst[d] = -1;
+                const int q = peer_index[d];
+                if (d == 13 || q < 0 || send_n[q] <= mig_cap_s[q]) continue;
+                h_dst[d] = fill[q];
+                fill[q] += cnt[d];
+            }
+            HIPCHK(hipMemcpyAsync(sendlist_aux, h_dst, 27 * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (ds[13] > 0)
+                hipLaunchKernelGGL(k_pack_migrate, dim3((ds[13] + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start, sendlist_aux, 0,
+                                   ds[13], ms, (double *)stage2_send);
+            const int tail = ds[27] - ds[14];
+            if (tail > 0)
+                hipLaunchKernelGGL(k_pack_migrate, dim3((tail + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start, sendlist_aux, ds[14],
+                                   tail, ms, (double *)stage2_send);
+        }
+        std::vector<void *> sb2(np, nullptr), rb2(np, nullptr);
+        std::vector<size_t> sn2(np, 0), rn2(np, 0);
+        for (int p = 0; p < np; p++) {
+            if (send_n[p] > mig_cap_s[p]) { sb2[p] = (double *)stage2_send + (size_t)ms * sbase[p]; sn2[p] = (size_t)send_n[p] * ms * sizeof(double); }
+            if (recv_n[p] > mig_cap_r[p]) { rb2[p] = (double *)stage2_recv + (size_t)ms * rbase[p]; rn2[p] = (size_t)recv_n[p] * ms * sizeof(double); }
+        }
+        xchg_what = "migration (resend)";
+        TRY(xchg(np, peers.data(), sb2.data(), sn2.data(), rb2.data(), rn2.data()));
+        // where every peer's migrants lie
+        MigSources S;
+        S.np = np;
+        int run = 0;
+        for (int p = 0; p < 26; p++) { S.src[p] = 0; S.second[p] = 0; }
+        for (int p = 0; p < np; p++) {
+            S.gbase[p] = run; run += recv_n[p];
+            if (recv_n[p] > mig_cap_r[p]) { S.second[p] = 1; S.src[p] = (long)ms * rbase[p]; }
+            else S.src[p] = P.base_r[p] + MIG_HDR_DOUBLES;
+        }
+        for (int p = np; p < 27; p++) S.gbase[p] = run;
+        // compact the stayers (their order is preserved; the reorder follows anyway), then append the arrivals
+        if (nstay != nlocal) {
+            launch_permute_atoms(cur, alt, sendlist + ds[13], nstay, 1, stream);
+            std::swap(cur, alt);
+        }
+        TRY(ensure_capacity(nstay + nrecv_tot + 1));
+        if (nrecv_tot > 0)
+            hipLaunchKernelGGL(k_unpack_migrate_from, dim3((nrecv_tot + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
+                               (const double *)stage2_recv, S, d_mass_type, nstay, ms);
+        nlocal = nstay + nrecv_tot;
+    }
+    if (getenv("MESO_DEBUG_BUILD") && rank == 0 && (again_s || again_r)) fprintf(stderr, "migration: %ld message(s) of rank 0 sent again so far\n", mig_resends);
+    mig_update_caps(send_n, recv_n);
     return 0;
 }
 

@@ -141,6 +141,15 @@ private:
     bool mr_caps_ready = false, mr_pending = false;
     double mr_cap_margin = 0.25;                  // option: capacity = count * (1 + margin) + 256
     int *d_mr = nullptr;                          // device-side offsets and counts of the exchange in flight (128 ints)
+    // migration with the counts in the messages (comm.hip)
+    std::vector<int> mig_cap_s, mig_cap_r;
+    bool mig_caps_ready = false;
+    int mig_cap_floor = 64;                       // option: capacity of a migration message = 2 * previous count + floor
+    long mig_resends = 0;                         // messages that had to be sent again (statistics)
+    void *stage2_send = nullptr, *stage2_recv = nullptr;      // exact resend of a migration message that outgrew its capacity
+    size_t stage2_send_bytes = 0, stage2_recv_bytes = 0;
+    void mig_update_caps(const std::vector<int> &send_n, const std::vector<int> &recv_n);
+    int migrate_inband();
     bool mr_async_ok() const;
     void mr_update_caps();
     int halo_borders_multi_async();

@@ -93,6 +93,9 @@ void Engine::free_all()
     if (stage_send) (void)hipFree(stage_send);
     if (stage_recv) (void)hipFree(stage_recv);
     stage_send = stage_recv = nullptr; stage_send_bytes = stage_recv_bytes = 0;
+    if (stage2_send) (void)hipFree(stage2_send);
+    if (stage2_recv) (void)hipFree(stage2_recv);
+    stage2_send = stage2_recv = nullptr; stage2_send_bytes = stage2_recv_bytes = 0;
     free_fwd_tab();
     comm_free();
     if (ev_pack) (void)hipEventDestroy(ev_pack);
@@ -331,6 +334,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "async_counts") { async_counts = (int)val; return 0; }
     if (key == "fuse_bonds") { fuse_bonds = (int)val; return 0; }
     if (key == "mr_cap_margin") { mr_cap_margin = val; return 0; }
+    if (key == "mig_cap_floor") { mig_cap_floor = (int)val; return 0; }
     if (key == "overlap_rebuild") { overlap_rebuild = (int)val; return 0; }
     if (key == "ghost_epilogue") { ghost_epilogue = (int)val; return 0; }
     if (key == "async_grid_scale") { async_grid_scale = val; return 0; }      // tests: under-sized grids must still cover every ghost
@@ -732,7 +736,7 @@ int Engine::atoms_upload(int n, const double *x, const double *v, const int *tag
     if (n < 0 || (n > 0 && (!x || !v || !tag || !type))) return fail(1, "Invalid atom arrays");      // a rank may start empty
     if (!have_box) return fail(3, "Box must be set before atoms are created");
     // a new deck: the estimates and message capacities that earlier rebuilds left behind say nothing about it
-    nghost_prev = -1; n_bulk_prev = -1; mr_caps_ready = false; counts_pending = false; mr_pending = false; bulk_pending = false;
+    nghost_prev = -1; n_bulk_prev = -1; mr_caps_ready = false; mig_caps_ready = false; counts_pending = false; mr_pending = false; bulk_pending = false;
     // capacity: locals + expected ghosts (periodic images within cutghost) with head-room
     double ext = 1.0;
     double cg = (cut_global > 0 ? cut_global : 1.0) + skin;

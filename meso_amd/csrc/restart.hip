@@ -143,7 +143,7 @@ int Engine::write_restart(const std::string &path)
 int Engine::read_restart(const std::string &path)
 {
     // (the estimates and message capacities of earlier rebuilds say nothing about the state in the file)
-    nghost_prev = -1; n_bulk_prev = -1; mr_caps_ready = false; counts_pending = false; mr_pending = false; bulk_pending = false;
+    nghost_prev = -1; n_bulk_prev = -1; mr_caps_ready = false; mig_caps_ready = false; counts_pending = false; mr_pending = false; bulk_pending = false;
     FILE *f = fopen(rank_path(path, nranks, rank).c_str(), "rb");
     if (!f) return fail(2, "Cannot open restart file " + path);
     FileCloser fc{f};

@@ -166,6 +166,12 @@ def test_borders_without_host_round_trip_equal_the_synchronous_path(every):
     for k in range(3):
         assert np.array_equal(a[1][k], b[1][k])
     assert a[2] == b[2]                                   # (nlocal, nghost, nsend) of every rank
+    # migration messages carry their counts too (capacity 2 x previous count + 64); with the floor at 0 every message that follows
+    # a rebuild without migrants to that peer does not fit and is sent again, exactly: still the same trajectory
+    c = _run_ranks(8, (2, 2, 2), 12, "dpd/fast/meso", 3.0, 23, every=every, opts=(("mig_cap_floor", 0),))
+    for k in range(3):
+        assert np.array_equal(a[1][k], c[1][k])
+    assert a[2] == c[2]
 
 
 def test_border_message_capacity_is_checked():
