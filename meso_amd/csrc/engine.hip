@@ -1347,9 +1347,9 @@ int Engine::reneighbor()
         TRY(reorder_locals());
         TRY(halo_borders());
     }
-    // neighbour rows and the ring records of the force kernel keep atom indices in 25 bits (pair_ring.hip, meso_device.h)
-    if ((long)nlocal + nghost > (1L << 25))
-        return fail(4, "Too many atoms on one rank: local + ghost atoms exceed 33554432 (25-bit neighbour indices); use more ranks");
+    // the gathers of the force kernel address the merged arrays through 32-bit byte offsets (16 bytes per atom)
+    if ((long)nlocal + nghost >= (1L << 28))
+        return fail(4, "Too many atoms on one rank: local + ghost atoms exceed 268435456 (32-bit byte offsets of the gathers); use more ranks");
     TRY(build_cells_and_table());
     if (dist_check) launch_copy_hold(cur, xhold, nlocal, nmax, stream);
     ago = 0;

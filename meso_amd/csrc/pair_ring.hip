@@ -55,7 +55,9 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 // uncontracted functions of meso_device.h, 36-fractional-bit fixed-point sums)
 // TY: 0 one atom type (coefficients are kernel-argument constants), 1 several types with ONE cutoff (the cutoff test stays scalar),
 // 2 several types, cutoff per type pair
-template <bool FAST, int TY, bool EW1, bool SHARE, int NPART>
+// NPART_: lanes per atom (1, 2, 4); 0 = one lane per atom with WIDE records for more than 2^25 atoms on a rank: the record word
+// is the whole 32-bit partner index, owner lane and pairing flag travel in a byte ring next to it
+template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_>
 __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
@@ -63,6 +65,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
     float *cf32 = (float *)smem;
     double *cf64 = smem;
     constexpr bool NT1 = TY == 0, UCUT = TY <= 1;
+    constexpr bool WIDE = NPART_ == 0;
+    constexpr int NPART = WIDE ? 1 : NPART_;
     // fp32 style: rows of 8 floats (a0, gamma, sigma, s | 1/rc, rc^2, rc, -): one 16-byte LDS read per evaluated pair
     constexpr int CFP = FAST ? 8 : N_COEFF;
     const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * CFP;
@@ -74,13 +78,14 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
     }
     const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (NT1 ? 0 : RG_RING);
+    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (NT1 ? 0 : RG_RING) + (WIDE ? RG_RING : 0);
     u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
     char *wb = (char *)smem + off + 3 * 64 * RG_WAVES * 8 + (size_t)w * per_wave;      // (accumulator area sized for NPART = 1)
     float4 *own_c = (float4 *)wb;
     float4 *own_v = own_c + 64;
     float4 *ring = own_v + 64;          // (partner x, y, z, record word): the coordinate is not gathered twice
     unsigned char *ringt = (unsigned char *)(ring + RG_RING);     // several types: the partner's type next to its record
+    unsigned char *ringm = ringt + (NT1 ? 0 : RG_RING);           // WIDE: owner lane | pairing flag << 6
 
     const int nbk = gridDim.x;
     const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
@@ -117,14 +122,14 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
 
     int qhead = 0, qtail = 0;     // wave-uniform
     int pn = 0;                   // records of the batch whose gathers are in flight
-    u32 pe = 0;
+    u32 pe = 0, pm = 0;
     float4 pc2 = make_float4(0.f, 0.f, 0.f, 0.f), pv2 = pc2;
 
     // evaluate the pending batch (lane = hit)
     auto compute = [&]() {
         if (pn > 0) {
             if (lane < pn) {
-                const u32 owner = pe >> RG_OWNER_SHIFT;
+                const u32 owner = WIDE ? (pm & 63u) : pe >> RG_OWNER_SHIFT;
                 const float4 ci = own_c[owner], vi = own_v[owner];
                 u64 qx, qy, qz;
                 if (FAST) {
@@ -172,10 +177,10 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                 __hip_atomic_fetch_add(&facc[oo], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[NB + oo], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[2 * NB + oo], qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (SHARE && (pe & RG_SHARED_BIT)) {
+                if (SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT))) {
                     // the partner is one of this workgroup's atoms: it receives the opposite force now and skips its own
                     // (mirrored) row entry
-                    const u32 pj = (pe & RG_INDEX_MASK) - (u32)blockbase;
+                    const u32 pj = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;
                     __hip_atomic_fetch_sub(&facc[pj], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_sub(&facc[NB + pj], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_sub(&facc[2 * NB + pj], qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -190,7 +195,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
             const float4 rec = ring[(qhead + lane) & (RG_RING - 1)];
             pe = __float_as_uint(rec.w);
             pc2 = make_float4(rec.x, rec.y, rec.z, 0.f);
-            const u32 joff = (pe & RG_INDEX_MASK) << 4;
+            if (WIDE) pm = ringm[(qhead + lane) & (RG_RING - 1)];
+            const u32 joff = (WIDE ? pe : (pe & RG_INDEX_MASK)) << 4;
             if (!NT1) pc2.w = __uint_as_float((u32)ringt[(qhead + lane) & (RG_RING - 1)]);     // (a fourth gather per hit before)
             pv2 = buf_load4(rv, joff);
         }
@@ -246,7 +252,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
             }
             if (hit) {
                 const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1);
-                ring[pos] = make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float((u32)j[q] | ((SHARE && shb[q]) ? lanehi | RG_SHARED_BIT : lanehi)));   // record word last
+                ring[pos] = make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float(WIDE ? (u32)j[q] : ((u32)j[q] | ((SHARE && shb[q]) ? lanehi | RG_SHARED_BIT : lanehi))));   // record word last
+                if (WIDE) ringm[pos] = (unsigned char)((u32)slot | ((SHARE && shb[q]) ? 64u : 0u));
                 if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(c2[q].w);
             }
             qtail += __popcll(m);
@@ -291,7 +298,9 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     if (n <= 0) return;
     const bool nt1 = p.ntypes == 1;
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * (fast ? 8 * 4 : N_COEFF * 8);
-    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (nt1 ? 0 : RG_RING) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
+    // more than 2^25 atoms (locals + ghosts): the record word cannot hold owner lane, pairing flag and index any more
+    const bool wide = (long)p.nall > (1L << 25) || p.debug == 9;      // (debug 9: the wide records on a small system - tests)
+    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (nt1 ? 0 : RG_RING) + (wide ? RG_RING : 0) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
     // small launches: 2 lanes per atom, so that the same atoms fill twice as many waves (a 32^3 box is 2048 waves for 1024
     // SIMDs otherwise, and each wave walks 7 row chunks and ~11 hit batches one after the other)
@@ -299,6 +308,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     // four lanes per atom never beat two)
     int npart = p.npart > 0 ? p.npart : (n <= 163840 ? 2 : 1);
     if (npart != 1 && npart != 2 && npart != 4) npart = 1;
+    if (wide) npart = 1;
     const int awg = 64 / npart * RG_WAVES;
     dim3 grid(((n + awg - 1) / awg + 7) / 8 * 8), block(64 * RG_WAVES);
     // p.debug 3/4: occupancy ablation - pad the LDS request so that only 3 / 4 workgroups fit a CU (default: 5)
@@ -313,7 +323,8 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     const bool share = p.share != 0 && (p.beg & (RG_GROUP - 1)) == 0;
 #define RG_LAUNCH(F, A, B, C)                                                                                   \
     do {                                                                                                        \
-        if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4>), grid, block, sm, s, p);            \
+        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0>), grid, block, sm, s, p);                  \
+        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4>), grid, block, sm, s, p);       \
         else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2>), grid, block, sm, s, p);       \
         else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1>), grid, block, sm, s, p);                       \
     } while (0)

@@ -228,3 +228,34 @@ def test_config2_64cube_against_the_pinned_cpu_restatement(oracle, style, tol_f)
         d -= np.round(d / (hi - lo)) * (hi - lo)
         assert np.abs(d).max() < 2e-5 and np.abs(vg - vs).max() < 4e-4
         assert m.temperature() == pytest.approx(s.temperature, rel=1e-6)
+
+
+def test_256cube_on_one_gpu_beyond_2_25_atoms():
+    """67 108 864 atoms (+ 2.4 M ghosts) on ONE MI355X (about 90 GB of its 288 GB): more atoms than the 25-bit index of the
+    force kernel's record word can name, so the launcher switches to the wide records (whole 32-bit index, owner lane and
+    pairing flag in a byte ring; bit-identical forces at small sizes: test_lanes_per_atom_give_identical_forces).  Size-independent
+    properties: every pair force has its opposite, the list holds the expected 35.8 entries per atom, 10 steps with two rebuilds
+    conserve momentum and atom identities."""
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(256)
+    n = len(x)
+    assert n == 4 * 256 ** 3 and n > 2 ** 25
+    with Meso() as m:
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style("dpd/fast/meso", 1.0, 419084618)
+        m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+        m.timestep(0.005)
+        m.setup()
+        info = m.neigh_info()
+        assert abs(info["avg_count"] - 35.82) < 0.2 and info["max_count"] < 90
+        f = m.gather()[2]
+        scale = np.abs(f).max()
+        assert 50 < scale < 1500 and np.abs(f.sum(0)).max() < 2e-4 * scale * np.sqrt(n)
+        del f
+        m.run(10)
+        xg, vg, fg, tag, typ = m.gather()
+        assert np.array_equal(tag, np.arange(1, n + 1))
+        assert np.abs(vg.sum(0)).max() < 1e-5 * n
+        assert 0.8 < m.temperature() < 2.0

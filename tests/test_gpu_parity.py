@@ -22,7 +22,9 @@ pytestmark = pytest.mark.gpu
 # tile builder; lane-per-atom cell builder), ring with and without Newton pairing / two lanes per atom
 PATHS = {"ring": (("pair_kernel", 2),), "lane": (("pair_kernel", 0),), "ring+cell-builder": (("pair_kernel", 2), ("neigh_kernel", 0)),
          "lane+cell-builder": (("pair_kernel", 0), ("neigh_kernel", 0)), "ring-unpaired": (("pair_share", 0),),
-         "ring-1-lane": (("pair_npart", 1),), "ring-4-lanes": (("pair_npart", 4),), "ring-unfused": (("fuse_pair", 0),)}
+         "ring-1-lane": (("pair_npart", 1),), "ring-4-lanes": (("pair_npart", 4),), "ring-unfused": (("fuse_pair", 0),),
+         # the record format for more than 2^25 atoms on a rank (whole 32-bit index, owner lane and pairing flag in a byte ring), forced
+         "ring-wide": (("pair_debug", 9),)}
 
 
 @pytest.fixture(scope="module")
@@ -191,7 +193,7 @@ def test_kernels_agree_on_a_large_box(Meso, style, tol):
     """32^3 (131 k atoms, 512+ workgroups, XCD remap active): every force kernel against the lane-per-atom one.
     (A register-spilling build of the compacted fp64 kernel was correct at 25^3 and wrong here.)"""
     ref = None
-    for path in ("lane", "ring", "ring-unpaired", "ring-1-lane", "ring+cell-builder"):
+    for path in ("lane", "ring", "ring-unpaired", "ring-1-lane", "ring+cell-builder", "ring-wide"):
         opts = PATHS[path]
         m, _ = _engine(Meso, 32, style=style, opts=opts)
         m.force_clear("local")
@@ -582,9 +584,12 @@ def test_lanes_per_atom_give_identical_forces(Meso, style):
     from meso_amd.datagen import make_polymer_box
     x, v, types, _, lo, hi = make_polymer_box(9, frac=0.3)
     res = []
-    for npart in (1, 2, 4):
+    for npart in (1, 2, 4, "wide"):
         m = Meso()
-        m.set_option("pair_npart", npart)
+        if npart == "wide":
+            m.set_option("pair_debug", 9)        # the record format of systems beyond 2^25 atoms (32-bit index, owner lane in a byte ring)
+        else:
+            m.set_option("pair_npart", npart)
         m.read_atoms(x, v, lo, hi, types=types, ntypes=2); m.neighbor(0.3); m.neigh_modify(delay=0, every=5, check=False)
         m.pair_style(style, 1.0, DP_RUN["seed"])
         for (i, j), a0 in {(1, 1): 15.0, (2, 2): 15.0, (1, 2): 40.0}.items():
@@ -592,7 +597,7 @@ def test_lanes_per_atom_give_identical_forces(Meso, style):
         m.timestep(0.005); m.setup()
         res.append(m.gather()[2])
         m.close()
-    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2]) and np.array_equal(res[0], res[3])
 
 
 @pytest.mark.parametrize("style", ["dpd/meso"])
