@@ -283,7 +283,24 @@ private:
     double *d_shift27 = nullptr;
     bool images_ready = false;      // this rebuild recorded the images
     bool build_images_now = false;
-    bool images_on() const { return nranks == 1 && (ghost_epilogue == 1 || (ghost_epilogue < 0 && nlocal <= 524288)); }
+    // (an atom has at most 7 periodic images - the table holds 8 - only while every periodic edge exceeds twice the ghost cutoff)
+    bool img_ok = false;
+    bool images_on() const { return nranks == 1 && img_ok && (ghost_epilogue == 1 || (ghost_epilogue < 0 && nlocal <= 524288)); }
+    // one rank: the rebuild in three launches (rebuild.hip) - count, place + gather + ghost emission, ghosts
+    int fused_rebuild = 1;          // option
+    bool fused_active = false;      // this rebuild ran the fused path: ghosts sit in slot order, directions in senddir
+    bool fused_dirty = false;       // a fused rebuild failed half-way: counters are cleared before the next one
+    bool fused_ok() const;
+    int rebuild_fused();
+    int fused_alloc();
+    int *fr_bucket = nullptr, *fr_ovf = nullptr, *fr_novf = nullptr, *fr_ttot[2] = {nullptr, nullptr}, *fr_stot[2] = {nullptr, nullptr};
+    int *fr_gttot[2] = {nullptr, nullptr}, *fr_gstot[2] = {nullptr, nullptr};
+    unsigned long long *fr_scratch = nullptr;
+    unsigned char *senddir = nullptr;
+    int fr_cap = 0, fr_gcap = 0, fr_cap_want = 0, fr_cap_user = 0;
+    size_t fr_M = 0;
+    unsigned fr_epoch = 0;
+    static constexpr int fr_ovf_cap = 65536;
     int overlap_rebuild = 0;        // measured slower at every size (profiles/r02_notes.md section 5): kept as a tested option
     bool ghosts_binned = false;     // this rebuild's ghosts were binned by rebuild_overlapped
     int rebuild_overlapped();
@@ -300,7 +317,6 @@ private:
     size_t estart_cap = 0;
     BrickArgs bargs{};
     int l1bits = 0;
-    int ensure_table32();
 
     // reorder
     uint32_t *rkey = nullptr, *rkey_alt = nullptr;

@@ -83,6 +83,8 @@ void Engine::free_all()
     dfree(pair_count); dfree(pair_table);
     dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(img_cnt); dfree(img); dfree(d_shift27);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
+    dfree(fr_bucket); dfree(fr_ovf); dfree(fr_novf); dfree(fr_scratch); dfree(senddir);
+    for (int k = 0; k < 2; k++) { dfree(fr_ttot[k]); dfree(fr_stot[k]); dfree(fr_gttot[k]); dfree(fr_gstot[k]); }
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
     dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot);
@@ -311,6 +313,8 @@ int Engine::pair_coeff_table(int i, int j, double gamma, double sigma, int len, 
 
 int Engine::set_option(const std::string &key, double val)
 {
+    if (key == "fused_rebuild") { fused_rebuild = (int)val; return 0; }
+    if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
     if (key == "fuse_clear") { fuse_clear = (int)val; return 0; }
@@ -422,6 +426,7 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(gslot, 0, c, stream));
     HIPCHK(regrow(gtmp_placed, 0, c, stream)); HIPCHK(regrow(gtmp_code, 0, c, stream)); HIPCHK(regrow(perm_inverse, 0, c, stream));
     HIPCHK(regrow(img_cnt, 0, c, stream)); HIPCHK(regrow(img, 0, c * 8, stream));
+    HIPCHK(regrow(senddir, 0, c, stream)); HIPCHK(regrow(fr_scratch, 0, c, stream));
     images_ready = false;
     send_cap = cap;
     chunk_cap = (cap + 255) / 256 + 1;
@@ -591,7 +596,7 @@ int Engine::rebuild_topology()
 {
     if (!have_bonds) return 0;
     const int *ng_dev = pending_nghost_dev();     // nghost is a launch bound while the counts travel
-    launch_tag_cell(cur.tag, gslot, nlocal, nghost, ng_dev, tagc, stream);
+    launch_tag_cell(cur.tag, fused_active ? nullptr : gslot, nlocal, nghost, ng_dev, tagc, stream);
     HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
     launch_set_map(tagc, nlocal, nghost, ng_dev, maxtag, tagbits, tagmap, stream);
     // (d_flags[4] counts partners that are neither local nor ghost; it stays set until check_overflow reports it)
@@ -914,6 +919,9 @@ int Engine::init_params()
             const double m128 = density * 128.0 * binvol * brick_margin * std::max(1.0, (double)brick_maxh_floor / std::max(1.0, mean + 6.5 * std::sqrt(mean)));
             reorder_cap = std::min(7680, std::max(2048, ((int)std::ceil(m128 + 6.5 * std::sqrt(m128)) + 63) / 64 * 64));
             if (reorder_cap_user > 0) reorder_cap = reorder_cap_user;
+            // bucket of one code in the fused rebuild: atoms of one bin, mean + 6.5 sigma + 8 (rarer: the overflow list)
+            const double m1 = density * binvol * brick_margin * std::max(1.0, (double)brick_maxh_floor / std::max(1.0, mean + 6.5 * std::sqrt(mean)));
+            fr_cap_want = ((int)std::ceil(m1 + 6.5 * std::sqrt(m1)) + 8 + 7) / 8 * 8;
             bargs.maxown = 0;
         }
         if ((M / brick_codes() + 8 > brick_cap || bargs.maxh != brick_maxh_alloc)) {
@@ -928,6 +936,9 @@ int Engine::init_params()
         bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
         for (int d = 0; d < 3; d++) bargs.mbin[d] = geom.mbin[d];
     }
+    img_ok = true;
+    for (int d = 0; d < 3; d++)
+        if (periodic[d] && !(prd[d] > 2.0 * cutghost)) img_ok = false;
     // coefficient tables (prepare_coeff pair_dpd_meso.cu:68-89)
     dfree(d_coeff64); dfree(d_coeff32); dfree(d_mass_type);
     HIPCHK(dalloc(d_coeff64, coeff.size()));
@@ -1088,6 +1099,115 @@ int Engine::rebuild_overlapped()
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// one rank: the whole rebuild in front of the list builder in three launches (rebuild.hip)
+// ------------------------------------------------------------------------------------------------
+bool Engine::fused_ok() const
+{
+    return fused_rebuild && async_ok() && !overlap_rebuild && nlocal > 0 && (long)nlocal < (1L << 27) && neigh_kernel == 1;
+}
+
+int Engine::fused_alloc()
+{
+    const size_t M = (size_t)bargs.M;
+    const int cap = fr_cap_user > 0 ? fr_cap_user : std::max(fr_cap_want, 16);
+    if (M != fr_M || cap > fr_cap || (fr_cap_user > 0 && cap != fr_cap)) {
+        dfree(fr_bucket);
+        for (int k = 0; k < 2; k++) { dfree(fr_ttot[k]); dfree(fr_stot[k]); dfree(fr_gttot[k]); dfree(fr_gstot[k]); }
+        fr_M = M; fr_cap = cap; fr_gcap = cap;
+        const size_t ntl = 2 * M / fused_tile_codes(), nsl = ntl / fused_super_tiles() + 1;
+        const size_t ntg = M / fused_tile_codes(), nsg = ntg / fused_super_tiles() + 1;
+        HIPCHK(dalloc(fr_bucket, 2 * M * (size_t)cap));
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(dalloc(fr_ttot[k], ntl)); HIPCHK(dalloc(fr_stot[k], nsl));
+            HIPCHK(dalloc(fr_gttot[k], ntg)); HIPCHK(dalloc(fr_gstot[k], nsg));      // (stot: [0] only, written afresh by k_fr_super)
+        }
+        fused_dirty = true;
+    }
+    if (!fr_ovf) {
+        HIPCHK(dalloc(fr_ovf, 2 * (size_t)fr_ovf_cap));
+        HIPCHK(dalloc(fr_novf, 1));
+        fused_dirty = true;
+    }
+    if (fused_dirty) {
+        const size_t ntl = 2 * M / fused_tile_codes(), nsl = ntl / fused_super_tiles() + 1;
+        const size_t ntg = M / fused_tile_codes(), nsg = ntg / fused_super_tiles() + 1;
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(hipMemsetAsync(fr_ttot[k], 0, ntl * sizeof(int), stream)); HIPCHK(hipMemsetAsync(fr_stot[k], 0, nsl * sizeof(int), stream));
+            HIPCHK(hipMemsetAsync(fr_gttot[k], 0, ntg * sizeof(int), stream)); HIPCHK(hipMemsetAsync(fr_gstot[k], 0, nsg * sizeof(int), stream));
+        }
+        HIPCHK(hipMemsetAsync(rcount, 0, (2 * M + 1) * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(fr_novf, 0, sizeof(int), stream));
+        fused_dirty = false;
+    }
+    return 0;
+}
+
+int Engine::rebuild_fused()
+{
+    tbegin("reorder");
+    // the ghost count of the previous rebuild (+ head-room) sizes the arrays and the later per-step launches; the ghost kernel
+    // itself covers every ghost cell whatever the count is, and reports a count beyond the capacity
+    const int bound = (int)(nghost_prev * async_grid_scale) + 1024;
+    TRY(ensure_capacity(nlocal + bound + bound / 2));
+    TRY(fused_alloc());
+    if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
+    FusedArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = cur; a.dst = alt;
+    a.n = nlocal;
+    a.with_f = permute_forces ? 1 : 0;
+    a.wrap = wrap_in_reorder ? 1 : 0;
+    for (int d = 0; d < 3; d++) {
+        a.boxlo[d] = boxlo[d]; a.boxhi[d] = boxhi[d]; a.per[d] = periodic[d];
+        a.sl.lo[d] = slab_lo[d]; a.sl.hi[d] = slab_hi[d];
+    }
+    a.g = geom;
+    a.sub_bits = reorder_sub_bits(geom);
+    a.M = bargs.M;
+    a.cnt = rcount; a.bucket = fr_bucket; a.cap = fr_cap;
+    a.ovf = fr_ovf; a.novf = fr_novf; a.ovf_cap = fr_ovf_cap;
+    const int par = (int)(fr_epoch & 1u);
+    a.ttot = fr_ttot[par]; a.ttot_next = fr_ttot[par ^ 1];
+    a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
+    a.stot = 2 * bargs.M / fused_tile_codes() > fused_direct_tiles() ? fr_stot[0] : nullptr;
+    a.gstot = bargs.M / fused_tile_codes() > fused_direct_tiles() ? fr_gstot[0] : nullptr;
+    fr_epoch++;
+    a.estart = estart;
+    a.perm = rval;
+    a.scratch = fr_scratch;
+    a.lds_cap = reorder_cap;
+    a.mg.coord4 = coord4; a.mg.veloc4 = veloc4;
+    a.mg.cx = 0.5 * (subhi[0] + sublo[0]); a.mg.cy = 0.5 * (subhi[1] + sublo[1]); a.mg.cz = 0.5 * (subhi[2] + sublo[2]);
+    a.mg.seed = premix_tea<64>((u32)seed, (u32)ntimestep);
+    a.mg.inverse = nullptr;
+    a.mg.zero = images_on() ? img_cnt : nullptr;
+    a.gstart = gstart;
+    a.dir_mask = 0;
+    for (int d = 0; d < 27; d++)
+        if (d != 13 && send_active[d]) a.dir_mask |= 1u << d;
+    for (int d = 0; d < 27; d++)
+        for (int k = 0; k < 3; k++) { a.sh.s[d][k] = shift27[3 * d + k]; a.ce.c[d][k] = center27[3 * d + k]; }
+    a.sendlist = sendlist; a.senddir = senddir;
+    a.img_cnt = images_on() ? img_cnt : nullptr; a.img = img;
+    a.ghost_cap = std::min(nmax - nlocal - 1, send_cap);
+    a.dir_start = d_dir_start;
+    a.flags = d_flags;
+    a.report = h_flags_dev;
+    launch_fused_rebuild(a, stream);
+    std::swap(cur, alt);
+    merged_in_reorder = true;
+    if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_counts, stream));
+    counts_pending = true;
+    bulk_pending = true;
+    ghosts_binned = true;
+    fused_active = true;
+    nsend = nghost = bound;            // launch bounds until resolve_counts() has the numbers
+    tend("reorder");
+    return 0;
+}
+
 // MesoComm::borders (comm_meso.cu:41-186) as device list building + device pack
 int Engine::halo_borders()
 {
@@ -1175,7 +1295,7 @@ int Engine::halo_forward_seed(uint32_t sd, bool async)
     // source atom's images for the step-boundary epilogue
     const bool rec = build_images_now && images_on();
     launch_pack_forward(cur, sendlist, nsend, d_dir_start, shift27, center27, sd, coord4 + nlocal, veloc4 + nlocal,
-                        gslot, rec ? img_cnt : nullptr, img, nlocal, stream);
+                        fused_active ? nullptr : gslot, rec ? img_cnt : nullptr, img, nlocal, fused_active ? senddir : nullptr, stream);
     if (rec) images_ready = true;
     tend("halo");
     return 0;
@@ -1229,7 +1349,9 @@ int Engine::build_cells_and_table()
         merged_in_reorder = false;
         {
             // (several ranks: the border message carried the velocities, the ghosts' merged pairs are built locally)
-            const int rc_fwd = nranks > 1 ? merge_new_ghosts(sd_now) : halo_forward_seed(sd_now);
+            // (fused rebuild: the ghosts' merged pairs and the image table were written with the ghosts)
+            const int rc_fwd = fused_active ? 0 : (nranks > 1 ? merge_new_ghosts(sd_now) : halo_forward_seed(sd_now));
+            if (fused_active && images_on()) images_ready = true;
             build_images_now = false;
             if (rc_fwd) return rc_fwd;
         }
@@ -1260,9 +1382,6 @@ int Engine::build_cells_and_table()
     }
 }
 
-// (the rows of the cell-ordered layout always hold global indices)
-int Engine::ensure_table32() { return 0; }
-
 bool Engine::async_ok() const
 {
     return async_counts && nranks == 1 && !ghost_sort && !reorder_sort && nghost_prev >= 0 &&
@@ -1278,7 +1397,7 @@ int Engine::resolve_counts()
     bulk_pending = false;
     if (h_flags[8]) { mr_pending = false; return check_overflow(); }
     n_bulk = h_flags[9];
-    for (int k = 0; k < 28; k++) h_dir_start[k] = h_flags[16 + k];
+    for (int k = 0; k < 28; k++) h_dir_start[k] = (fused_active && k < 27) ? 0 : h_flags[16 + k];      // (fused rebuild: no direction segments)
     if (mr_pending) return mr_resolve();
     nsend = nghost = h_dir_start[27];
     nghost_prev = nghost; n_bulk_prev = n_bulk;
@@ -1306,9 +1425,18 @@ int Engine::check_overflow()
             HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
             counts_pending = false;
             nghost_prev = -1;      // the next rebuild takes the synchronous path again
+            fused_dirty = true;
             return fail(4, h_flags[0] == 200000 ? "Ghost list outgrew the capacity reserved from the previous rebuild (the ghost count rose by more "
                                                   "than two thirds within one rebuild interval): run again with option async_counts 0"
                                                 : "Border section moved in front of the scanned range: run again with option async_counts 0");
+        }
+        if (h_flags[0] >= 300000) {
+            HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+            counts_pending = false;
+            nghost_prev = -1;
+            fused_dirty = true;
+            return fail(4, "Fused rebuild: a cell holds more atoms than its bucket and the overflow list together can take (local density far "
+                           "above the mean): run again with option fused_rebuild 0");
         }
         if (h_flags[0] >= 100000)
             snprintf(buf, sizeof buf, "Brick halo overflow: %d atoms in one brick neighbourhood (capacity %d); local density too "
@@ -1341,7 +1469,10 @@ int Engine::reneighbor()
     if (!wrap_in_reorder) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
     TRY(migrate());
     ghosts_binned = false;
-    if (async_ok() && overlap_rebuild && nlocal > 0) {
+    fused_active = false;
+    if (fused_ok()) {
+        TRY(rebuild_fused());
+    } else if (async_ok() && overlap_rebuild && nlocal > 0) {
         TRY(rebuild_overlapped());
     } else {
         TRY(reorder_locals());
@@ -1452,7 +1583,6 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     p.fuse_nve = 0;
     p.debug = 0;
     p.chunked = 1;
-    TRY(ensure_table32());
     tbegin("pair");
     launch_pair(p, ev);
     tend("pair");
@@ -1533,7 +1663,6 @@ int Engine::run(int nsteps)
         ghosts_by_epilogue = false;
         PairArgs p;
         p.bond.nbond = nullptr;
-    p.bond.nbond = nullptr;
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
         for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
         p.e_pair = nullptr;
@@ -1749,7 +1878,6 @@ int Engine::neigh_info(int *ncol, int *max_count, double *avg, int64_t *nb)
 
 int Engine::neigh_download(int *count, int *table, int stride)
 {
-    TRY(ensure_table32());
     HIPCHK(hipStreamSynchronize(stream));
     if (!nlocal) return 0;
     HIPCHK(hipMemcpy(count, pair_count, nlocal * sizeof(int), hipMemcpyDeviceToHost));

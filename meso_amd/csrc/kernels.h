@@ -96,7 +96,8 @@ void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const 
 void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start /*dev [28]*/,
                          const double *shift27 /*host [27][3]*/, const double *center27 /*host [27][3]*/,
                          uint32_t seed, float4 *dcoord, float4 *dveloc, const int *dest_slot /*nullable*/,
-                         int *img_cnt /*nullable: also record each source atom's images*/, int *img, int img_base, hipStream_t s);
+                         int *img_cnt /*nullable: also record each source atom's images*/, int *img, int img_base,
+                         const unsigned char *dirs /*nullable: direction per entry instead of the 27 segments*/, hipStream_t s);
 
 
 

@@ -529,58 +529,12 @@ void launch_reorder_keys(const AtomSoA &a, const BinGeom &g, const double *slab_
 // gpu_permute_copy / gpu_deinterleave with permutation (atom_vec_meso.h:11-67): device-resident gather
 // mg.coord4 != null: the merged float4 pair of the atom's new place is written as well (gpu_merge_xvt folded into the gather:
 // the reorder has x, v, tag and type in registers anyway; 17 us of re-reading them at 64^3)
-struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; int *inverse; int *zero; };
 __global__ void __launch_bounds__(256) k_permute_atoms(AtomSoA src, AtomSoA dst, const int *__restrict__ from, int n, int with_f,
                                                        MergeOut mg)
 {
     int i = blockDim.x * blockIdx.x + threadIdx.x;
     if (i >= n) return;
-    int j = from[i];
-    if (mg.inverse) mg.inverse[j] = i;      // old place -> new place (the overlapped rebuild translates its send list with it)
-    if (mg.zero) mg.zero[i] = 0;            // image counters of the new order (filled by the rebuild's k_pack_forward)
-    double xx[3], vv[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        xx[d] = src.x[d][j];
-        vv[d] = src.v[d][j];
-        dst.x[d][i] = xx[d];
-        dst.v[d][i] = vv[d];
-        if (with_f) dst.f[d][i] = src.f[d][j];      // inside run() the forces are recomputed before anyone reads them
-    }
-    const int tg = src.tag[j], ty = src.type[j];
-    if (mg.coord4) {
-        float4 c, v;
-        c.x = (float)(xx[0] - mg.cx); c.y = (float)(xx[1] - mg.cy); c.z = (float)(xx[2] - mg.cz);
-        c.w = __uint_as_float((u32)(ty - 1));
-        v.x = (float)vv[0]; v.y = (float)vv[1]; v.z = (float)vv[2];
-        v.w = __uint_as_float(signature(mg.seed, tg, v.x, v.y, v.z));
-        mg.coord4[i] = c;
-        mg.veloc4[i] = v;
-    }
-    dst.tag[i] = tg;
-    dst.type[i] = ty;
-    dst.mask[i] = src.mask[j];
-    dst.image[i] = src.image[j];
-    dst.mass[i] = src.mass[j];
-    // topology lists: only the entries in use travel (most atoms of a solution have none)
-    if (src.bpa > 0) {
-        const int nb = src.nbond[j];
-        dst.nbond[i] = nb;
-        for (int b = 0; b < nb; b++) {
-            dst.bond_tag[(size_t)i * src.bpa + b] = src.bond_tag[(size_t)j * src.bpa + b];
-            dst.bond_type[(size_t)i * src.bpa + b] = src.bond_type[(size_t)j * src.bpa + b];
-        }
-    }
-    if (src.apa > 0) {
-        const int na = src.nangle[j];
-        dst.nangle[i] = na;
-        for (int a = 0; a < 4 * na; a++) dst.angle_tag[(size_t)i * 4 * src.apa + a] = src.angle_tag[(size_t)j * 4 * src.apa + a];
-    }
-    if (src.msp > 0) {
-        const int ns = src.nspecial[j];
-        dst.nspecial[i] = ns;
-        for (int s = 0; s < ns; s++) dst.special[(size_t)i * src.msp + s] = src.special[(size_t)j * src.msp + s];
-    }
+    permute_one(src, dst, from[i], i, with_f, mg);
 }
 void launch_permute_atoms(const AtomSoA &src, const AtomSoA &dst, const int *perm_from, int n, int with_f, hipStream_t s)
 {
@@ -609,30 +563,6 @@ void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s
 // halo: border lists (deterministic two-pass compaction, no global atomics) + pack kernels
 // =========================================================================================
 #define BORDER_CHUNK 256
-
-__device__ inline int near_flags(double cx, double cy, double cz, const double *sl, const double *sh)
-{
-    // bit 2d: near the low face of dim d (sent down), bit 2d+1: near the high face (sent up)
-    int f = 0;
-    if (cx <= sl[0]) f |= 1;
-    if (cx >= sh[0]) f |= 2;
-    if (cy <= sl[1]) f |= 4;
-    if (cy >= sh[1]) f |= 8;
-    if (cz <= sl[2]) f |= 16;
-    if (cz >= sh[2]) f |= 32;
-    return f;
-}
-
-__device__ inline bool in_dir(int flags, int dir)
-{
-    int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
-    bool okx = sx == 0 || (sx < 0 ? (flags & 1) : (flags & 2));
-    bool oky = sy == 0 || (sy < 0 ? (flags & 4) : (flags & 8));
-    bool okz = sz == 0 || (sz < 0 ? (flags & 16) : (flags & 32));
-    return okx && oky && okz;
-}
-
-struct Slabs { double lo[3], hi[3]; };
 
 __global__ void __launch_bounds__(BORDER_CHUNK) k_border_count(const double *__restrict__ x,
                                                                const double *__restrict__ y,
@@ -901,14 +831,15 @@ __global__ void __launch_bounds__(256) k_pack_forward(AtomSoA a, const int *__re
                                                       const int *__restrict__ dir_start, Shift27 sh, Center27 ce,
                                                       u32 seed, float4 *__restrict__ dcoord,
                                                       float4 *__restrict__ dveloc, const int *__restrict__ dest_slot,
-                                                      int *__restrict__ img_cnt, int *__restrict__ img, int img_base)
+                                                      int *__restrict__ img_cnt, int *__restrict__ img, int img_base,
+                                                      const unsigned char *__restrict__ dirs)
 {
     __shared__ int ds[28];
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
     __syncthreads();
     for (int k = blockDim.x * blockIdx.x + threadIdx.x; k < ds[27]; k += gridDim.x * blockDim.x) {      // (nsend only sized the grid)
         int j = sendlist[k];
-        int d = dir_of_entry(ds, k);
+        int d = dirs ? (int)dirs[k] : dir_of_entry(ds, k);      // (fused rebuild: ghosts in slot order, direction per entry)
         float4 c;
         c.x = (float)((a.x[0][j] + sh.s[d][0]) - ce.c[d][0]);
         c.y = (float)((a.x[1][j] + sh.s[d][1]) - ce.c[d][1]);
@@ -942,7 +873,7 @@ void launch_pack_border(const AtomSoA &a, const int *sendlist, int nsend, const 
 
 void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const int *dir_start, const double *shift27,
                          const double *center27, uint32_t seed, float4 *dcoord, float4 *dveloc, const int *dest_slot,
-                         int *img_cnt, int *img, int img_base, hipStream_t s)
+                         int *img_cnt, int *img, int img_base, const unsigned char *dirs, hipStream_t s)
 {
     if (nsend <= 0) return;
     Shift27 sh;
@@ -950,7 +881,7 @@ void launch_pack_forward(const AtomSoA &a, const int *sendlist, int nsend, const
     for (int d = 0; d < 27; d++)
         for (int k = 0; k < 3; k++) { sh.s[d][k] = shift27[3 * d + k]; ce.c[d][k] = center27[3 * d + k]; }
     hipLaunchKernelGGL(k_pack_forward, dim3(nblk(nsend, 256)), dim3(256), 0, s, a, sendlist, nsend, dir_start, sh, ce,
-                       seed, dcoord, dveloc, dest_slot, img_cnt, img, img_base);
+                       seed, dcoord, dveloc, dest_slot, img_cnt, img, img_base, dirs);
 }
 
 // =========================================================================================

@@ -357,6 +357,82 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
     }
 }
 
+// One atom of the reorder gather (gpu_permute_copy / gpu_deinterleave with permutation, atom_vec_meso.h:11-67): atom j of the old
+// order becomes atom i of the new one.  mg.coord4 != null: the merged float4 pair of the atom's new place is written as well
+// (gpu_merge_xvt folded into the gather: the reorder has x, v, tag and type in registers anyway).  One definition for
+// k_permute_atoms and the fused rebuild (rebuild.hip).
+struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; int *inverse; int *zero; };
+__device__ inline void permute_one(const AtomSoA &src, const AtomSoA &dst, int j, int i, int with_f, const MergeOut &mg)
+{
+    if (mg.inverse) mg.inverse[j] = i;      // old place -> new place (the overlapped rebuild translates its send list with it)
+    if (mg.zero) mg.zero[i] = 0;            // image counters of the new order (filled by the rebuild's k_pack_forward)
+    double xx[3], vv[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        xx[d] = src.x[d][j];
+        vv[d] = src.v[d][j];
+        dst.x[d][i] = xx[d];
+        dst.v[d][i] = vv[d];
+        if (with_f) dst.f[d][i] = src.f[d][j];      // inside run() the forces are recomputed before anyone reads them
+    }
+    const int tg = src.tag[j], ty = src.type[j];
+    if (mg.coord4) {
+        float4 c, v;
+        c.x = (float)(xx[0] - mg.cx); c.y = (float)(xx[1] - mg.cy); c.z = (float)(xx[2] - mg.cz);
+        c.w = __uint_as_float((u32)(ty - 1));
+        v.x = (float)vv[0]; v.y = (float)vv[1]; v.z = (float)vv[2];
+        v.w = __uint_as_float(signature(mg.seed, tg, v.x, v.y, v.z));
+        mg.coord4[i] = c;
+        mg.veloc4[i] = v;
+    }
+    dst.tag[i] = tg;
+    dst.type[i] = ty;
+    dst.mask[i] = src.mask[j];
+    dst.image[i] = src.image[j];
+    dst.mass[i] = src.mass[j];
+    // topology lists: only the entries in use travel (most atoms of a solution have none)
+    if (src.bpa > 0) {
+        const int nb = src.nbond[j];
+        dst.nbond[i] = nb;
+        for (int b = 0; b < nb; b++) {
+            dst.bond_tag[(size_t)i * src.bpa + b] = src.bond_tag[(size_t)j * src.bpa + b];
+            dst.bond_type[(size_t)i * src.bpa + b] = src.bond_type[(size_t)j * src.bpa + b];
+        }
+    }
+    if (src.apa > 0) {
+        const int na = src.nangle[j];
+        dst.nangle[i] = na;
+        for (int a = 0; a < 4 * na; a++) dst.angle_tag[(size_t)i * 4 * src.apa + a] = src.angle_tag[(size_t)j * 4 * src.apa + a];
+    }
+    if (src.msp > 0) {
+        const int ns = src.nspecial[j];
+        dst.nspecial[i] = ns;
+        for (int s = 0; s < ns; s++) dst.special[(size_t)i * src.msp + s] = src.special[(size_t)j * src.msp + s];
+    }
+}
+
+// border slabs: near_flags bit 2d = near the low face of dim d (sent down), bit 2d+1 = near the high face (sent up)
+struct Slabs { double lo[3], hi[3]; };
+__device__ inline int near_flags(double cx, double cy, double cz, const double *sl, const double *sh)
+{
+    int f = 0;
+    if (cx <= sl[0]) f |= 1;
+    if (cx >= sh[0]) f |= 2;
+    if (cy <= sl[1]) f |= 4;
+    if (cy >= sh[1]) f |= 8;
+    if (cz <= sl[2]) f |= 16;
+    if (cz >= sh[2]) f |= 32;
+    return f;
+}
+__device__ inline bool in_dir(int flags, int dir)
+{
+    int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
+    bool okx = sx == 0 || (sx < 0 ? (flags & 1) : (flags & 2));
+    bool oky = sy == 0 || (sy < 0 ? (flags & 4) : (flags & 8));
+    bool okz = sz == 0 || (sz < 0 ? (flags & 16) : (flags & 32));
+    return okx && oky && okz;
+}
+
 // bins: neighbor_meso.cu:410-412 clamp at [nmin,nmax)
 __host__ __device__ inline int clampi(int i, int nmin, int nmax)
 {
@@ -370,24 +446,45 @@ __host__ __device__ inline int clampi(int i, int nmin, int nmax)
 // and a wave's access to chunk c of its 64 atoms is one contiguous 2 KiB.
 // rank of every lane inside its code, with ONE atomic per run of equal codes in the wave: the atoms arrive nearly sorted, so a
 // wave holds ~7 runs of ~9 equal codes, and same-address atomics serialise in L2 (61 us for 1 M single atomics, 64^3)
-__device__ inline int run_rank(u32 code, bool valid, int *__restrict__ cnt)
+// tot != null: the head of a run also books the run into the total of its group of (1 << tshift) codes
+__device__ inline int run_rank(u32 code, bool valid, int *__restrict__ cnt, int *__restrict__ tot = nullptr, int tshift = 0)
 {
     const int lane = __lane_id();
+    // (both shuffles outside the short-circuit expression: every lane has to take part in them)
     const u32 prev = __shfl_up(code, 1, 64);
-    const bool head = valid && (lane == 0 || code != prev || !__shfl_up((int)valid, 1, 64));
+    const int prev_valid = __shfl_up((int)valid, 1, 64);
+    const bool head = valid && (lane == 0 || code != prev || !prev_valid);
     const unsigned long long heads = __ballot(head), live = __ballot(valid);
     int rank = 0;
+    int start = 0, base = 0;
     if (valid) {
         const unsigned long long below = heads & ((2ull << lane) - 1ull);         // heads at or below my lane (never empty)
-        const int start = 63 - __builtin_clzll(below);
-        const unsigned long long after = (heads & ~((2ull << start) - 1ull)) | ~live;   // next head, or the first dead lane
+        start = 63 - __builtin_clzll(below);
+        const unsigned long long after = (heads | ~live) & ~((2ull << start) - 1ull);   // next head or dead lane behind the run's head
         const int end = after ? __builtin_ctzll(after) : 64;
-        int base = 0;
-        if (lane == start) base = atomicAdd(cnt + code, end - start);
-        base = __shfl(base, start, 64);
-        rank = base + (lane - start);
+        if (lane == start) {
+            base = atomicAdd(cnt + code, end - start);
+            if (tot) atomicAdd(tot + (code >> tshift), end - start);
+        }
     }
+    base = __shfl(base, start, 64);
+    if (valid) rank = base + (lane - start);
     return rank;
+}
+
+// tot[group] += number of valid lanes with that group, ONE atomic per distinct group in the wave (atoms arrive nearly sorted:
+// one or two groups per wave).  Same-address atomics cost ~150 ns each on this chip: one per run of equal codes made the tile
+// totals of the fused rebuild cost 20 us at 32^3.
+__device__ inline void wave_group_add(u32 group, bool valid, int *__restrict__ tot)
+{
+    unsigned long long rest = __ballot(valid);
+    while (rest) {
+        const int first = __builtin_ctzll(rest);
+        const u32 g0 = (u32)__builtin_amdgcn_readlane((int)group, first);
+        const unsigned long long m = __ballot(valid && group == g0);
+        if (__lane_id() == first) atomicAdd(tot + g0, __popcll(m));
+        rest &= ~m;
+    }
 }
 
 __device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
@@ -406,6 +503,47 @@ __device__ inline double from_fixed(u64 a) { return (double)(long long)a * (1.0 
 
 struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0 when not crossing a PBC)
 struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction
+
+// Arguments of the three-launch rebuild of one rank (rebuild.hip)
+struct FusedArgs {
+    AtomSoA src, dst;          // old order -> new order (ghosts go behind the n locals of dst)
+    int n;                     // local atoms
+    int with_f;                // the gather carries the forces along
+    int wrap;                  // MesoDomain::pbc folded into the count kernel
+    double boxlo[3], boxhi[3];
+    int per[3];
+    BinGeom g;
+    Slabs sl;
+    int sub_bits, M;
+    // locals: counts per extended code [2M+1], buckets [2M][cap] of old indices, overflow list, totals per tile / supertile
+    int *cnt, *bucket, cap;
+    int *ovf, *novf, ovf_cap;
+    int *ttot, *ttot_next;     // atoms per tile of 64 codes (double-buffered by rebuild parity: a tile clears the other buffer's entry)
+    int *stot;                 // atoms per supertile of 256 tiles, summed from ttot by k_fr_super - only when there are more than
+                               // FR_DIRECT_TILES tiles (null otherwise: every tile adds up the tile totals in front of it directly)
+    int *estart;               // out [2M+1]
+    int *perm;                 // out, nullable: new place -> old place
+    unsigned long long *scratch;   // [n] (a code denser than the LDS stage)
+    int lds_cap;               // entries of the LDS stage of one pass
+    MergeOut mg;               // merged pairs of the new order (+ the ghosts'), image counters cleared
+    // ghosts (gttot null: no ghost stage - several ranks create their ghosts by exchange): ghosts per tile of 64 ghost cells
+    int *gttot, *gttot_next, *gstot;
+    unsigned dir_mask;         // bit d: direction d is a periodic image direction of this rank
+    int *gstart;               // out [M+1]
+    Shift27 sh;
+    Center27 ce;
+    int *sendlist;             // out: ghost slot -> source atom (new order)
+    unsigned char *senddir;    // out: ghost slot -> direction
+    int *img_cnt, *img;        // nullable: image table of the step-boundary epilogue
+    int ghost_cap;             // ghosts the arrays can take
+    int *dir_start;            // device [28]: [27] = ghost count (the per-step refresh loops to it)
+    int *flags;                // device flags ([0] overflow code)
+    int *report;               // pinned host memory as the device sees it
+};
+void launch_fused_rebuild(const FusedArgs &a, hipStream_t s);
+int fused_tile_codes();
+int fused_direct_tiles();
+int fused_super_tiles();
 
 __device__ inline int dir_of_entry(const int *__restrict__ dir_start, int k)
 {

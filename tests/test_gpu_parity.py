@@ -632,8 +632,12 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
     res = []
     # (async_grid_scale 0.05: the ghost kernels' grids are sized for a twentieth of the ghosts and have to loop)
     # ghost_epilogue: the per-step ghost refresh done by the force kernel's step-boundary epilogue (on by default at this size)
-    for opts in ((("async_counts", 0), ("ghost_epilogue", 0)), (), (("overlap_rebuild", 1),), (("async_grid_scale", 0.05),),
-                 (("overlap_rebuild", 1), ("async_grid_scale", 0.05)), (("ghost_epilogue", 0),), (("ghost_epilogue", 1), ("async_counts", 0))):
+    # fused_rebuild: the whole rebuild in front of the list builder in three launches (rebuild.hip; default) against the chain of
+    # small launches it replaced; fused_cap 2: two atoms per cell bucket, everything else through the overflow list
+    for opts in ((("async_counts", 0), ("ghost_epilogue", 0)), (), (("fused_rebuild", 0),), (("overlap_rebuild", 1),),
+                 (("async_grid_scale", 0.05), ("fused_rebuild", 0)), (("overlap_rebuild", 1), ("async_grid_scale", 0.05)),
+                 (("ghost_epilogue", 0),), (("ghost_epilogue", 0), ("fused_rebuild", 0)), (("ghost_epilogue", 1), ("async_counts", 0)),
+                 (("fused_cap", 2),), (("fused_cap", 2), ("reorder_cap", 64), ("ghost_epilogue", 0))):
         m, _ = _engine(Meso, 16, style=style, opts=opts)
         m.run(23)
         res.append(m.gather())
