@@ -293,7 +293,8 @@ private:
     bool fused_ok() const;
     int rebuild_fused();
     int fused_alloc();
-    int *fr_bucket = nullptr, *fr_ovf = nullptr, *fr_novf = nullptr, *fr_ttot[2] = {nullptr, nullptr}, *fr_stot[2] = {nullptr, nullptr};
+    unsigned long long *fr_bucket = nullptr, *fr_ovf = nullptr;
+    int *fr_novf = nullptr, *fr_ttot[2] = {nullptr, nullptr}, *fr_stot[2] = {nullptr, nullptr};
     int *fr_gttot[2] = {nullptr, nullptr}, *fr_gstot[2] = {nullptr, nullptr};
     unsigned long long *fr_scratch = nullptr;
     unsigned char *senddir = nullptr;

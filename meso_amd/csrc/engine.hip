@@ -1116,7 +1116,7 @@ int Engine::fused_alloc()
         for (int k = 0; k < 2; k++) { dfree(fr_ttot[k]); dfree(fr_stot[k]); dfree(fr_gttot[k]); dfree(fr_gstot[k]); }
         fr_M = M; fr_cap = cap; fr_gcap = cap;
         const size_t ntl = 2 * M / fused_tile_codes(), nsl = ntl / fused_super_tiles() + 1;
-        const size_t ntg = M / fused_tile_codes(), nsg = ntg / fused_super_tiles() + 1;
+        const size_t ntg = M / fused_gtile_codes(), nsg = ntg / fused_super_tiles() + 1;
         HIPCHK(dalloc(fr_bucket, 2 * M * (size_t)cap));
         for (int k = 0; k < 2; k++) {
             HIPCHK(dalloc(fr_ttot[k], ntl)); HIPCHK(dalloc(fr_stot[k], nsl));
@@ -1131,7 +1131,7 @@ int Engine::fused_alloc()
     }
     if (fused_dirty) {
         const size_t ntl = 2 * M / fused_tile_codes(), nsl = ntl / fused_super_tiles() + 1;
-        const size_t ntg = M / fused_tile_codes(), nsg = ntg / fused_super_tiles() + 1;
+        const size_t ntg = M / fused_gtile_codes(), nsg = ntg / fused_super_tiles() + 1;
         for (int k = 0; k < 2; k++) {
             HIPCHK(hipMemsetAsync(fr_ttot[k], 0, ntl * sizeof(int), stream)); HIPCHK(hipMemsetAsync(fr_stot[k], 0, nsl * sizeof(int), stream));
             HIPCHK(hipMemsetAsync(fr_gttot[k], 0, ntg * sizeof(int), stream)); HIPCHK(hipMemsetAsync(fr_gstot[k], 0, nsg * sizeof(int), stream));
@@ -1171,7 +1171,7 @@ int Engine::rebuild_fused()
     a.ttot = fr_ttot[par]; a.ttot_next = fr_ttot[par ^ 1];
     a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
     a.stot = 2 * bargs.M / fused_tile_codes() > fused_direct_tiles() ? fr_stot[0] : nullptr;
-    a.gstot = bargs.M / fused_tile_codes() > fused_direct_tiles() ? fr_gstot[0] : nullptr;
+    a.gstot = bargs.M / fused_gtile_codes() > fused_direct_tiles() ? fr_gstot[0] : nullptr;
     fr_epoch++;
     a.estart = estart;
     a.perm = rval;

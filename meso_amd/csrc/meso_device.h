@@ -362,7 +362,7 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
 // (gpu_merge_xvt folded into the gather: the reorder has x, v, tag and type in registers anyway).  One definition for
 // k_permute_atoms and the fused rebuild (rebuild.hip).
 struct MergeOut { float4 *coord4, *veloc4; double cx, cy, cz; u32 seed; int *inverse; int *zero; };
-__device__ inline void permute_one(const AtomSoA &src, const AtomSoA &dst, int j, int i, int with_f, const MergeOut &mg)
+__device__ inline void permute_one(const AtomSoA &src, const AtomSoA &dst, int j, int i, int with_f, const MergeOut &mg, double *xout = nullptr)
 {
     if (mg.inverse) mg.inverse[j] = i;      // old place -> new place (the overlapped rebuild translates its send list with it)
     if (mg.zero) mg.zero[i] = 0;            // image counters of the new order (filled by the rebuild's k_pack_forward)
@@ -374,6 +374,7 @@ __device__ inline void permute_one(const AtomSoA &src, const AtomSoA &dst, int j
         dst.x[d][i] = xx[d];
         dst.v[d][i] = vv[d];
         if (with_f) dst.f[d][i] = src.f[d][j];      // inside run() the forces are recomputed before anyone reads them
+        if (xout) xout[d] = xx[d];
     }
     const int tg = src.tag[j], ty = src.type[j];
     if (mg.coord4) {
@@ -515,9 +516,10 @@ struct FusedArgs {
     BinGeom g;
     Slabs sl;
     int sub_bits, M;
-    // locals: counts per extended code [2M+1], buckets [2M][cap] of old indices, overflow list, totals per tile / supertile
-    int *cnt, *bucket, cap;
-    int *ovf, *novf, ovf_cap;
+    // locals: counts per extended code [2M+1], buckets [2M][cap], overflow list [(code, entry)], totals per tile / supertile
+    int *cnt, cap;
+    unsigned long long *bucket, *ovf;      // (sub-cell key << 32) | old index
+    int *novf, ovf_cap;
     int *ttot, *ttot_next;     // atoms per tile of 64 codes (double-buffered by rebuild parity: a tile clears the other buffer's entry)
     int *stot;                 // atoms per supertile of 256 tiles, summed from ttot by k_fr_super - only when there are more than
                                // FR_DIRECT_TILES tiles (null otherwise: every tile adds up the tile totals in front of it directly)
@@ -542,6 +544,7 @@ struct FusedArgs {
 };
 void launch_fused_rebuild(const FusedArgs &a, hipStream_t s);
 int fused_tile_codes();
+int fused_gtile_codes();
 int fused_direct_tiles();
 int fused_super_tiles();
 

@@ -32,7 +32,15 @@
 
 namespace meso {
 
-#define FR_TILE 64            // codes per tile (= one brick of the list builder)
+#ifndef FR_TILE
+#define FR_TILE 64            // cells per tile of k_fr_place (<= 64)
+#endif
+#ifndef FR_U
+#define FR_U 4                // trips of k_fr_place whose loads are issued together
+#endif
+#ifndef FR_GTILE
+#define FR_GTILE 32           // ghost cells per tile of k_fr_ghosts (<= 64)
+#endif
 #define FR_SUPER 256          // tiles per supertile
 #define FR_THREADS 256       // k_fr_ghosts, k_fr_super
 #ifndef FR_PLACE_THREADS
@@ -48,6 +56,24 @@ __device__ inline u32 compact3(u32 x)      // inverse of bit_space3: every third
     x = (x ^ (x >> 8)) & 0xff0000ff;
     x = (x ^ (x >> 16)) & 0x000003ff;
     return x;
+}
+
+// Bit d of the result: the atom has a periodic image in direction d = (sx+1) + 3 (sy+1) + 9 (sz+1).  fl: near_flags of its
+// coordinate; (bx, by, bz): its cell.  An image sent up (s = +1) comes from the last cell below the high face, one sent down
+// from the first cell above the low face (an atom ON the slab plane of a box whose cells are exactly one ghost cutoff wide can
+// sit in the cell next to it: not an image for any kernel here - they all use this function).
+__device__ inline u32 image_mask(int fl, int bx, int by, int bz, const int *mbin, u32 dir_mask)
+{
+    const u32 mx = 2u | ((fl & 1) && bx == 1 ? 1u : 0u) | ((fl & 2) && bx == mbin[0] - 2 ? 4u : 0u);
+    const u32 my = 2u | ((fl & 4) && by == 1 ? 1u : 0u) | ((fl & 8) && by == mbin[1] - 2 ? 4u : 0u);
+    const u32 mz = 2u | ((fl & 16) && bz == 1 ? 1u : 0u) | ((fl & 32) && bz == mbin[2] - 2 ? 4u : 0u);
+    u32 row = 0;                                   // 9 bits: (sx, sy)
+#pragma unroll
+    for (int k = 0; k < 3; k++) row |= ((my >> k) & 1u) ? mx << (3 * k) : 0u;
+    u32 m = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) m |= ((mz >> k) & 1u) ? row << (9 * k) : 0u;
+    return m & ~(1u << 13) & dir_mask;
 }
 
 __device__ inline int fr_block_sum(int v, int *wsum)
@@ -69,7 +95,7 @@ __global__ void __launch_bounds__(256) k_fr_count(FusedArgs a)
 {
     const int i = blockDim.x * blockIdx.x + threadIdx.x;
     const bool valid = i < a.n;
-    u32 e = 0;
+    u32 e = 0, key = 0;
     if (valid) {
         double c[3] = {a.src.x[0][i], a.src.x[1][i], a.src.x[2][i]};
         if (a.wrap) {
@@ -88,10 +114,15 @@ __global__ void __launch_bounds__(256) k_fr_count(FusedArgs a)
                 a.src.image[i] = im[0] | (im[1] << 10) | (im[2] << 20);
             }
         }
-        u32 b[3];
+        const int res = 1 << (a.sub_bits / 3);
+        u32 b[3], sc[3];
 #pragma unroll
-        for (int d = 0; d < 3; d++) b[d] = (u32)clampi((int)((c[d] - a.g.lo[d]) * a.g.bininv[d] + 1), 0, a.g.mbin[d]);
+        for (int d = 0; d < 3; d++) {
+            b[d] = (u32)clampi((int)((c[d] - a.g.lo[d]) * a.g.bininv[d] + 1), 0, a.g.mbin[d]);
+            sc[d] = (u32)clampi((int)((c[d] - a.g.lo[d] - ((double)b[d] - 1) * a.g.binsize[d]) * (res * a.g.bininv[d])), 0, res);
+        }
         e = interleave3(b[0], b[1], b[2]);
+        key = interleave3(sc[0], sc[1], sc[2]);      // sub-cell Morton key: the order inside the cell (gpu_build_reorder_keypair)
         const bool border = c[0] <= a.sl.lo[0] || c[0] >= a.sl.hi[0] || c[1] <= a.sl.lo[1] || c[1] >= a.sl.hi[1] || c[2] <= a.sl.lo[2] ||
                             c[2] >= a.sl.hi[2];
         if (border) e += (u32)a.M;
@@ -100,10 +131,12 @@ __global__ void __launch_bounds__(256) k_fr_count(FusedArgs a)
     const int rank = run_rank(e, valid, a.cnt);
     wave_group_add(e / FR_TILE, valid, a.ttot);
     if (!valid) return;
-    if (rank < a.cap) a.bucket[(size_t)e * a.cap + rank] = i;
+    // (sub-cell key, old index) travels as one word: the placing kernel orders a cell without touching the coordinates
+    const unsigned long long ent = ((unsigned long long)key << 32) | (u32)i;
+    if (rank < a.cap) a.bucket[(size_t)e * a.cap + rank] = ent;
     else {
         const int o = atomicAdd(a.novf, 1);
-        if (o < a.ovf_cap) { a.ovf[2 * o] = (int)e; a.ovf[2 * o + 1] = i; }
+        if (o < a.ovf_cap) { a.ovf[2 * o] = (unsigned long long)e; a.ovf[2 * o + 1] = ent; }
         else atomicMax(a.flags, 300000);
     }
 }
@@ -129,15 +162,15 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_super(const int *__restrict__
 
 // members of code e beyond the bucket's capacity: the r-th one (r >= cap) in list order... any order is fine, the ordering
 // pass sorts by (key, index); the list is short (normally empty), every lane that needs it scans it
-__device__ inline int fr_overflow_member(const int *__restrict__ ovf, int novf, int e, int r)
+__device__ inline unsigned long long fr_overflow_member(const unsigned long long *__restrict__ ovf, int novf, int e, int r)
 {
     int seen = 0;
     for (int o = 0; o < novf; o++)
-        if (ovf[2 * o] == e) {
+        if (ovf[2 * o] == (unsigned long long)e) {
             if (seen == r) return ovf[2 * o + 1];
             seen++;
         }
-    return -1;
+    return ~0ull;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -153,101 +186,158 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS) k_fr_place(FusedArgs a)
     const int base = fr_tile_base(a.ttot, a.stot, t, wsum);
     // counts of my codes -> local starts (one wave), estart, clean counters
     if (tid < 64) {
-        const int c = a.cnt[code0 + tid];
+        const int c = tid < FR_TILE ? a.cnt[code0 + tid] : 0;
         int incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int u = __shfl_up(incl, o, 64);
             if (tid >= o) incl += u;
         }
-        lstart[tid] = incl - c;
-        if (tid == 63) lstart[64] = incl;
-        a.estart[code0 + tid] = base + incl - c;
-        if (tid == 63 && code0 + 64 == 2 * a.M) a.estart[2 * a.M] = base + incl;
-        a.cnt[code0 + tid] = 0;
+        if (tid < FR_TILE) {
+            lstart[tid] = incl - c;
+            a.estart[code0 + tid] = base + incl - c;
+            a.cnt[code0 + tid] = 0;
+        }
+        if (tid == FR_TILE - 1) {
+            lstart[FR_TILE] = incl;
+            if (code0 + FR_TILE == 2 * a.M) a.estart[2 * a.M] = base + incl;
+        }
     }
     if (tid == 0) a.ttot_next[t] = 0;
     __syncthreads();
     const int total = lstart[FR_TILE];
     if (total == 0) return;
     const int novf = *a.novf;
-    const int sub_bits = a.sub_bits, res = 1 << (sub_bits / 3);
     const bool border_tile = code0 >= a.M;
     // passes over sub-ranges of codes whose atoms fit the LDS stage (one pass at ordinary densities)
     int cb = 0;
     while (cb < FR_TILE) {
-        int ce = cb + 1;
-        while (ce < FR_TILE && lstart[ce + 1] - lstart[cb] <= a.lds_cap) ce++;
+        // (the usual case first: the rest of the tile fits the stage - a walk over the 64 starts is 64 dependent LDS reads, 3 us)
+        int ce = FR_TILE;
+        if (lstart[FR_TILE] - lstart[cb] > a.lds_cap) {
+            ce = cb + 1;
+            while (ce < FR_TILE && lstart[ce + 1] - lstart[cb] <= a.lds_cap) ce++;
+        }
         const int s0 = lstart[cb], ns = lstart[ce] - s0;
         const bool staged = ns <= a.lds_cap;          // (a single code beyond the stage: ordered straight from global memory)
-        for (int p = tid; p < ns; p += FR_PLACE_THREADS) {
-            int lo = cb, hi = ce;                     // code of slot s0 + p: largest c with lstart[c] <= s0 + p
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (lstart[mid] <= s0 + p) lo = mid; else hi = mid;
-            }
-            const int r = s0 + p - lstart[lo];
-            const int e = code0 + lo;
-            int j = r < a.cap ? a.bucket[(size_t)e * a.cap + r] : fr_overflow_member(a.ovf, min(novf, a.ovf_cap), e, r - a.cap);
-            u32 key = 0;
-            if (j >= 0) {
-                const double c[3] = {a.src.x[0][j], a.src.x[1][j], a.src.x[2][j]};
-                u32 sc[3];
+        // FR_U trips at a time, every load of the group in flight before the first store: a wave's loads wait for its older stores
+        // (one vmcnt counter), so trip after trip cost one store acknowledgement + one load round trip each (~3 us)
+        for (int p0 = tid; p0 < ns; p0 += FR_U * FR_PLACE_THREADS) {
+            unsigned long long ent[FR_U];
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const u32 b = (u32)clampi((int)((c[d] - a.g.lo[d]) * a.g.bininv[d] + 1), 0, a.g.mbin[d]);
-                    sc[d] = (u32)clampi((int)((c[d] - a.g.lo[d] - ((double)b - 1) * a.g.binsize[d]) * (res * a.g.bininv[d])), 0, res);
+            for (int u = 0; u < FR_U; u++) {
+                const int p = p0 + u * FR_PLACE_THREADS;
+                ent[u] = 0;
+                if (p < ns) {
+                    int lo = cb, hi = ce;             // code of slot s0 + p: largest c with lstart[c] <= s0 + p
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (lstart[mid] <= s0 + p) lo = mid; else hi = mid;
+                    }
+                    const int r = s0 + p - lstart[lo];
+                    const int e = code0 + lo;
+                    ent[u] = r < a.cap ? a.bucket[(size_t)e * a.cap + r] : fr_overflow_member(a.ovf, min(novf, a.ovf_cap), e, r - a.cap);
                 }
-                key = interleave3(sc[0], sc[1], sc[2]);
-            } else { j = 0; atomicMax(a.flags, 300001); }
-            if (staged) fr_pairs[p] = ((unsigned long long)key << 32) | (u32)j;
-            else a.scratch[(size_t)base + s0 + p] = ((unsigned long long)key << 32) | (u32)j;
+            }
+#pragma unroll
+            for (int u = 0; u < FR_U; u++) {
+                const int p = p0 + u * FR_PLACE_THREADS;
+                if (p < ns) {
+                    if (ent[u] == ~0ull) { ent[u] = 0; atomicMax(a.flags, 300001); }
+                    if (staged) fr_pairs[p] = ent[u];
+                    else a.scratch[(size_t)base + s0 + p] = ent[u];
+                }
+            }
         }
         __syncthreads();
-        // (whole waves take every trip: the ghost emission ranks its atomics per run of equal ghost codes in a wave)
-        for (int p = tid; p < ((ns + 63) & ~63); p += FR_PLACE_THREADS) {
-            const bool act = p < ns;
-            int j = 0, n = 0, lo_code = 0;
-            if (act) {
-                int lo = cb, hi = ce;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (lstart[mid] <= s0 + p) lo = mid; else hi = mid;
+        // (whole waves take every trip: the image counting below is a wave-level operation)
+        const bool lists = a.src.bpa > 0 || a.src.apa > 0 || a.src.msp > 0;
+        for (int p0 = tid; p0 < ((ns + 63) & ~63); p0 += FR_U * FR_PLACE_THREADS) {
+            int jj[FR_U], nn[FR_U], cc[FR_U];
+            double X[FR_U][3], V[FR_U][3], F[FR_U][3], MS[FR_U];
+            int TG[FR_U], TY[FR_U], MK[FR_U], IM[FR_U];
+#pragma unroll
+            for (int u = 0; u < FR_U; u++) {
+                const int p = p0 + u * FR_PLACE_THREADS;
+                jj[u] = -1; nn[u] = 0; cc[u] = 0;
+                if (p < ns) {
+                    int lo = cb, hi = ce;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (lstart[mid] <= s0 + p) lo = mid; else hi = mid;
+                    }
+                    cc[u] = lo;
+                    const int sb = lstart[lo] - s0, se = lstart[lo + 1] - s0;
+                    const unsigned long long *pairs = staged ? fr_pairs : a.scratch + (size_t)base + s0;
+                    const unsigned long long mine = pairs[p];
+                    int pos = 0;
+                    for (int q = sb; q < se; q++) pos += pairs[q] < mine ? 1 : 0;
+                    jj[u] = (int)(u32)mine;
+                    nn[u] = base + s0 + sb + pos;     // the atom's new place
                 }
-                lo_code = lo;
-                const int sb = lstart[lo] - s0, se = lstart[lo + 1] - s0;
-                const unsigned long long *pairs = staged ? fr_pairs : a.scratch + (size_t)base + s0;
-                const unsigned long long mine = pairs[p];
-                int pos = 0;
-                for (int q = sb; q < se; q++) pos += pairs[q] < mine ? 1 : 0;
-                j = (int)(u32)mine;
-                n = base + s0 + sb + pos;             // the atom's new place
-                permute_one(a.src, a.dst, j, n, a.with_f, a.mg);
+            }
+#pragma unroll
+            for (int u = 0; u < FR_U; u++) {
+                X[u][0] = X[u][1] = X[u][2] = 0.0;
+                if (jj[u] >= 0 && !lists) {
+                    const int j = jj[u];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        X[u][d] = a.src.x[d][j]; V[u][d] = a.src.v[d][j];
+                        if (a.with_f) F[u][d] = a.src.f[d][j];
+                    }
+                    TG[u] = a.src.tag[j]; TY[u] = a.src.type[j]; MK[u] = a.src.mask[j]; IM[u] = a.src.image[j]; MS[u] = a.src.mass[j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FR_U; u++) {
+                if (jj[u] < 0) continue;
+                const int j = jj[u], n = nn[u];
+                if (lists) {                          // bonded systems: the general gather (topology lists travel too)
+                    permute_one(a.src, a.dst, j, n, a.with_f, a.mg, X[u]);
+                } else {
+                    // permute_one (meso_device.h) with the loads hoisted: the same values to the same places
+                    if (a.mg.zero) a.mg.zero[n] = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        a.dst.x[d][n] = X[u][d]; a.dst.v[d][n] = V[u][d];
+                        if (a.with_f) a.dst.f[d][n] = F[u][d];
+                    }
+                    float4 c, v;
+                    c.x = (float)(X[u][0] - a.mg.cx); c.y = (float)(X[u][1] - a.mg.cy); c.z = (float)(X[u][2] - a.mg.cz);
+                    c.w = __uint_as_float((u32)(TY[u] - 1));
+                    v.x = (float)V[u][0]; v.y = (float)V[u][1]; v.z = (float)V[u][2];
+                    v.w = __uint_as_float(signature(a.mg.seed, TG[u], v.x, v.y, v.z));
+                    a.mg.coord4[n] = c;
+                    a.mg.veloc4[n] = v;
+                    a.dst.tag[n] = TG[u]; a.dst.type[n] = TY[u]; a.dst.mask[n] = MK[u]; a.dst.image[n] = IM[u]; a.dst.mass[n] = MS[u];
+                }
                 if (a.perm) a.perm[n] = j;
             }
             if (border_tile && a.gttot) {
                 // periodic images of a border atom: k_fr_ghosts PULLS the ghosts of a ghost cell from the cell they are images of,
-                // so all that is needed here is the number of ghosts per tile of 64 ghost cells (its first slot is the sum of the
+                // so all that is needed here is the number of ghosts per tile of ghost cells (its first slot is the sum of the
                 // totals in front of it).  The ghost cell of an image is the geometric image of the atom's own cell.  No returning
                 // atomics: nothing waits (a chain of rank atomics, one per direction, cost 25-40 us here)
-                int fl = 0;
-                if (act) fl = near_flags(a.src.x[0][j], a.src.x[1][j], a.src.x[2][j], a.sl.lo, a.sl.hi);
-                if (__ballot(fl != 0) != 0ull) {
-                    const u32 lc = (u32)(code0 - a.M) + (u32)lo_code;          // Morton code of the atom's cell
+#pragma unroll
+                for (int u = 0; u < FR_U; u++) {
+                    if (__ballot(jj[u] >= 0) == 0ull) continue;
+                    u32 emask = 0;
+                    const u32 lc = (u32)(code0 - a.M) + (u32)cc[u];           // Morton code of the atom's cell
                     const int bx = (int)compact3(lc), by = (int)compact3(lc >> 1), bz = (int)compact3(lc >> 2);
-#pragma unroll 1
-                    for (int dir = 0; dir < 27; dir++) {
+                    if (jj[u] >= 0) emask = image_mask(near_flags(X[u][0], X[u][1], X[u][2], a.sl.lo, a.sl.hi), bx, by, bz, a.g.mbin, a.dir_mask);
+                    u32 any = emask;                  // directions some lane of the wave has an image in
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) any |= (u32)__shfl_xor((int)any, o, 64);
+                    any = (u32)__builtin_amdgcn_readfirstlane((int)any);
+                    while (any) {
+                        const int dir = __builtin_ctz(any);
+                        any &= any - 1u;
+                        const bool em = (emask >> dir) & 1u;
                         const int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
-                        // an image sent up (s = +1) comes from the last cell below the high face and lands in ghost cell 0; k_fr_ghosts
-                        // pulls exactly these (an atom ON the slab plane of a box whose cells are exactly one ghost cutoff wide can
-                        // sit in the cell next to it: not an image for either kernel)
-                        const bool cellok = (sx == 0 || bx == (sx > 0 ? a.g.mbin[0] - 2 : 1)) && (sy == 0 || by == (sy > 0 ? a.g.mbin[1] - 2 : 1)) &&
-                                            (sz == 0 || bz == (sz > 0 ? a.g.mbin[2] - 2 : 1));
-                        const bool em = dir != 13 && fl && in_dir(fl, dir) && ((a.dir_mask >> dir) & 1u) && cellok;
-                        if (__ballot(em) == 0ull) continue;
                         const u32 gc = interleave3((u32)(sx == 0 ? bx : (sx > 0 ? 0 : a.g.mbin[0] - 1)), (u32)(sy == 0 ? by : (sy > 0 ? 0 : a.g.mbin[1] - 1)),
                                                    (u32)(sz == 0 ? bz : (sz > 0 ? 0 : a.g.mbin[2] - 1)));
-                        wave_group_add(em ? gc / FR_TILE : 0u, em, a.gttot);
+                        wave_group_add(em ? gc / FR_GTILE : 0u, em, a.gttot);
                     }
                 }
             }
@@ -263,17 +353,19 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS) k_fr_place(FusedArgs a)
 __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
 {
     extern __shared__ unsigned char fr_em[];      // per candidate of the pass: 1 = becomes a ghost of this cell
-    __shared__ int cstart[FR_TILE + 1];           // candidates (atoms of the source cell) in front of each of my cells
-    __shared__ int gl[FR_TILE + 1];               // ghosts in front of each of my cells
-    __shared__ int src0[FR_TILE];                 // first atom of the source cell (new order), direction
-    __shared__ int sdir[FR_TILE];
+    __shared__ int cstart[FR_GTILE + 1];           // candidates (atoms of the source cell) in front of each of my cells
+    __shared__ int gl[FR_GTILE + 1];               // ghosts in front of each of my cells
+    __shared__ int src0[FR_GTILE];                 // first atom of the source cell (new order), direction
+    __shared__ int sdir[FR_GTILE];
+    __shared__ int scell[FR_GTILE];                // the source cell's coordinates, 10 bits each
     __shared__ int wsum[FR_THREADS / 64];
     const int t = blockIdx.x, tid = threadIdx.x;
-    const int ntiles = a.M / FR_TILE;
-    const int code0 = t * FR_TILE;
-    const int base = fr_tile_base(a.gttot, a.gstot, t, wsum);
-    if (tid < 64) {
-        // the cell my ghosts are images of, and the direction they were sent in (geometry only)
+    const int ntiles = a.M / FR_GTILE;
+    const int code0 = t * FR_GTILE;
+    int nc = 0;
+    if (tid < FR_GTILE) {
+        // the cell my ghosts are images of, and the direction they were sent in (geometry only); its atoms sit in the border
+        // section of the new order (these loads are in flight while the tile's first slot is added up)
         const u32 g = (u32)(code0 + tid);
         const int b[3] = {(int)compact3(g), (int)compact3(g >> 1), (int)compact3(g >> 2)};
         int sb[3], sd[3];
@@ -286,30 +378,54 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
             else { sb[d] = b[d]; sd[d] = 0; }
         }
         const int dir = (sd[0] + 1) + 3 * (sd[1] + 1) + 9 * (sd[2] + 1);
-        int nc = 0, first = 0;
+        int first = 0;
         if (ghostcell && inside && ((a.dir_mask >> dir) & 1u)) {
             const u32 ms = interleave3((u32)sb[0], (u32)sb[1], (u32)sb[2]);
             first = a.estart[a.M + ms];
             nc = a.estart[a.M + ms + 1] - first;
         }
-        src0[tid] = first; sdir[tid] = dir;
+        src0[tid] = first; sdir[tid] = dir; scell[tid] = sb[0] | (sb[1] << 10) | (sb[2] << 20);
+    }
+    const int base = fr_tile_base(a.gttot, a.gstot, t, wsum);
+    if (t == 0) {
+        // the rebuild's counts, reported by the tile that starts first: on the device for the kernels that follow, in pinned host
+        // memory for the engine (four words: every store to host memory is a trip over the host link)
+        int part = 0;
+        for (int k = tid; k < ntiles; k += FR_THREADS) part += a.gttot[k];
+        const int ng = fr_block_sum(part, wsum);
+        if (tid < 28) a.dir_start[tid] = tid == 27 ? ng : 0;
+        if (tid == 0) {
+            a.gstart[a.M] = ng;
+            int f = a.flags[0];
+            if (ng > a.ghost_cap) f = 200000;
+            if (f) a.flags[0] = f;
+            *a.novf = 0;
+            a.report[8] = f;
+            a.report[9] = a.estart[a.M];            // n_bulk
+            a.report[10] = a.flags[5];              // fullest brick neighbourhood of the previous list build
+            a.report[16 + 27] = ng;
+        }
+    }
+    if (tid < 64) {
         int incl = nc;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int u = __shfl_up(incl, o, 64);
             if (tid >= o) incl += u;
         }
-        cstart[tid] = incl - nc;
-        if (tid == 63) cstart[64] = incl;
-        gl[tid] = 0;
+        if (tid < FR_GTILE) { cstart[tid] = incl - nc; gl[tid] = 0; }
+        if (tid == FR_GTILE - 1) cstart[FR_GTILE] = incl;
     }
-    if (tid == 0) { a.gttot_next[t] = 0; gl[64] = 0; }
+    if (tid == 0) { a.gttot_next[t] = 0; gl[FR_GTILE] = 0; }
     __syncthreads();
     // candidates -> ghost flags, ghosts per cell (passes over sub-ranges of cells whose candidates fit the LDS stage)
     int cb = 0;
-    while (cb < FR_TILE) {
-        int ce = cb + 1;
-        while (ce < FR_TILE && cstart[ce + 1] - cstart[cb] <= a.lds_cap) ce++;
+    while (cb < FR_GTILE) {
+        int ce = FR_GTILE;
+        if (cstart[FR_GTILE] - cstart[cb] > a.lds_cap) {
+            ce = cb + 1;
+            while (ce < FR_GTILE && cstart[ce + 1] - cstart[cb] <= a.lds_cap) ce++;
+        }
         const int s0 = cstart[cb], ns = cstart[ce] - s0;
         if (ns > a.lds_cap) { if (tid == 0) atomicMax(a.flags, 300003); cb = ce; continue; }      // one cell beyond the stage
         for (int p = tid; p < ns; p += FR_THREADS) {
@@ -329,45 +445,30 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
     }
     // ghosts per cell -> first slot of each cell
     if (tid < 64) {
-        const int c = gl[tid];
+        const int c = tid < FR_GTILE ? gl[tid] : 0;
         int incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int u = __shfl_up(incl, o, 64);
             if (tid >= o) incl += u;
         }
-        a.gstart[code0 + tid] = base + incl - c;
-        gl[tid] = incl - c;
-        if (tid == 63) gl[64] = incl;
+        if (tid < FR_GTILE) { a.gstart[code0 + tid] = base + incl - c; gl[tid] = incl - c; }
+        if (tid == FR_GTILE - 1) gl[FR_GTILE] = incl;
     }
     __syncthreads();
-    const int total = gl[FR_TILE];
-    if (t == ntiles - 1 && tid < 28) {
-        // the rebuild's counts: on the device for the kernels that follow, in pinned host memory for the engine (four words: every
-        // store to host memory is a trip over the host link on this tile's critical path)
-        const int ng = base + total;
-        a.dir_start[tid] = tid == 27 ? ng : 0;
-        if (tid == 0) {
-            a.gstart[a.M] = ng;
-            int f = a.flags[0];
-            if (ng > a.ghost_cap) f = 200000;
-            if (f) a.flags[0] = f;
-            *a.novf = 0;
-            a.report[8] = f;
-            a.report[9] = a.estart[a.M];            // n_bulk
-            a.report[10] = a.flags[5];              // fullest brick neighbourhood of the previous list build
-            a.report[16 + 27] = ng;
-        }
-    }
+    const int total = gl[FR_GTILE];
     if (total == 0) return;
     // second walk over the candidates: the ghosts, in (cell, source index) order - deterministic, no atomics
     cb = 0;
-    while (cb < FR_TILE) {
-        int ce = cb + 1;
-        while (ce < FR_TILE && cstart[ce + 1] - cstart[cb] <= a.lds_cap) ce++;
+    while (cb < FR_GTILE) {
+        int ce = FR_GTILE;
+        if (cstart[FR_GTILE] - cstart[cb] > a.lds_cap) {
+            ce = cb + 1;
+            while (ce < FR_GTILE && cstart[ce + 1] - cstart[cb] <= a.lds_cap) ce++;
+        }
         const int s0 = cstart[cb], ns = cstart[ce] - s0;
         if (ns > a.lds_cap) { cb = ce; continue; }
-        const bool refill = !(cb == 0 && ce == FR_TILE);      // several passes: the flags of this pass again
+        const bool refill = !(cb == 0 && ce == FR_GTILE);      // several passes: the flags of this pass again
         if (refill) {
             __syncthreads();
             for (int p = tid; p < ns; p += FR_THREADS) {
@@ -397,7 +498,8 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
             const int j = src0[lo] + (p - q0), d = sdir[lo];
             const int gi = a.n + k;
             // pack_border_vel (atom_vec_dpd_atomic_meso.cu:61-135): x + shift, tag, type, mask
-            const double gx = a.dst.x[0][j] + a.sh.s[d][0], gy = a.dst.x[1][j] + a.sh.s[d][1], gz = a.dst.x[2][j] + a.sh.s[d][2];
+            const double xj = a.dst.x[0][j], yj = a.dst.x[1][j], zj = a.dst.x[2][j];
+            const double gx = xj + a.sh.s[d][0], gy = yj + a.sh.s[d][1], gz = zj + a.sh.s[d][2];
             a.dst.x[0][gi] = gx; a.dst.x[1][gi] = gy; a.dst.x[2][gi] = gz;
             const int tg = a.dst.tag[j], ty = a.dst.type[j];
             a.dst.tag[gi] = tg; a.dst.type[gi] = ty; a.dst.mask[gi] = a.dst.mask[j];
@@ -411,9 +513,15 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
             a.mg.veloc4[gi] = v;
             a.sendlist[k] = j;
             a.senddir[k] = (unsigned char)d;
-            if (a.img_cnt) {      // where the images of atom j live (the step-boundary epilogue refreshes them between rebuilds)
-                const int slot = atomicAdd(&a.img_cnt[j], 1);
+            if (a.img_cnt) {
+                // where the images of atom j live (the step-boundary epilogue refreshes them between rebuilds).  The atom's slot for
+                // this image = the number of its images in lower directions - no atomic, no round trip; the image in its lowest
+                // direction also books their number
+                const int sc = scell[lo];
+                const u32 emask = image_mask(near_flags(xj, yj, zj, a.sl.lo, a.sl.hi), sc & 1023, (sc >> 10) & 1023, sc >> 20, a.g.mbin, a.dir_mask);
+                const int slot = __popc(emask & ((1u << d) - 1u)), nimg = __popc(emask);
                 if (slot < 8) a.img[(size_t)j * 8 + slot] = gi | (d << 26);
+                if (slot == 0) a.img_cnt[j] = nimg;
             }
         }
         cb = ce;
@@ -424,7 +532,7 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
 {
     if (a.n <= 0) return;
     hipLaunchKernelGGL(k_fr_count, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
-    const int ntl = 2 * a.M / FR_TILE, ntg = a.M / FR_TILE;
+    const int ntl = 2 * a.M / FR_TILE, ntg = a.M / FR_GTILE;
     if (a.stot) hipLaunchKernelGGL(k_fr_super, dim3((ntl + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.ttot, ntl, a.stot);
     const size_t dyn2 = (size_t)a.lds_cap * 8, dyn3 = (size_t)a.lds_cap;
     if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_fr_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
@@ -435,6 +543,7 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
 
 int fused_direct_tiles() { return FR_DIRECT_TILES; }
 int fused_tile_codes() { return FR_TILE; }
+int fused_gtile_codes() { return FR_GTILE; }
 int fused_super_tiles() { return FR_SUPER; }
 
 } // namespace meso
