@@ -168,21 +168,33 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 //     indices on the way out, tail slots padded with the atom itself.
 // Entry order inside a row is (batch, lane): deterministic, and different from the lane-per-atom builders.
 #define TB_G 4
+#ifndef TB2_THREADS
+#define TB2_THREADS 256      // workgroup of the 2x2x2-brick builder: 4 waves, 2 bins each
+#endif
 #define TB_ROWCAP_MAX 1024         // rows are staged in LDS at their full capacity n_col (2 bytes per entry)
 
-__global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
+// E: brick edge in bins.  4: the 4x4x4 brick (64 Morton codes, 6x6x6-bin neighbourhood, 10 waves) of rounds 1-2.  2 (default):
+// a 2x2x2 brick (8 codes, 4x4x4-bin neighbourhood, 4 waves of 2 bins each): eight times as many workgroups of a fifth of
+// the LDS, eight to a CU - a 32^3 box (343 4-bricks = 2.7 workgroups per CU, one round) fills the chip evenly, and large boxes
+// gain as well although 8 atoms are staged per own atom instead of 3.4 (staging is a small part; the finer grain hides the
+// staging latency of one workgroup behind the scans of the seven others): 32^3 77 -> 52 us, 64^3 303 -> 265, 128^3 2257 -> 1784.
+// The 4-brick remains the fallback when a 2-brick neighbourhood nears its LDS stage (which does not grow).
+template <int E>
+__global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3 : 2) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
                                                               int n_col, int *__restrict__ count, int *__restrict__ table,
                                                               int *__restrict__ overflow, int split, int dbg)
 {
 #pragma clang fp contract(fast)
+    constexpr int CODES = E * E * E, H = E + 2, NHB = H * H * H, THREADS = E == 4 ? BRK_THREADS : TB2_THREADS, WAVES = THREADS / 64;
+    const int maxh = E == 4 ? g.maxh : g.maxh2;
     // staged neighbourhood, SoA (candidate reads are consecutive slots); sized at launch for g.maxh halo atoms, so denser
     // systems trade occupancy for capacity instead of failing
     extern __shared__ float tb_dyn[];
-    float *hx = tb_dyn, *hy = hx + g.maxh, *hz = hy + g.maxh;
-    u32 *hgi = (u32 *)(hz + g.maxh);
-    unsigned short *rowbuf = (unsigned short *)(hgi + g.maxh);          // [wave][TB_G][n_col]
-    __shared__ int hoff[BRK_NHB + 1];
-    __shared__ int hloc[BRK_NHB];
+    float *hx = tb_dyn, *hy = hx + maxh, *hz = hy + maxh;
+    u32 *hgi = (u32 *)(hz + maxh);
+    unsigned short *rowbuf = (unsigned short *)(hgi + maxh);          // [wave][TB_G][n_col]
+    __shared__ int hoff[NHB + 1];
+    __shared__ int hloc[NHB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // few bricks (small boxes, sub-boxes of many ranks): `split` workgroups share one brick, each staging the neighbourhood
     // and taking every split-th group of own bins - a brick then finishes sooner, which is what the launch waits for
@@ -194,15 +206,15 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
         // the brick's plan (k_brick_plan) computed here, in LDS: the halo-bin runs from estart / gstart, their prefix, and
         // the halo slot -> global index map by binary search - no plan launch, no round trip of the map through HBM
         __shared__ int wtot[4];
-        int *hs0 = (int *)rowbuf, *hl0 = hs0 + BRK_NHB, *hs1 = hl0 + BRK_NHB, *hl1 = hs1 + BRK_NHB, *hs2 = hl1 + BRK_NHB;   // rows are not staged yet
+        int *hs0 = (int *)rowbuf, *hl0 = hs0 + NHB, *hs1 = hl0 + NHB, *hl1 = hs1 + NHB, *hs2 = hl1 + NHB;   // rows are not staged yet
         const int B = slot;                  // identity brick list (cell-ordered layout)
-        const size_t e0 = (size_t)BRK_CODES * B;
-        if (g.estart[e0 + BRK_CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + BRK_CODES] - g.estart[(size_t)g.M + e0] == 0) return;
+        const size_t e0 = (size_t)CODES * B;
+        if (g.estart[e0 + CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + CODES] - g.estart[(size_t)g.M + e0] == 0) return;
         const u32 code0 = (u32)e0;
         const int bx0 = (int)compact3(code0), by0 = (int)compact3(code0 >> 1), bz0 = (int)compact3(code0 >> 2);
         int tot = 0;
-        if (tid < BRK_NHB) {
-            const int qx = bx0 - 1 + tid % BRK_H, qy = by0 - 1 + (tid / BRK_H) % BRK_H, qz = bz0 - 1 + tid / (BRK_H * BRK_H);
+        if (tid < NHB) {
+            const int qx = bx0 - 1 + tid % H, qy = by0 - 1 + (tid / H) % H, qz = bz0 - 1 + tid / (H * H);
             int s0 = 0, l0 = 0, s1 = 0, l1 = 0, s2 = 0, l2 = 0;
             if (qx >= 0 && qx < g.mbin[0] && qy >= 0 && qy < g.mbin[1] && qz >= 0 && qz < g.mbin[2]) {
                 const u32 m = interleave3((u32)qx, (u32)qy, (u32)qz);
@@ -224,17 +236,23 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
         __syncthreads();
         int base = 0;
         for (int k = 0; k < w && k < 4; k++) base += wtot[k];
-        if (tid < BRK_NHB) hoff[tid] = base + incl - tot;
-        if (tid == BRK_NHB - 1) hoff[BRK_NHB] = base + incl;
+        if (tid < NHB) hoff[tid] = base + incl - tot;
+        if (tid == NHB - 1) hoff[NHB] = base + incl;
         __syncthreads();
-        nh = hoff[BRK_NHB];
-        if (nh > g.maxh) {
-            if (tid == 0) atomicMax(overflow, 100000 + nh);
+        nh = hoff[NHB];
+        if (nh > maxh) {
+            // (2-brick: reported as the 4-brick neighbourhood of the same density would be - the engine grows both stages)
+            if (tid == 0) atomicMax(overflow, 100000 + (E == 4 ? nh : (int)(((long)nh * g.maxh + g.maxh2 - 1) / g.maxh2)));
             return;
         }
-        if (tid == 0 && nh * 8 > g.maxh * 7) atomicMax(overflow + 5, nh);      // high-water mark (see k_brick_plan)
-        for (int h = tid; h < nh; h += BRK_THREADS) {
-            int lo = 0, hi = BRK_NHB;            // largest halo bin with hoff[bin] <= h
+        if (E == 4 && tid == 0 && nh * 8 > maxh * 7) atomicMax(overflow + 5, nh);      // high-water mark (see k_brick_plan)
+        // the 2-brick's stage does not grow: at three quarters of it the engine goes back to the 4-brick, whose stage does (a
+        // 4^3-bin neighbourhood feels a local compression more than a 6^3-bin one, so this comes first)
+        if (E == 2 && tid == 0 && nh * 4 > maxh * 3) overflow[6] = 1;
+        // ... and the 4-brick's stage keeps growing meanwhile: a 6^3-bin neighbourhood around this one holds at most 27/8 as many
+        if (E == 2 && tid == 0 && (long)nh * 27 > (long)g.maxh * 7) atomicMax(overflow + 5, (int)((long)nh * 27 / 8));
+        for (int h = tid; h < nh; h += THREADS) {
+            int lo = 0, hi = NHB;            // largest halo bin with hoff[bin] <= h
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (hoff[mid] <= h) lo = mid; else hi = mid;
@@ -252,9 +270,9 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
         const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;
         nh = hdr[0];
         if (hdr[2] + hdr[4] == 0) return;
-        for (int t = tid; t <= BRK_NHB; t += BRK_THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
-        for (int t = tid; t < BRK_NHB; t += BRK_THREADS) hloc[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + t];
-        for (int h = tid; h < nh; h += BRK_THREADS) {
+        for (int t = tid; t <= NHB; t += THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
+        for (int t = tid; t < NHB; t += THREADS) hloc[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + t];
+        for (int h = tid; h < nh; h += THREADS) {
             const u32 src = g.hmap[(size_t)slot * g.maxh + h];
             hgi[h] = src;
             const float4 c = coord4[src];
@@ -266,10 +284,10 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
     auto myrow = [&](int t) { return myrow0 + t * n_col; };
     if (dbg == 1) return;        // timing ablation: staging only
 
-    for (int k = w + BRK_WAVES * part; k < BRK_CODES; k += BRK_WAVES * split) {
+    for (int k = w + WAVES * part; k < CODES; k += WAVES * split) {
         const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
                   kz = ((k >> 2) & 1) | (((k >> 5) & 1) << 1);
-        const int hb = (kx + 1) + BRK_H * ((ky + 1) + BRK_H * (kz + 1));
+        const int hb = (kx + 1) + H * ((ky + 1) + H * (kz + 1));
         // wave-uniform values are forced into SGPRs: counters, branches and the own coordinates then stay scalar
         const int own0 = __builtin_amdgcn_readfirstlane(hoff[hb]), na = __builtin_amdgcn_readfirstlane(hloc[hb]);
         if (na == 0) continue;
@@ -282,7 +300,7 @@ __global__ void __launch_bounds__(BRK_THREADS, 3) k_tile_build(BrickArgs g, cons
             int rstart[9], pre[10];
             pre[0] = 0;
             const int rl = lane < 9 ? lane : 0;
-            const int hrow_l = hb + (rl % 3 - 1) * BRK_H + (rl / 3 - 1) * BRK_H * BRK_H;
+            const int hrow_l = hb + (rl % 3 - 1) * H + (rl / 3 - 1) * H * H;
             const int lo_l = hoff[hrow_l - 1], hi_l = hoff[hrow_l + 2];
 #pragma unroll
             for (int r = 0; r < 9; r++) {
@@ -580,14 +598,24 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     // card in one round (3 workgroups per CU); only the bricks that overlap the bin grid own atoms (measured: 25^3 best with 4
     // workgroups per brick, 32^3 with 2, from 48^3 on with 1)
     const int occupied = ((g.mbin[0] + 3) / 4) * ((g.mbin[1] + 3) / 4) * ((g.mbin[2] + 3) / 4);
+    if (dbg != 99 && g.plan_inline && g.maxh2 > 0 && occupied <= g.brick2_limit && g.M >= 64) {
+        // 2x2x2 bricks: eight times as many workgroups of 4 waves
+        BrickArgs g2 = g;
+        g2.nactive = g.M / 8;
+        const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
+        const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2;
+        if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+        hipLaunchKernelGGL(k_tile_build<2>, tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg);
+    } else {
     int split = 1;
     while (split < 4 && occupied * split * 2 <= 900) split *= 2;
     if (dbg >= 100) { split = dbg - 100; dbg = 0; }     // timing experiments: pair_debug 110 + split
     const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
     const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2;
     if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
-    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    hipLaunchKernelGGL(k_tile_build, tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg);
+    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(k_tile_build<4>, tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg);
+    }
     if (excl && excl->tagc && nlocal > 0) {
         const int nw = (nlocal + 63) / 64;                                  // one wave per 64 consecutive atoms
         hipLaunchKernelGGL(k_filter_exclusion, dim3((nw + 3) / 4), dim3(256), 0, s, *excl, nlocal, n_col, count, table);

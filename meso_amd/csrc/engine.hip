@@ -314,6 +314,8 @@ int Engine::pair_coeff_table(int i, int j, double gamma, double sigma, int len, 
 int Engine::set_option(const std::string &key, double val)
 {
     if (key == "fused_rebuild") { fused_rebuild = (int)val; return 0; }
+    if (key == "brick2") { brick2 = (int)val; return 0; }
+    if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }               // 0: never the 2x2x2 bricks of small boxes
     if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
@@ -915,6 +917,16 @@ int Engine::init_params()
             if (want < brick_maxh_floor) want = brick_maxh_floor;
             tile_fits = want <= tile_build_maxh_limit(n_col, have_bonds && msp > 0 ? 1 : 0);
             bargs.maxh = want;
+            {
+                // the 2x2x2 brick of small boxes: 64 bins, scaled like the 4-brick stage when that one had to grow
+                const double mean2 = density * 64.0 * binvol * brick_margin;
+                const double grow = std::max(1.0, (double)want / std::max(1.0, std::ceil(mean + 6.5 * std::sqrt(mean))));
+                bargs.maxh2 = ((int)std::ceil((mean2 + 7.0 * std::sqrt(mean2)) * grow) + 63) / 64 * 64;
+                // eight 4-wave workgroups fit a CU whatever they stage up to 20 KB each: the head-room is free (a 4^3-bin
+                // neighbourhood feels a local compression more than a 6^3-bin one does)
+                const int roomy = (20 * 1024 - 4 * 4 * n_col * 2) / 16 / 64 * 64;
+                if (bargs.maxh2 < roomy) bargs.maxh2 = roomy;
+            }
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
             const double m128 = density * 128.0 * binvol * brick_margin * std::max(1.0, (double)brick_maxh_floor / std::max(1.0, mean + 6.5 * std::sqrt(mean)));
             reorder_cap = std::min(7680, std::max(2048, ((int)std::ceil(m128 + 6.5 * std::sqrt(m128)) + 63) / 64 * 64));
@@ -1366,7 +1378,10 @@ int Engine::build_cells_and_table()
                 // (the inline plan borrows the row stage for its run tables: 5 x 216 ints)
                 bargs.plan_inline = (tile_plan == 0 && bargs.active == nullptr && n_col >= 64) ? 1 : 0;
                 if (!bargs.plan_inline) launch_brick_plan(bargs, d_flags, stream);
-                launch_tile_build(bargs, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,
+                BrickArgs bb = bargs;
+                if (brick2_off || !brick2) bb.maxh2 = 0;
+                bb.brick2_limit = brick2_limit;
+                launch_tile_build(bb, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,
                                   pair_debug >= 10 ? pair_debug - 10 : 0, stream);
                 tend("neigh");
                 nbuild++;
@@ -1406,7 +1421,7 @@ int Engine::resolve_counts()
 
 int Engine::check_overflow()
 {
-    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 6 * sizeof(int), hipMemcpyDeviceToHost, stream));      // [5]: fullest brick neighbourhood so far
+    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 7 * sizeof(int), hipMemcpyDeviceToHost, stream));      // [5]: fullest brick neighbourhood so far, [6]: 2-brick near its stage
     HIPCHK(hipStreamSynchronize(stream));
     if (have_bonds && h_flags[4]) {
         HIPCHK(hipMemsetAsync(d_flags + 4, 0, sizeof(int), stream));
@@ -1454,6 +1469,7 @@ int Engine::reneighbor()
     {
         // denser than expected (chains, phase separation): the LDS stage of a brick neighbourhood grows BEFORE it overflows - the
         // high-water mark of the earlier list builds came with the count report (or with the last check_overflow)
+        if (h_flags[6] || h_flags[11]) brick2_off = true;      // (the 2-brick of small boxes neared its stage: 4-bricks from here on)
         const int hwm = std::max(h_flags[5], h_flags[10]);
         if (params_ready && neigh_kernel == 1 && (long)hwm * 100 > (long)bargs.maxh * 93) {
             brick_maxh_floor = ((int)(hwm * 1.08) + 63) / 64 * 64;

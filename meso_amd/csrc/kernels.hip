@@ -777,6 +777,7 @@ __global__ void __launch_bounds__(1024) k_border_scan(const int *__restrict__ cn
         report[8] = f;
         report[9] = *n_bulk;
         report[10] = flags[5];       // fullest brick neighbourhood of the previous list build
+        report[11] = flags[6];       // ... a 2-brick neighbourhood neared its stage
     }
 }
 // send list built on the pre-reorder order -> indices of the new order; also the last word of the host report (n_bulk)

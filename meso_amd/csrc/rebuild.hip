@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
             a.report[8] = f;
             a.report[9] = a.estart[a.M];            // n_bulk
             a.report[10] = a.flags[5];              // fullest brick neighbourhood of the previous list build
+            a.report[11] = a.flags[6];              // ... a 2-brick neighbourhood neared its stage
             a.report[16 + 27] = ng;
         }
     }
