@@ -24,11 +24,16 @@ def _deps(src):
     return d
 
 
+# per-file flags.  pair_ring.hip: the SLP vectoriser packs two of the three coordinate differences of a distance into v_pk_*_f32
+# and pays two v_mov per entry for the register pairs (7 instead of 6 instructions, profiles/r03_isa_pair_ring.txt): 103 -> 101 us
+EXTRA = {"pair_ring.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile(src):
     obj = os.path.join(OBJ, src + ".o")
     if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
         return obj, False
-    cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = ["hipcc"] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -199,11 +199,12 @@ __device__ inline float gaussian_tea_fast(u32 u, u32 v)
     bool pred = u > v;
     u32 v0 = pred ? u : v, v1 = pred ? v : u;
     tea_core<4>(v0, v1);
-    float t = (float)(int)v0 * (float)MESO_2_TO_MINUS_31;       // [-1,1)
-    float f = __builtin_amdgcn_sinf(0.5f * t);                  // sin(pi*t)
+    // (float)(int)v0 * 2^-31 in [-1,1), halved for v_sin_f32's revolutions: one multiplication by 2^-32 - powers of two, the
+    // same bits; the clamp to +-4 is one v_med3_f32 (its NaN rule differs from fmin/fmax only when v0 = v1 = 0: 2^-64)
+    float f = __builtin_amdgcn_sinf((float)(int)v0 * (float)MESO_2_TO_MINUS_32);                  // sin(pi*t)
     float lg = __builtin_amdgcn_logf((float)v1 * (float)MESO_2_TO_MINUS_32);
     float r = __builtin_amdgcn_sqrtf(-2.0f * (float)MESO_LN_2 * lg);
-    return fmaxf(-4.0f, fminf(r * f, 4.0f));
+    return __builtin_amdgcn_fmed3f(r * f, -4.0f, 4.0f);
 }
 
 // pair_style dpd/mini/meso (pair_dpd_minimal_meso.cu:50-89): mean0var1<8> - the sum of the two signatures mapped to

@@ -37,7 +37,18 @@ namespace meso {
 #define RG_WAVES 4
 #endif
 #define RG_GROUP (64 * RG_WAVES)      // atoms of a workgroup = Newton-pairing group
+#ifndef RG_GATHER_AHEAD
+#define RG_GATHER_AHEAD 0     // measured (profiles/r03_notes.md): gathers of chunk c + 1 in flight while chunk c is tested need 128
+#endif                        // VGPRs = 4 waves per SIMD instead of 5: 101 -> 112 us at 64^3
+#ifndef RG_RING
 #define RG_RING 256                 // records per wave; a drain check every 2 slots keeps the fill below 64 + 128
+#endif
+#ifndef RG_OCC
+#define RG_OCC 20                   // waves per CU the fp32 kernel is compiled for
+#endif
+#ifndef RG_EXEC_GATHER
+#define RG_EXEC_GATHER 0      // measured: lanes switched off for the gather 103 -> 109 us (out-of-range lanes are cheap already)
+#endif
 #define RG_OWNER_SHIFT 26
 #define RG_SHARED_BIT 0x02000000u   // record: evaluate once, add to owner and partner
 #define RG_INDEX_MASK 0x01FFFFFFu
@@ -57,8 +68,10 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 // 2 several types, cutoff per type pair
 // NPART_: lanes per atom (1, 2, 4); 0 = one lane per atom with WIDE records for more than 2^25 atoms on a rank: the record word
 // is the whole 32-bit partner index, owner lane and pairing flag travel in a byte ring next to it
-template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_>
-__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
+// PLAIN: the noise is the TEA-keyed Gaussian and the conservative force a0 w (dpd/meso, dpd/fast/meso): the wave-uniform
+// switches for dpd/mini, dpd/polyforce and dpd/tableforce (PairArgs::rng / poly / ftab) are compiled out of the hot loop
+template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_, bool PLAIN>
+__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (RG_OCC / RG_WAVES > 0 ? RG_OCC / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
     extern __shared__ double smem[];
@@ -145,7 +158,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                     }
                     const float dx = ci.x - pc2.x, dy = ci.y - pc2.y, dz = ci.z - pc2.z;
                     const float rsq = dx * dx + dy * dy + dz * dz;
-                    const float rn = pair_noise_fast(a.rng, __float_as_uint(vi.w), __float_as_uint(pv2.w));
+                    const float rn = PLAIN ? gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w))
+                                           : pair_noise_fast(a.rng, __float_as_uint(vi.w), __float_as_uint(pv2.w));
                     const float rinv = __builtin_amdgcn_rsqf(rsq);
                     const float r = rsq * rinv;
                     const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;
@@ -154,9 +168,9 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
                     float wr = wc;
                     if (!EW1 && c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
                     float fcons = c_a0 * wc;
-                    if (a.poly)      // dpd/polyforce/meso (gpu_dpd_polyforce pair_dpd_polyforce_meso.cu:159-162)
+                    if (!PLAIN && a.poly)      // dpd/polyforce/meso (gpu_dpd_polyforce pair_dpd_polyforce_meso.cu:159-162)
                         fcons = polyval_f32(wc, a.poly + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * MESO_POLY_PITCH));
-                    if (a.ftab)      // dpd/tableforce/meso (gpu_dpd_tableforce pair_dpd_tableforce_meso.cu:181)
+                    if (!PLAIN && a.ftab)      // dpd/tableforce/meso (gpu_dpd_tableforce pair_dpd_tableforce_meso.cu:181)
                         fcons = table_force_f32(r * c_cutinv, a.ftab + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * a.ftab_len), a.ftab_len);
                     float fpair = fcons - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
                     fpair *= rinv;
@@ -205,63 +219,100 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (20 / RG_WAVES > 0 ? 20 
     };
 
     const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);
-    int4 w0 = make_int4(0, 0, 0, 0), w1 = w0;
-    if (nch > 0) { w0 = rows[(size_t)part * 128]; w1 = rows[(size_t)part * 128 + 1]; }
-#pragma unroll 1
-    for (int c = 0; c < nchmax; c++) {
-        const bool active = c < nch;
-        const u64 actm = __builtin_amdgcn_ballot_w64(active);
-        const int j[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        if (c + 1 < nch) { w0 = rows[(size_t)((c + 1) * NPART + part) * 128]; w1 = rows[(size_t)((c + 1) * NPART + part) * 128 + 1]; }
-        float4 c2[8];
-        bool use[8], shb[8];
-        u64 usem[8];
+    // chunk ch of my row: two 16-byte words (lanes past their row: zeros, never used)
+    auto ldrow = [&](int ch, int4 &w0, int4 &w1) {
+        w0 = make_int4(0, 0, 0, 0); w1 = w0;
+        if (ch < nch) { w0 = rows[(size_t)(ch * NPART + part) * 128]; w1 = rows[(size_t)(ch * NPART + part) * 128 + 1]; }
+    };
+    // the entries of one chunk: which of them are looked at, and their coordinate gathers on the way
+    auto prep = [&](int ch, const int4 w0, const int4 w1, int (&j)[8], bool (&use)[8], bool (&shb)[8], float4 (&c2)[8]) {
+        const bool active = ch < nch;
+        j[0] = w0.x; j[1] = w0.y; j[2] = w0.z; j[3] = w0.w; j[4] = w1.x; j[5] = w1.y; j[6] = w1.z; j[7] = w1.w;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             use[q] = active;
             shb[q] = false;
-            usem[q] = actm;
             if (SHARE) {
-                // (lane masks from the same compares through the icmp builtins: 36 = ULT)
-                usem[q] = actm & ~(__builtin_amdgcn_uicmp((u32)j[q] ^ (u32)i, (u32)NB, 36) & __builtin_amdgcn_uicmp((u32)j[q], (u32)i, 36));
-                // same aligned 256-group: lower partner index = mirrored entry, not looked at; higher (and one of this
-                // launch's atoms) = evaluated once for both
-                const bool same = ((u32)j[q] ^ (u32)i) < (u32)NB;
-                use[q] = active & !(same & ((u32)j[q] < (u32)i));
-                shb[q] = same & ((u32)j[q] > (u32)i) & ((u32)j[q] < (u32)a.end);
+                // same aligned group: lower partner index = mirrored entry, not looked at; higher (and one of this launch's atoms) =
+                // evaluated once for both.  Two compares per entry; everything else is scalar logic on their lane masks
+                // (lower-or-equal: the tail slots of a row hold the atom itself - not looked at either)
+                const bool same = ((u32)j[q] ^ (u32)i) < (u32)NB, lower = (u32)j[q] <= (u32)i;
+                use[q] = active & !(same & lower);
+                shb[q] = same & !lower;
             }
         }
 #pragma unroll
         for (int q = 0; q < 8; q++) c2[q] = buf_load4(rc, use[q] ? ((u32)j[q] << 4) : 0xFFFFFFF0u);   // out of range: returns 0, no fetch
+    };
+    // cutoff test of one chunk's entries, hits into the ring, drain checks
+    auto proc = [&](const int (&j)[8], const bool (&use)[8], const bool (&shb)[8], const float4 (&c2)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            // lane masks straight from the compares (LLVM predicates: 4 = OLT, 3 = OGE); tail slots hold i itself: rsq = 0
-            u64 m;
+            // tail slots hold i itself: rsq = 0.  One set of compares: the hit is a lane mask already, its ballot costs nothing
             bool hit;
             if (FAST) {
                 const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
                 const float rsq = dx * dx + dy * dy + dz * dz;
                 const float cutsq = UCUT ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * 8 + 5];
-                m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) & usem[q];
                 hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & use[q];
             } else {
                 const double rsq = rsq_f64(c1, c2[q]);
                 const double cutsq = UCUT ? a.cf1[P_CUTSQ] : cf64[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * N_COEFF + P_CUTSQ];
-                m = __builtin_amdgcn_fcmp(rsq, cutsq, 4) & __builtin_amdgcn_fcmp(rsq, MESO_EPSILON_SQ, 3) & usem[q];
                 hit = (rsq < cutsq) & (rsq >= MESO_EPSILON_SQ) & use[q];
             }
+            const u64 m = __builtin_amdgcn_ballot_w64(hit);
             if (hit) {
                 const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1);
-                ring[pos] = make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float(WIDE ? (u32)j[q] : ((u32)j[q] | ((SHARE && shb[q]) ? lanehi | RG_SHARED_BIT : lanehi))));   // record word last
-                if (WIDE) ringm[pos] = (unsigned char)((u32)slot | ((SHARE && shb[q]) ? 64u : 0u));
+                const bool sh = SHARE && shb[q] && (u32)j[q] < (u32)a.end;
+                ring[pos] = make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float(WIDE ? (u32)j[q] : ((u32)j[q] | (sh ? lanehi | RG_SHARED_BIT : lanehi))));   // record word last
+                if (WIDE) ringm[pos] = (unsigned char)((u32)slot | (sh ? 64u : 0u));
                 if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(c2[q].w);
             }
             qtail += __popcll(m);
-            if (q & 1) {
+            if (RG_RING < 256 || (q & 1)) {
                 while (qtail - qhead >= 64) { compute(); issue(64); }
             }
         }
+    };
+#if RG_GATHER_AHEAD
+    // the gathers of chunk c + 1 are in flight while chunk c is tested (and the row words of chunk c + 2 while those are
+    // issued): the kernel is bound by the latency of its dependent gathers more than by instruction issue
+    {
+        int jA[8], jB[8];
+        bool useA[8], useB[8], shbA[8], shbB[8];
+        float4 cA[8], cB[8];
+        int4 wa0, wa1, wb0, wb1;
+        ldrow(0, wa0, wa1);
+        ldrow(1, wb0, wb1);
+        prep(0, wa0, wa1, jA, useA, shbA, cA);
+        ldrow(2, wa0, wa1);
+#pragma unroll 1
+        for (int c = 0; c < nchmax; c += 2) {
+            prep(c + 1, wb0, wb1, jB, useB, shbB, cB);
+            ldrow(c + 3, wb0, wb1);
+            proc(jA, useA, shbA, cA);
+            if (c + 1 >= nchmax) break;
+            prep(c + 2, wa0, wa1, jA, useA, shbA, cA);
+            ldrow(c + 4, wa0, wa1);
+            proc(jB, useB, shbB, cB);
+        }
     }
+#else
+    {
+        int j[8];
+        bool use[8], shb[8];
+        float4 c2[8];
+        int4 w0, w1;
+        ldrow(0, w0, w1);
+#pragma unroll 1
+        for (int c = 0; c < nchmax; c++) {
+            const int4 v0 = w0, v1 = w1;
+            ldrow(c + 1, w0, w1);
+            prep(c, v0, v1, j, use, shb, c2);
+            proc(j, use, shb, c2);
+        }
+    }
+#endif
     compute();
     while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
@@ -321,12 +372,19 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     else ew1 = p.all_expw_one != 0;
     // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom
     const bool share = p.share != 0 && (p.beg & (RG_GROUP - 1)) == 0;
-#define RG_LAUNCH(F, A, B, C)                                                                                   \
+    const bool plain = p.rng == 0 && !p.poly && !p.ftab;
+#define RG_LAUNCH2(F, A, B, C, P)                                                                               \
     do {                                                                                                        \
-        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0>), grid, block, sm, s, p);                  \
-        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4>), grid, block, sm, s, p);       \
-        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2>), grid, block, sm, s, p);       \
-        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1>), grid, block, sm, s, p);                       \
+        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0, P>), grid, block, sm, s, p);               \
+        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P>), grid, block, sm, s, p);    \
+        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P>), grid, block, sm, s, p);    \
+        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P>), grid, block, sm, s, p);                    \
+    } while (0)
+    // (the fp64 style has no variants: always "plain")
+#define RG_LAUNCH(F, A, B, C)                                   \
+    do {                                                        \
+        if (plain || !(F)) RG_LAUNCH2(F, A, B, C, true);        \
+        else RG_LAUNCH2(F, A, B, C, false);                     \
     } while (0)
 #define RG_TYPES(F, B, C)                                      \
     do {                                                       \
@@ -346,6 +404,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
 #undef RG_PICK
 #undef RG_TYPES
 #undef RG_LAUNCH
+#undef RG_LAUNCH2
 }
 
 int pair_ring_group() { return RG_GROUP; }
