@@ -950,11 +950,14 @@ int Engine::migrate_inband()
     xchg_what = "migration (fixed capacity)";
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
     // the one host round trip: lost-atom flag, my direction starts, the counts in the peers' headers
-    hipLaunchKernelGGL(k_mig_read_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, h_flags_dev + 96);
+    hipLaunchKernelGGL(k_mig_read_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, h_flags_dev + 128);      // (slots of its own)
     HIPCHK(hipMemcpyAsync(h_flags + 3, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    if (h_flags[3]) return fail(5, "Atoms moved further than one sub-domain between rebuilds (lost atoms)");
+    // an error of this rank is reported AFTER the second exchange: the peers of this rebuild get what they wait for, and the host
+    // (LAMMPS error->one -> MPI_Abort, torch.distributed's launcher) ends the job of every rank on the status this one returns
+    const char *deferred = nullptr;
+    if (h_flags[3]) deferred = "Atoms moved further than one sub-domain between rebuilds (lost atoms)";
     int ds[28], cnt[27];
     for (int k = 0; k < 28; k++) ds[k] = h_flags[16 + k];
     for (int d = 0; d < 27; d++) cnt[d] = ds[d + 1] - ds[d];
@@ -962,14 +965,14 @@ int Engine::migrate_inband()
     std::vector<int> send_n(np, 0), recv_n(np, 0);
     for (int d = 0; d < 27; d++) {
         if (d == 13 || !cnt[d]) continue;
-        if (peer_index[d] < 0) return fail(5, "Atom left the box through a non-periodic boundary");
+        if (peer_index[d] < 0) { deferred = "Atom left the box through a non-periodic boundary"; continue; }
         send_n[peer_index[d]] += cnt[d];
     }
     int nrecv_tot = 0;
     bool again_s = false, again_r = false;
     for (int p = 0; p < np; p++) {
-        recv_n[p] = h_flags[96 + p];
-        if (recv_n[p] < 0) return fail(5, "migration: corrupt message header");
+        recv_n[p] = h_flags[128 + p];
+        if (recv_n[p] < 0) { deferred = "migration: corrupt message header"; recv_n[p] = 0; }
         nrecv_tot += recv_n[p];
         again_s |= send_n[p] > mig_cap_s[p];
         if (send_n[p] > mig_cap_s[p]) mig_resends++;
@@ -1026,6 +1029,7 @@ int Engine::migrate_inband()
         }
         xchg_what = "migration (resend)";
         TRY(xchg(np, peers.data(), sb2.data(), sn2.data(), rb2.data(), rn2.data()));
+        if (deferred) return fail(5, deferred);
         // where every peer's migrants lie
         MigSources S;
         S.np = np;

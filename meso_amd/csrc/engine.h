@@ -14,6 +14,7 @@ struct ncclComm;
 
 namespace meso {
 
+struct FusedArgs;
 struct DirTab;
 struct LocalGroup;
 
@@ -296,6 +297,7 @@ private:
     bool fused_dirty = false;       // a fused rebuild failed half-way: counters are cleared before the next one
     bool fused_ok() const;
     int rebuild_fused();
+    void fused_locals_args(FusedArgs &a);
     int fused_alloc();
     unsigned long long *fr_bucket = nullptr, *fr_ovf = nullptr;
     int *fr_novf = nullptr, *fr_ttot[2] = {nullptr, nullptr}, *fr_stot[2] = {nullptr, nullptr};

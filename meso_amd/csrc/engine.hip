@@ -384,7 +384,7 @@ int Engine::alloc_atoms(int cap)
         HIPCHK(dalloc(d_flags, 16));
         HIPCHK(dalloc(d_dir_start, 32));
         HIPCHK(dalloc(sendlist_aux, 2 * 27 * 27 + 64));
-        HIPCHK(hipHostMalloc((void **)&h_flags, 128 * sizeof(int)));      // [64..127]: report of the multi-rank border exchange
+        HIPCHK(hipHostMalloc((void **)&h_flags, 192 * sizeof(int)));      // [64..127]: report of the multi-rank border exchange, [128..159]: of the migration
         HIPCHK(hipHostMalloc((void **)&h_scalar, 16 * sizeof(double)));
         HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), stream));
     }
@@ -1004,9 +1004,21 @@ int Engine::reorder_locals()
     }
     tbegin("reorder");
     int bits = reorder_key_bits(geom);
+    bool gathered = false;
     if (!reorder_sort) {
         // counting per extended code instead of a comparison sort (kernels.hip): ~8 launches instead of ~28; estart - first
         // index of every extended code ([border][Morton(bin)]), the border section starts at estart[M] = n_bulk - is the scan
+        if (fused_rebuild && neigh_kernel == 1 && (long)nlocal < (1L << 27)) {
+            // count + place/gather (rebuild.hip, the locals' half of the fused rebuild): two launches for count, scan x2, place,
+            // order and gather; estart and the merged pairs come with it (several ranks, and the first rebuild of one rank)
+            TRY(fused_alloc());
+            FusedArgs a;
+            fused_locals_args(a);
+            fr_epoch++;
+            launch_fused_rebuild(a, stream);
+            if (!async_ok()) HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
+            gathered = true;
+        } else {
         const int ncodes = 2 * bargs.M;
         launch_reorder_count(cur, geom, slab_lo, slab_hi, rkey, rval_alt, rcount, nlocal, wrap_in_reorder ? boxlo : nullptr, boxhi, periodic,
                              stream);
@@ -1016,6 +1028,7 @@ int Engine::reorder_locals()
         std::swap(rkey, bin_key_alt);            // sorted keys (the lane-per-atom list builder reads them)
         // n_bulk = estart[M]: the asynchronous rebuild reads it where it is (halo_borders), the others through d_flags[1]
         if (!async_ok()) HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        }
     } else {
         // option reorder_sort: the former path - one rocPRIM radix_sort_pairs on the full key (same resulting order)
         launch_reorder_keys(cur, geom, slab_lo, slab_hi, nullptr, rkey, rval, nlocal, stream);
@@ -1023,13 +1036,13 @@ int Engine::reorder_locals()
         launch_estart(rkey, nlocal, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);
         HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
     }
-    {
+    if (!gathered) {
         // the gather also writes the merged float4 pair of the new order, with the signatures of the current step
         launch_permute_merge(cur, alt, rval, nlocal, permute_forces ? 1 : 0, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
                              0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), nullptr,
                              images_on() ? img_cnt : nullptr, stream);
-        merged_in_reorder = true;      // (alloc_atoms clears it: a regrown coord4 has lost the values)
     }
+    merged_in_reorder = true;      // (alloc_atoms clears it: a regrown coord4 has lost the values)
     std::swap(cur, alt);
     if (!(nranks == 1 && async_ok())) HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
@@ -1155,16 +1168,9 @@ int Engine::fused_alloc()
     return 0;
 }
 
-int Engine::rebuild_fused()
+// arguments of the count + place kernels (the locals' half of the fused rebuild)
+void Engine::fused_locals_args(FusedArgs &a)
 {
-    tbegin("reorder");
-    // the ghost count of the previous rebuild (+ head-room) sizes the arrays and the later per-step launches; the ghost kernel
-    // itself covers every ghost cell whatever the count is, and reports a count beyond the capacity
-    const int bound = (int)(nghost_prev * async_grid_scale) + 1024;
-    TRY(ensure_capacity(nlocal + bound + bound / 2));
-    TRY(fused_alloc());
-    if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
-    FusedArgs a;
     memset(&a, 0, sizeof a);
     a.src = cur; a.dst = alt;
     a.n = nlocal;
@@ -1181,10 +1187,7 @@ int Engine::rebuild_fused()
     a.ovf = fr_ovf; a.novf = fr_novf; a.ovf_cap = fr_ovf_cap;
     const int par = (int)(fr_epoch & 1u);
     a.ttot = fr_ttot[par]; a.ttot_next = fr_ttot[par ^ 1];
-    a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
     a.stot = 2 * bargs.M / fused_tile_codes() > fused_direct_tiles() ? fr_stot[0] : nullptr;
-    a.gstot = bargs.M / fused_gtile_codes() > fused_direct_tiles() ? fr_gstot[0] : nullptr;
-    fr_epoch++;
     a.estart = estart;
     a.perm = rval;
     a.scratch = fr_scratch;
@@ -1194,6 +1197,24 @@ int Engine::rebuild_fused()
     a.mg.seed = premix_tea<64>((u32)seed, (u32)ntimestep);
     a.mg.inverse = nullptr;
     a.mg.zero = images_on() ? img_cnt : nullptr;
+    a.flags = d_flags;
+}
+
+int Engine::rebuild_fused()
+{
+    tbegin("reorder");
+    // the ghost count of the previous rebuild (+ head-room) sizes the arrays and the later per-step launches; the ghost kernel
+    // itself covers every ghost cell whatever the count is, and reports a count beyond the capacity
+    const int bound = (int)(nghost_prev * async_grid_scale) + 1024;
+    TRY(ensure_capacity(nlocal + bound + bound / 2));
+    TRY(fused_alloc());
+    if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
+    FusedArgs a;
+    fused_locals_args(a);
+    const int par = (int)(fr_epoch & 1u);
+    a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
+    a.gstot = bargs.M / fused_gtile_codes() > fused_direct_tiles() ? fr_gstot[0] : nullptr;
+    fr_epoch++;
     a.gstart = gstart;
     a.dir_mask = 0;
     for (int d = 0; d < 27; d++)
@@ -1204,7 +1225,6 @@ int Engine::rebuild_fused()
     a.img_cnt = images_on() ? img_cnt : nullptr; a.img = img;
     a.ghost_cap = std::min(nmax - nlocal - 1, send_cap);
     a.dir_start = d_dir_start;
-    a.flags = d_flags;
     a.report = h_flags_dev;
     launch_fused_rebuild(a, stream);
     std::swap(cur, alt);
@@ -1558,7 +1578,9 @@ void Engine::launch_pair(PairArgs &p, int ev)
 {
     const bool cell_ring = !ev && ring_selected();
     if (!cell_ring) p.fuse_nve = 0;              // only the ring kernel has the epilogue
-    p.nall = counts_pending ? nmax : nlocal + nghost;      // bound of the buffer-addressed gathers (the ghost count may still be an estimate)
+    // bound of the buffer-addressed gathers (the ghost count may still be an estimate: then the capacity); 32-bit byte offsets,
+    // 16 bytes per atom: never beyond 2^28 - 1 atoms (reneighbor refuses more atoms than that on a rank)
+    p.nall = (int)std::min<long>(counts_pending ? (long)nmax : (long)nlocal + nghost, (1L << 28) - 1);
     p.rng = pair_rng;
     p.npart = pair_npart;
     p.poly = pair_poly ? d_poly : nullptr;

@@ -492,9 +492,11 @@ __device__ inline void wave_group_add(u32 group, bool valid, int *__restrict__ t
 __device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
 
 // x -> two's-complement 64-bit fixed point with 32 fractional bits: floor(x) in the high word, fract(x) * 2^32 in the low
-// word (exact for every fp32 x with |x| < 2^31 down to 2^-32 resolution)
+// word (exact for every fp32 x with |x| < 2^19 down to 2^-32 resolution; a larger force component - a diverging run - is
+// clamped to +-2^19 instead of wrapping into a plausible-looking sum: v_med3_f32, one instruction)
 __device__ inline u64 to_fixed(float x)
 {
+    x = __builtin_amdgcn_fmed3f(x, -524287.0f, 524287.0f);
     // x + 1.5 * 2^20 as a double has x * 2^32 (rounded to nearest, two's complement) in its low 52 bits; taking the exponent and
     // the 1.5 off the high word leaves the 64-bit fixed-point number (|x| < 2^19): cvt, add, one integer add
     const double y = (double)x + 1572864.0;

@@ -121,8 +121,10 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (RG_OCC / RG_WAVES > 0 ?
     }
     __syncthreads();   // coefficient table (multi-type), accumulators, this wave's own_c/own_v
 
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.coord4, 0, a.nall * 16, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, a.nall * 16, 0x00020000);
+    // (num_records is 32 bits: launch_pair clamps nall below 2^28 atoms, 16 bytes each)
+    const u32 nrec = (u32)min((unsigned long long)(u32)a.nall * 16ull, 0xFFFFFFFFull);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.coord4, 0, (int)nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, (int)nrec, 0x00020000);
     const u32 t1 = __float_as_uint(c1.w);
     const float dtis = (float)a.dt_inv_sqrt;
     const u32 lanehi = (u32)slot << RG_OWNER_SHIFT;

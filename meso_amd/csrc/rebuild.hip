@@ -36,7 +36,8 @@ namespace meso {
 #define FR_TILE 64            // cells per tile of k_fr_place (<= 64)
 #endif
 #ifndef FR_U
-#define FR_U 4                // trips of k_fr_place whose loads are issued together
+#define FR_U 1                // trips of k_fr_place whose loads are issued together (measured 1..4: the registers of more
+                              // trips cost occupancy - 64^3 141 us with 1, 158 us with 4; 32^3 the same)
 #endif
 #ifndef FR_GTILE
 #define FR_GTILE 32           // ghost cells per tile of k_fr_ghosts (<= 64)
@@ -540,6 +541,7 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
     hipLaunchKernelGGL(k_fr_place, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     if (a.gttot && a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
     if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(ntg), dim3(FR_THREADS), dyn3, s, a);
+    else (void)hipMemsetAsync(a.novf, 0, sizeof(int), s);      // (the ghost kernel clears the overflow count otherwise)
 }
 
 int fused_direct_tiles() { return FR_DIRECT_TILES; }
