@@ -48,8 +48,8 @@ def parse():
 
 
 def host_cores():
-    """Threads for the CPU baseline: the scheduler affinity, clipped by the cgroup CPU quota and by 64
-    (the OpenMP mode keeps one private force window per thread)."""
+    """Threads for the CPU baseline: every core this process may use - the scheduler affinity, clipped by the cgroup CPU quota
+    (the OpenMP mode of the restatement keeps a private force WINDOW per thread and reduces in chunks: no thread limit)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -57,7 +57,12 @@ def host_cores():
             n = min(n, max(1, int(int(q) / int(p))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, 64))
+    return max(1, n)
+
+
+def _norm_kernel(name):
+    """Kernel names as rocprofv3 prints them and as the engine reports them, made comparable."""
+    return name.replace("void ", "").replace("meso::", "").split("(")[0].replace(" ", "")
 
 
 def cpu_baseline(L, x, v, lo, hi, every, steps):
@@ -288,15 +293,19 @@ def main():
     # HBM traffic of the force kernel: PMC counters cannot be read inside this process; the figure of the separate
     # `rocprofv3 --pmc` passes over this same command is kept in profiles/ (traffic_source names the file) and attached only
     # while kernel and workload match
+    # ... and only for the very instantiation this run launched: the engine names it (meso_pair_kernel_name), the profile file
+    # records the name rocprofv3 printed and the commit it was collected at (tools/update_profiles.py)
     traffic = traffic_source = limiter = None
+    variant = m.pair_kernel_name()
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if L == tj.get("box") and a.style == tj.get("style") and a.gpus == 1 and tj.get("kernel") == kernel:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "force_kernel_profile.json")))
+        if (L == tj.get("box") and a.style == tj.get("style") and a.gpus == 1 and variant
+                and _norm_kernel(tj.get("kernel_variant", "")) == _norm_kernel(variant)):
             traffic = tj["traffic_bytes_per_launch"]
-            traffic_source = "profiles/r02_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc")
+            traffic_source = "profiles/force_kernel_profile.json (%s; collected at %s)" % (tj.get("source", "rocprofv3 --pmc"), tj.get("head", "?"))
             # what the counters of the same profile say bounds the kernel (not HBM): profile-derived, not measured in this run
-            limiter = {"units": "VALU issue and texture addresser", "valu_issue_frac": 0.79, "ta_busy_frac": 0.73,
-                       "arithmetic_ceiling_frac_of_hbm_peak": 0.43, "source": "profiles/r02_pmc_ring_focus.txt, profiles/r02_notes.md section 1"}
+            if tj.get("limiter"):
+                limiter = dict(tj["limiter"], collected_at=tj.get("head"))
     except (OSError, ValueError, KeyError):
         pass
 
@@ -321,7 +330,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                     "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "bytes_per_launch": b_pair_only,
+                     "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "kernel_variant": variant, "bytes_per_launch": b_pair_only,
                      "us_per_launch": t_alone * 1e6, "fused": fused_rec, "limiter_from_profile": limiter},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
     }

@@ -180,6 +180,10 @@ int64_t meso_ntimestep(meso_ctx *ctx);
 /* measured HBM peak for the roofline (nominal and measured): float4 copy of nbytes (read + write counted),
  * best of reps launches timed with HIP events on the engine's stream; result in GB/s */
 int meso_membw_probe(meso_ctx *ctx, size_t nbytes, int reps, double *copy_gbs);
+/* name of the force-kernel instantiation the last launch ran ("k_pair_dpd_ring<true, 0, true, true, 1, true>", as rocprofv3
+ * prints it; empty before the first launch): measurement harnesses key profile-derived numbers on it (the reference keeps
+ * one static GridConfig per kernel instead, pair_dpd_meso.cu:216,228) */
+int meso_pair_kernel_name(meso_ctx *ctx, char *buf, int nbuf);
 
 /* ---- restart files and profiler window.  Inside LAMMPS the restart file is LAMMPS' own (the glue's
  *      Pair::write_restart keeps MesoPairDPD::write_restart's layout, pair_dpd_meso.cu:363-447).  The stand-alone driver

@@ -348,6 +348,12 @@ class Meso:
         self._ck(self.lib.meso_comm_count(self._h, C.byref(n)))
         return n.value
 
+    def pair_kernel_name(self):
+        """Instantiation of the force kernel the last launch ran, as rocprofv3 prints it."""
+        buf = C.create_string_buffer(160)
+        self._ck(self.lib.meso_pair_kernel_name(self._h, buf, 160))
+        return buf.value.decode()
+
     def membw_probe(self, nbytes=1 << 30, reps=5):
         """Measured float4 copy rate of this GPU in GB/s (read + write)."""
         g = C.c_double()

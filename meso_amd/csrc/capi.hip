@@ -97,6 +97,13 @@ int meso_comm_count(meso_ctx *ctx, int *nranks_seen)
     RET(E.comm_count(nranks_seen));
 }
 
+int meso_pair_kernel_name(meso_ctx *ctx, char *buf, int nbuf)
+{
+    if (!ctx || !buf || nbuf <= 0) return 1;
+    snprintf(buf, (size_t)nbuf, "%s", meso::pair_ring_last_variant());
+    return 0;
+}
+
 int meso_membw_probe(meso_ctx *ctx, size_t nbytes, int reps, double *copy_gbs)
 {
     CTX(ctx);

@@ -162,6 +162,7 @@ void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // records, heavy phase on full waves with the partner data re-gathered through buffer loads (pair_ring.hip)
 int pair_ring_group();   // atoms per workgroup of the ring kernel (alignment of paired launches)
 void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s);
+const char *pair_ring_last_variant();   // instantiation of the last launch, as a profiler prints it
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
 void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
 struct ExclArgs;

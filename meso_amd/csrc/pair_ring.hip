@@ -28,6 +28,7 @@
 // One wave owns its 64 atoms from start to end: no block barriers after the prologue, no global atomics; integer
 // addition is associative, so the sums do not depend on the order in which hits are drained (bit-reproducible).
 // Arithmetic of this kernel is contracted (a*b+c -> fma), like nvcc's default for the reference's fp32 kernel.
+#include <cstdio>
 #include "kernels.h"
 #include "meso_device.h"
 
@@ -345,6 +346,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (RG_OCC / RG_WAVES > 0 ?
     }
 }
 
+// the instantiation the last launch ran, spelled as rocprofv3 prints it: bench.py attaches profile-derived numbers to its line
+// only while this is the kernel they were collected for
+static char g_last_variant[128] = "";
+const char *pair_ring_last_variant() { return g_last_variant; }
+
 void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
 {
     int n = p.end - p.beg;
@@ -402,6 +408,9 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
         if (ew1) RG_TYPES(F, true, false);                \
         else RG_TYPES(F, false, false);                   \
     }
+    snprintf(g_last_variant, sizeof g_last_variant, "k_pair_dpd_ring<%s, %d, %s, %s, %d, %s>", fast ? "true" : "false",
+             nt1 ? 0 : (p.uniform_cut ? 1 : 2), ew1 ? "true" : "false", share ? "true" : "false", wide ? 0 : npart,
+             (plain || !fast) ? "true" : "false");
     if (fast) { RG_PICK(true) } else { RG_PICK(false) }
 #undef RG_PICK
 #undef RG_TYPES

@@ -44,6 +44,9 @@ done
 cd $R
 ( echo "# rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline --opt fuse_pair=0   (force kernel alone; mean per dispatch, KB)"; python3 tools/pmc_summary.py gpurun_out/${tag}_pmcp pair_dpd merge_xvt nve ) > gpurun_out/${tag}_pmc_pair_only.txt
 echo "pair-only pmc done"
+# issue / texture-path counters of the force kernel launched alone (the limiter block of the bench line)
+bash tools/pmc_focus.sh ${tag}_focus --opt fuse_pair=0 > gpurun_out/${tag}_focus.log 2>&1 || echo "focus counters failed"
+echo "focus pmc done"
 # the other configurations of BASELINE.json (parity-test cases; timed for the record)
 timeout -k 10 300 python3 bench.py --box 25 --no-cpu-baseline > gpurun_out/${tag}_bench25_fast.json 2>/dev/null
 timeout -k 10 300 python3 bench.py --box 32 --no-cpu-baseline > gpurun_out/${tag}_bench32_fast.json 2>/dev/null

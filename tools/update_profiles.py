@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the artefacts of tools/collect_profiles.sh from gpurun_out/ into profiles/ and rebuild profiles/<tag>_traffic.json
 (HBM bytes of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes).   usage: tools/update_profiles.py r01"""
-import json, re, shutil, sys
+import json, re, shutil, subprocess, sys
 tag = sys.argv[1]
 import os
 for f in ("bench64_fast.json", "kernel_stats_64_fast.txt", "kernel_stats_64_pair_only.txt", "pmc_64_fast.txt", "pmc_pair_only.txt"):
@@ -12,23 +12,53 @@ for f in ("bench25_fast.json", "bench32_fast.json", "bench48_fast.json", "bench6
     if os.path.exists(src) and os.path.getsize(src) > 100:
         shutil.copy(src, "profiles/%s_%s" % (tag, f))
 d = json.loads(open("profiles/%s_bench64_fast.json" % tag).read().strip().splitlines()[-1])
-vals = {}
+vals, variant = {}, None
 # the graded kernel is the force kernel ALONE: its counters come from the passes with the step boundary in its own kernel
 for ln in open("profiles/%s_pmc_pair_only.txt" % tag):
     m = re.match(r"(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+mean\s+([0-9.e+]+)", ln)
     if m and "k_pair_dpd_ring" in m.group(1):
         vals[m.group(2)] = float(m.group(3))
+# the instantiation, as rocprofv3 names it in the kernel statistics of the same runs
+for ln in open("profiles/%s_kernel_stats_64_pair_only.txt" % tag):
+    m = re.search(r"(k_pair_dpd_ring<[^>]*>)", ln)
+    if m:
+        variant = m.group(1)
+        break
+head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = subprocess.run(["git", "status", "--porcelain", "meso_amd/csrc"], capture_output=True, text=True).stdout.strip()
 t = {
     "source": "profiles/%s_pmc_pair_only.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, force kernel launched alone, mean per dispatch; tools/collect_profiles.sh)" % tag,
+    "head": head + ("+uncommitted kernel sources" if dirty else ""),
     "box": 64, "style": "dpd/fast/meso",
-    "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads (MI355X_MICROARCH.md, HBM): calibrated in the same passes on k_merge_xvt (28.7 MB reported for 58.7 MB read) and k_nve_final (30.7 vs 62.9 MB) -> x2, applied to the whole kernel (an upper bound for its 16-byte gathers); WRITE_SIZE is exact",
+    "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads (MI355X_MICROARCH.md, HBM): x2, applied to the whole kernel (an upper bound for its 16-byte gathers); WRITE_SIZE is exact",
     "workload": "64^3 rho=4, dpd/fast/meso",
     "kernel": d["roofline"]["kernel"].split(" (")[0],
+    "kernel_variant": variant,
     "FETCH_SIZE_KB": vals["FETCH_SIZE"],
     "WRITE_SIZE_KB": vals["WRITE_SIZE"],
     "traffic_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024),
     "algorithmic_bytes_per_launch": int(d["roofline"]["bytes_per_launch"]),
 }
 t["ratio"] = round(t["traffic_bytes_per_launch"] / t["algorithmic_bytes_per_launch"], 3)
+# issue and texture-path counters of the same kernel (tools/pmc_focus.sh ... --opt fuse_pair=0 -> gpurun_out/<tag>_focus.summary.txt)
+foc = "gpurun_out/%s_focus.summary.txt" % tag
+if os.path.exists(foc):
+    shutil.copy(foc, "profiles/%s_pmc_ring_focus.txt" % tag)
+    c = {}
+    for ln in open(foc):
+        m = re.match(r"(.*?)\s+(\S+)\s+mean\s+([0-9.e+]+)", ln)
+        if m and "k_pair_dpd_ring" in m.group(1):
+            c[m.group(2)] = float(m.group(3))
+    if "SQ_BUSY_CYCLES" in c and "SQ_INSTS_VALU" in c:
+        cyc = c["SQ_BUSY_CYCLES"] / 32.0                       # summed over the 32 shader engines
+        lim = {"units": "VALU issue and texture addresser", "kernel_cycles": cyc,
+               "valu_issue_frac": round(c["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cyc, 3),       # wave-instructions / 1024 SIMDs x 4 cycles
+               "source": "profiles/%s_pmc_ring_focus.txt (tools/pmc_focus.sh, force kernel launched alone)" % tag}
+        if "TA_TA_BUSY_sum" in c:
+            lim["ta_busy_frac"] = round(c["TA_TA_BUSY_sum"] / 256.0 / cyc, 3)               # per CU
+        if "TCP_PENDING_STALL_CYCLES_sum" in c and "TCP_GATE_EN1_sum" in c:
+            lim["l1_pending_stall_frac"] = round(c["TCP_PENDING_STALL_CYCLES_sum"] / c["TCP_GATE_EN1_sum"], 3)
+        t["limiter"] = lim
 json.dump(t, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
+json.dump(t, open("profiles/force_kernel_profile.json", "w"), indent=1)      # the file bench.py reads
 print(json.dumps(t, indent=1))
