@@ -166,6 +166,10 @@ int meso_step_advance(meso_ctx *ctx, int64_t ntimestep); /* update->ntimestep fo
 int meso_compute_temp(meso_ctx *ctx, double *temperature);
 int meso_compute_pe(meso_ctx *ctx, double *pe_total);
 int meso_compute_pressure(meso_ctx *ctx, double *pressure);
+/* a thermo step that was not announced to the force call (Integrate::ev_set src/integrate.cpp:117-150 sets eflag/vflag BEFORE
+ * the step's force; ModifiedVerlet::run mvv_meso.cu:411-415 prints after it): per-atom energy and virial are tallied at the
+ * current configuration with the forces the run continues with left untouched; no-op when this step's force call tallied */
+int meso_tally_ev(meso_ctx *ctx);
 
 /* ---- introspection used by the parity tests and bench.py */
 int meso_neigh_info(meso_ctx *ctx, int *n_col, int *max_count, double *avg_count, int64_t *nbuild);

@@ -298,6 +298,10 @@ class Meso:
         self._ck(self.lib.meso_compute_pe(self._h, C.byref(t)))
         return t.value
 
+    def tally(self):
+        """Energy and virial at the current configuration, forces untouched (a thermo output between two run() calls)."""
+        self._ck(self.lib.meso_tally_ev(self._h))
+
     def pressure(self):
         t = C.c_double()
         self._ck(self.lib.meso_compute_pressure(self._h, C.byref(t)))

@@ -237,6 +237,8 @@ int meso_neigh_info(meso_ctx *ctx, int *n_col, int *max_count, double *avg, int6
     CTX(ctx);
     RET(E.neigh_info(n_col, max_count, avg, nbuild));
 }
+
+int meso_tally_ev(meso_ctx *ctx) { CTX(ctx); RET(E.tally_ev()); }
 int meso_neigh_download(meso_ctx *ctx, int *count, int *table, int stride)
 {
     CTX(ctx);

@@ -28,3 +28,18 @@ gcc -O2 -fPIC -w -I"$SRC/STUBS" -c "$SRC/STUBS/mpi.c" -o "$OUT/obj/mpi_stubs.o"
 g++ $CXXFLAGS -c "$HERE/ref_harness.cpp" -o "$OUT/obj/ref_harness.o"
 g++ -o "$OUT/ref_lmp" "$OUT/obj/ref_harness.o" $OBJS "$OUT/obj/mpi_stubs.o" -Wl,--unresolved-symbols=ignore-all -lm
 echo "$OUT/ref_lmp"
+# the reference's own bonded styles (src/MOLECULE, compiled where they lie) behind oracle/ref_bonded.cpp -> oracle/_ref/ref_bonded
+BOBJS=""
+for f in bond angle memory error universe; do
+    o=$OUT/obj/$f.o
+    if [ ! -f "$o" ] || [ "$SRC/$f.cpp" -nt "$o" ]; then g++ $CXXFLAGS -c "$SRC/$f.cpp" -o "$o"; fi
+    BOBJS="$BOBJS $o"
+done
+for f in bond_harmonic bond_fene angle_harmonic; do
+    o=$OUT/obj/$f.o
+    if [ ! -f "$o" ] || [ "$SRC/MOLECULE/$f.cpp" -nt "$o" ]; then g++ $CXXFLAGS -I"$SRC/MOLECULE" -c "$SRC/MOLECULE/$f.cpp" -o "$o"; fi
+    BOBJS="$BOBJS $o"
+done
+g++ $CXXFLAGS -I"$SRC/MOLECULE" -c "$HERE/ref_bonded.cpp" -o "$OUT/obj/ref_bonded.o"
+g++ -o "$OUT/ref_bonded" "$OUT/obj/ref_bonded.o" $BOBJS "$OUT/obj/mpi_stubs.o" -Wl,--unresolved-symbols=ignore-all -lm
+echo "$OUT/ref_bonded"

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 BIN = os.path.join(_HERE, "_ref", "ref_lmp")
+BIN_BONDED = os.path.join(_HERE, "_ref", "ref_bonded")
 REFERENCE = os.environ.get("MESO_REFERENCE", "/root/reference")
 
 
@@ -68,3 +69,32 @@ def run(x, v, lo, hi, *, nsteps, sample, T=1.0, cut=1.0, seed=419084618, coeff=(
                          virial=r[5:11].copy(), nbuild=int(r[11]), x=r[12:12 + 3 * n].reshape(n, 3).copy(),
                          v=r[12 + 3 * n:12 + 6 * n].reshape(n, 3).copy(), f=r[12 + 6 * n:].reshape(n, 3).copy()))
     return recs
+
+
+def bonded(x, bonds=None, bond_coeffs=None, style="harmonic", angles=None, angle_coeffs=None):
+    """The reference's own BondHarmonic / BondFENE / AngleHarmonic::compute (src/MOLECULE, compiled unmodified into
+    oracle/_ref/ref_bonded) on coordinates x (no periodic images: keep the topology away from the boundary).
+    bonds (nb,3: atom, atom, type; 0-based atoms, 1-based types); bond_coeffs [(k, r0)] or [(K, R0, epsilon, sigma)] per type;
+    angles (na,4: atom, apex, atom, type); angle_coeffs [(K, theta0 in degrees)].
+    Returns (f_bond, e_bond, f_angle, e_angle)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(x)
+    bonds = np.zeros((0, 3), np.int32) if bonds is None else np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 3)
+    angles = np.zeros((0, 4), np.int32) if angles is None else np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, 4)
+    bc = np.zeros((len(bond_coeffs or []), 4))
+    for t, c in enumerate(bond_coeffs or []):
+        bc[t, :len(c)] = c
+    ac = np.ascontiguousarray(angle_coeffs if angle_coeffs else np.zeros((0, 2)), dtype=np.float64).reshape(-1, 2)
+    hdr = struct.pack("<6i", n, len(bonds), len(angles), len(bc), len(ac), 0 if style == "harmonic" else 1)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "i.bin"), os.path.join(d, "o.bin")
+        with open(fin, "wb") as f:
+            f.write(hdr)
+            for a in (x, bonds, bc, angles, ac):
+                f.write(a.tobytes())
+        subprocess.run([BIN_BONDED, fin, fout], check=True, timeout=120)
+        raw = np.fromfile(fout, dtype=np.float64)
+    assert raw.size == 2 * (3 * n + 1), raw.size
+    fb, eb = raw[:3 * n].reshape(n, 3).copy(), float(raw[3 * n])
+    fa, ea = raw[3 * n + 1:6 * n + 1].reshape(n, 3).copy(), float(raw[6 * n + 1])
+    return fb, eb, fa, ea

@@ -230,6 +230,43 @@ def test_config2_64cube_against_the_pinned_cpu_restatement(oracle, style, tol_f)
         assert m.temperature() == pytest.approx(s.temperature, rel=1e-6)
 
 
+def test_config1_25cube_fp64_rebuild_every_step(oracle):
+    """configs[1] as written: 25^3 rho=4 (62 500 atoms), pair_style dpd/meso (fp64 arithmetic), neighbour rebuild EVERY step,
+    20 steps, sigma = 0, against the restatement of the reference's stock CPU path that oracle/_ref pins bit for bit
+    (same rebuild cadence on both sides): positions, velocities, forces and temperature after the 20 steps."""
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(25)
+    n = len(x)
+    s = oracle.LmpDpd(x, lo, hi, nthreads=min(8, len(__import__("os").sched_getaffinity(0))))
+    s.pair_style(0.0, 1.0, 419084618)
+    s.pair_coeff(1, 1, 15.0, 4.5)
+    s.set_velocities(v)
+    s.neighbor(0.3, 1, 0)
+    s.timestep(0.005)
+    s.setup()
+    s.run(20)
+    with Meso() as m:
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=1, check=False)
+        m.pair_style("dpd/meso", 1.0, 419084618)
+        m.pair_coeff(1, 1, 15.0, 4.5, 0.0, 1.0, 1.0)
+        m.timestep(0.005)
+        m.setup()
+        m.run(20)
+        assert m.neigh_info()["nbuild"] == 20
+        xg, vg, fg = m.gather()[:3]
+        xs, vs, fs = s.state()
+        d = xg - xs
+        d -= np.round(d / (hi - lo)) * (hi - lo)
+        # fp32 merged coordinates at |x| <= 12.5 (ulp 9.5e-7): the tolerances of the L = 8 comparison scaled by the coordinate range
+        assert np.abs(d).max() < 5e-6 and np.abs(vg - vs).max() < 2e-4
+        assert np.abs(fg - fs).max() < 2e-3 and np.median(np.abs(fg - fs)) < 5e-5
+        assert m.temperature() == pytest.approx(s.temperature, rel=1e-6)
+        assert n == 62500
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("MESO_TEST_SLOW"), reason="24 s for a size no BASELINE config names: MESO_TEST_SLOW=1 runs it")
 def test_256cube_on_one_gpu_beyond_2_25_atoms():
     """67 108 864 atoms (+ 2.4 M ghosts) on ONE MI355X (about 90 GB of its 288 GB): more atoms than the 25-bit index of the
     force kernel's record word can name, so the launcher switches to the wide records (whole 32-bit index, owner lane and
