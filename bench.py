@@ -43,6 +43,8 @@ def parse():
                     help="multi-rank transport: rccl (production) or host (gloo point-to-point through host buffers: lets several "
                          "ranks share one GPU, for rehearsing the multi-process flow on a one-GPU box)")
     ap.add_argument("--special-12", type=float, default=0.0, help="--polymer: special_bonds weight of bonded neighbours (1.0: no exclusions; timing ablation)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="let several RCCL ranks name the same GPU (a probe: RCCL normally refuses it - the refusal is the result)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     return ap.parse_args()
 
@@ -165,7 +167,7 @@ def main():
         x, v, lo, hi = make_box(L)
     n = len(x)
     ndev = max(1, torch.cuda.device_count())
-    if a.transport == "rccl" and world > ndev:
+    if a.transport == "rccl" and world > ndev and not a.shared_gpu:
         raise SystemExit("bench: %d ranks but %d GPU(s) - RCCL needs one GPU per rank (use --transport host to rehearse)" % (world, ndev))
     dev = local_rank % ndev
     m = Meso(dev)
@@ -233,6 +235,7 @@ def main():
     for name in ("pair", "neigh", "nve", "merge", "halo", "reorder", "bin", "total_steps"):
         ms, calls = m.timer(name)
         phases[name] = {"ms_per_call": ms / calls if calls else None, "calls": calls, "ms": ms}
+    xstats = m.xchg_stats() if world > 1 and a.transport == "host" else None
     m.set_option("profile", 0)
     # per launch on one rank; with several ranks the force kernel runs twice per step (bulk, then border range after the
     # ghost refresh): the two launches together cover the rank's atoms once, so they are timed together
@@ -336,6 +339,13 @@ def main():
     }
     if world > 1:
         line["n_ranks_seen"] = m.comm_count()      # ncclCommCount of the engine's communicator
+    if xstats:
+        # rank 0's host-side account of the exchanges during the profiled pass (host transport: a rehearsal of the multi-process
+        # flow, several ranks on one GPU): per kind of exchange the time until the device had the messages ready, the time on the
+        # wire including the wait for the slowest peer, and the copy back - separates exchange waits from kernels
+        line["exchange_us_per_step"] = {k: {"calls": v["calls"], "device": 1e3 * v["ms_device"] / a.profile_steps, "wire_and_peer_wait": 1e3 * v["ms_wire"] / a.profile_steps,
+                                            "back": 1e3 * v["ms_back"] / a.profile_steps, "bytes_per_call": v["bytes"] / max(v["calls"], 1)}
+                                        for k, v in xstats.items()}
     # CPU baseline: timed on rank 0 at N = 1 only; the N > 1 lines of the same box re-use that sample (scratch file)
     cache = os.path.join(ROOT, "gpurun_out", "cpu_baseline_%d_%d.json" % (L, a.every))
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and bonds is None:

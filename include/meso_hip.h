@@ -188,6 +188,11 @@ int meso_membw_probe(meso_ctx *ctx, size_t nbytes, int reps, double *copy_gbs);
  * prints it; empty before the first launch): measurement harnesses key profile-derived numbers on it (the reference keeps
  * one static GridConfig per kernel instead, pair_dpd_meso.cu:216,228) */
 int meso_pair_kernel_name(meso_ctx *ctx, char *buf, int nbuf);
+/* host-side account of the exchanges of the host / in-process transports since meso_timer_reset (option profile 1): one line
+ * per kind of exchange, "what|calls|ms until the device had the messages ready|ms on the wire incl. waiting for the slowest
+ * peer|ms until the received bytes were back on the device|bytes sent" (the reference stamps Timer::COMM around the same calls,
+ * mvv_meso.cu:289,320).  RCCL exchanges are stream-ordered and appear in a kernel trace instead */
+int meso_xchg_stats(meso_ctx *ctx, char *buf, int nbuf);
 
 /* ---- restart files and profiler window.  Inside LAMMPS the restart file is LAMMPS' own (the glue's
  *      Pair::write_restart keeps MesoPairDPD::write_restart's layout, pair_dpd_meso.cu:363-447).  The stand-alone driver

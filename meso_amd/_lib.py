@@ -35,6 +35,7 @@ SIGNATURES = {
     "meso_membw_probe": (_i, [_vp, _sz, _i, C.POINTER(_d)]),
     "meso_pair_kernel_name": (_i, [_vp, C.c_char_p, _i]),
     "meso_tally_ev": (_i, [_vp]),
+    "meso_xchg_stats": (_i, [_vp, C.c_char_p, _i]),
     "meso_comm_set_host_exchange": (_i, [_vp, HOST_EXCHANGE_FN, _vp]),
     "meso_set_mass": (_i, [_vp, _i, _vp]),
     "meso_atoms_upload": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -352,6 +352,17 @@ class Meso:
         self._ck(self.lib.meso_comm_count(self._h, C.byref(n)))
         return n.value
 
+    def xchg_stats(self):
+        """{kind of exchange: dict(calls, ms_device, ms_wire, ms_back, bytes)} of the host / in-process transports (profile on)."""
+        buf = C.create_string_buffer(4096)
+        self._ck(self.lib.meso_xchg_stats(self._h, buf, 4096))
+        out = {}
+        for ln in buf.value.decode().split("\n"):
+            if ln:
+                what, calls, a, b, c, by = ln.split("|")
+                out[what] = dict(calls=int(calls), ms_device=float(a), ms_wire=float(b), ms_back=float(c), bytes=float(by))
+        return out
+
     def pair_kernel_name(self):
         """Instantiation of the force kernel the last launch ran, as rocprofv3 prints it."""
         buf = C.create_string_buffer(160)

@@ -239,6 +239,13 @@ int meso_neigh_info(meso_ctx *ctx, int *n_col, int *max_count, double *avg, int6
 }
 
 int meso_tally_ev(meso_ctx *ctx) { CTX(ctx); RET(E.tally_ev()); }
+
+int meso_xchg_stats(meso_ctx *ctx, char *buf, int nbuf)
+{
+    if (!ctx || !ctx->eng || !buf || nbuf <= 0) return set_err(MESO_ERR_ARG, "null argument");
+    snprintf(buf, (size_t)nbuf, "%s", ctx->eng->xchg_report().c_str());
+    return 0;
+}
 int meso_neigh_download(meso_ctx *ctx, int *count, int *table, int stride)
 {
     CTX(ctx);

@@ -9,6 +9,7 @@
 // Transports: RCCL (ncclSend/ncclRecv grouped), LOCAL (several ranks inside one process, device-to-device
 // copies: how the multi-rank path is exercised on a single GPU), HOST (caller-supplied exchange on host buffers).
 #include "engine.h"
+#include <chrono>
 #include <cstdlib>
 #include "meso_device.h"
 #include <algorithm>
@@ -212,8 +213,26 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
         }
         return 0;
     }
+    // host-side account of an exchange (option profile): time until the device has finished what the messages hold, time on the
+    // "wire" (for the host and in-process transports that includes waiting for the slowest peer), time until the received
+    // bytes are back on the device.  RCCL exchanges are enqueued on the stream and show up in the kernel trace instead.
+    typedef std::chrono::steady_clock clk;
+    const bool acct = profiling && (transport == 2 || transport == 3);
+    clk::time_point t0, t1, t2;
+    if (acct) t0 = clk::now();
+    auto book = [&](clk::time_point a, clk::time_point b, clk::time_point c, clk::time_point d) {
+        XchgStat &st = xchg_stats[xchg_what];
+        st.calls++;
+        st.ms_device += std::chrono::duration<double, std::milli>(b - a).count();
+        st.ms_wire += std::chrono::duration<double, std::milli>(c - b).count();
+        st.ms_back += std::chrono::duration<double, std::milli>(d - c).count();
+        size_t bytes = 0;
+        for (int k = 0; k < np; k++) bytes += sbytes[k];
+        st.bytes += (double)bytes;
+    };
     if (transport == 3) {
         HIPCHK(hipStreamSynchronize(stream));
+        if (acct) t1 = clk::now();
         LocalPost &me = local->post[rank];
         me.npeer = np; me.peer = peer; me.sbuf = sbuf; me.sbytes = sbytes;
         local->barrier();
@@ -234,8 +253,10 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
             if (!from) return fail(5, "local transport: peer did not post a message");
             HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k], hipMemcpyDeviceToDevice, stream));
         }
+        if (acct) t2 = clk::now();
         HIPCHK(hipStreamSynchronize(stream));
         local->barrier();
+        if (acct) book(t0, t1, t2, clk::now());
         return 0;
     }
     if (transport == 2) {
@@ -248,13 +269,29 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
             sp[k] = hs[k].data(); rp[k] = hr[k].data();
         }
         HIPCHK(hipStreamSynchronize(stream));
+        if (acct) t1 = clk::now();
         if (host_exchange(host_exchange_user, np, peer, sp.data(), sbytes, rp.data(), rbytes)) return fail(5, "host exchange failed");
+        if (acct) t2 = clk::now();
         for (int k = 0; k < np; k++)
             if (rbytes[k]) HIPCHK(hipMemcpyAsync(rbuf[k], hr[k].data(), rbytes[k], hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        if (acct) book(t0, t1, t2, clk::now());
         return 0;
     }
     return fail(5, "exchange without a transport");
+}
+
+// "what calls ms_device ms_wire ms_back bytes" per kind of exchange, one per line (meso_xchg_stats)
+std::string Engine::xchg_report() const
+{
+    std::string out;
+    char buf[256];
+    for (const auto &kv : xchg_stats) {
+        snprintf(buf, sizeof buf, "%s|%ld|%.6f|%.6f|%.6f|%.0f\n", kv.first.c_str(), kv.second.calls, kv.second.ms_device, kv.second.ms_wire,
+                 kv.second.ms_back, kv.second.bytes);
+        out += buf;
+    }
+    return out;
 }
 
 double Engine::reduce_global_sum(double v)

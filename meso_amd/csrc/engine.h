@@ -109,6 +109,10 @@ public:
     int sync();
     int resolve_counts();      // counts of the last rebuild that are still on their way to the host (async_counts)
     int comm_count(int *n);
+    // host-side account of the exchanges of the host / in-process transports while option profile is on (comm.hip xchg)
+    struct XchgStat { long calls = 0; double ms_device = 0, ms_wire = 0, ms_back = 0, bytes = 0; };
+    std::map<std::string, XchgStat> xchg_stats;
+    std::string xchg_report() const;
     int membw_probe(size_t nbytes, int reps, double *gbs);
 
     std::string err;
