@@ -207,7 +207,9 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
         // the halo slot -> global index map by binary search - no plan launch, no round trip of the map through HBM
         __shared__ int wtot[4];
         int *hs0 = (int *)rowbuf, *hl0 = hs0 + NHB, *hs1 = hl0 + NHB, *hl1 = hs1 + NHB, *hs2 = hl1 + NHB;   // rows are not staged yet
-        const int B = slot;                  // identity brick list (cell-ordered layout)
+        // 2-bricks: the bricks that own real cells, heaviest first (order2, built by the engine from the geometry): the light
+        // bricks at the faces, edges and corners of the bin grid then form the launch's tail instead of whole bricks
+        const int B = (E == 2 && g.order2) ? g.order2[slot] : slot;
         const size_t e0 = (size_t)CODES * B;
         if (g.estart[e0 + CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + CODES] - g.estart[(size_t)g.M + e0] == 0) return;
         const u32 code0 = (u32)e0;
@@ -601,7 +603,7 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     if (dbg != 99 && g.plan_inline && g.maxh2 > 0 && occupied <= g.brick2_limit && g.M >= 64) {
         // 2x2x2 bricks: eight times as many workgroups of 4 waves
         BrickArgs g2 = g;
-        g2.nactive = g.M / 8;
+        g2.nactive = g.order2 ? g.norder2 : g.M / 8;
         const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
         const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2;
         if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);

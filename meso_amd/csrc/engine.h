@@ -292,6 +292,7 @@ private:
     bool img_ok = false;
     bool images_on() const { return nranks == 1 && img_ok && (ghost_epilogue == 1 || (ghost_epilogue < 0 && nlocal <= 524288)); }
     // one rank: the rebuild in three launches (rebuild.hip) - count, place + gather + ghost emission, ghosts
+    int *brick_order2 = nullptr;    // launch order of the 2-bricks (those that own real cells, fullest first)
     int brick2 = 1;                 // option: 2x2x2 bricks in the list builder (0: the 4x4x4 bricks of rounds 1-2)
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
