@@ -222,7 +222,11 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                 const u32 m = interleave3((u32)qx, (u32)qy, (u32)qz);
                 s0 = g.estart[m]; l0 = g.estart[m + 1] - s0;
                 s1 = g.estart[(size_t)g.M + m]; l1 = g.estart[(size_t)g.M + m + 1] - s1;
-                s2 = g.ghost_base + g.gstart[m]; l2 = g.gstart[m + 1] - g.gstart[m];
+                if (g.gcnt) {
+                    // (fused rebuild: only the tiles of ghost cells were written - start and count of a ghost cell, nothing for others)
+                    const bool ghostcell = qx == 0 || qx == g.mbin[0] - 1 || qy == 0 || qy == g.mbin[1] - 1 || qz == 0 || qz == g.mbin[2] - 1;
+                    if (ghostcell) { s2 = g.ghost_base + g.gstart[m]; l2 = g.gcnt[m]; }
+                } else { s2 = g.ghost_base + g.gstart[m]; l2 = g.gstart[m + 1] - g.gstart[m]; }
             }
             hs0[tid] = s0; hl0[tid] = l0; hs1[tid] = s1; hl1[tid] = l1; hs2[tid] = s2;
             hloc[tid] = l0 + l1;

@@ -308,6 +308,9 @@ private:
     int *fr_novf = nullptr, *fr_ttot[2] = {nullptr, nullptr}, *fr_stot[2] = {nullptr, nullptr};
     int *fr_gttot[2] = {nullptr, nullptr}, *fr_gstot[2] = {nullptr, nullptr};
     unsigned long long *fr_scratch = nullptr;
+    int *fr_gorder = nullptr, *fr_gcnt = nullptr;     // ghost tiles that hold ghost cells; ghosts per cell
+    int fr_ngorder = 0;
+    bool fused_gcnt_valid = false;
     unsigned char *senddir = nullptr;
     int fr_cap = 0, fr_gcap = 0, fr_cap_want = 0, fr_cap_user = 0;
     size_t fr_M = 0;

@@ -83,7 +83,7 @@ void Engine::free_all()
     dfree(pair_count); dfree(pair_table);
     dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(img_cnt); dfree(img); dfree(d_shift27);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
-    dfree(fr_bucket); dfree(fr_ovf); dfree(fr_novf); dfree(fr_scratch); dfree(senddir);
+    dfree(fr_bucket); dfree(fr_ovf); dfree(fr_novf); dfree(fr_scratch); dfree(senddir); dfree(fr_gorder); dfree(fr_gcnt);
     for (int k = 0; k < 2; k++) { dfree(fr_ttot[k]); dfree(fr_stot[k]); dfree(fr_gttot[k]); dfree(fr_gstot[k]); }
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
@@ -972,6 +972,27 @@ int Engine::init_params()
             HIPCHK(dalloc(brick_order2, std::max<size_t>(h.size(), 1)));
             HIPCHK(hipMemcpy(brick_order2, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
             bargs.order2 = brick_order2; bargs.norder2 = (int)h.size();
+            // tiles of the fused rebuild's ghost kernel that hold a ghost cell of the bin grid (a coordinate 0 or mbin - 1)
+            std::vector<int> gt;
+            const int gtile = fused_gtile_codes();
+            for (int t = 0; t < (int)(M / gtile); t++) {
+                bool any = false;
+                for (int k = 0; k < gtile && !any; k++) {
+                    const u32 c = (u32)t * (u32)gtile + (u32)k;
+                    int b[3] = {0, 0, 0};
+                    for (int bit = 0; bit < 10; bit++)
+                        for (int d = 0; d < 3; d++) b[d] |= (int)((c >> (3 * bit + d)) & 1u) << bit;
+                    const bool inside = b[0] < geom.mbin[0] && b[1] < geom.mbin[1] && b[2] < geom.mbin[2];
+                    any = inside && (b[0] == 0 || b[0] == geom.mbin[0] - 1 || b[1] == 0 || b[1] == geom.mbin[1] - 1 || b[2] == 0 || b[2] == geom.mbin[2] - 1);
+                }
+                if (any) gt.push_back(t);
+            }
+            dfree(fr_gorder); dfree(fr_gcnt);
+            HIPCHK(dalloc(fr_gorder, std::max<size_t>(gt.size(), 1)));
+            HIPCHK(hipMemcpy(fr_gorder, gt.data(), gt.size() * sizeof(int), hipMemcpyHostToDevice));
+            fr_ngorder = (int)gt.size();
+            HIPCHK(dalloc(fr_gcnt, M + 1));
+            HIPCHK(hipMemset(fr_gcnt, 0, (M + 1) * sizeof(int)));
         }
         bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / brick_codes());
         bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
@@ -1242,7 +1263,12 @@ int Engine::rebuild_fused()
     fused_locals_args(a);
     const int par = (int)(fr_epoch & 1u);
     a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
-    a.gstot = bargs.M / fused_gtile_codes() > fused_direct_tiles() ? fr_gstot[0] : nullptr;
+    // (the separate-plan option reads gstart by differences: every tile runs then)
+    const bool skip_tiles = tile_plan == 0 && fr_ngorder > 0;
+    a.gorder = skip_tiles ? fr_gorder : nullptr; a.ngorder = fr_ngorder; a.gcnt_out = skip_tiles ? fr_gcnt : nullptr;
+    // few tiles run: each adds up the tile totals in front of it directly (no supertile launch) up to 16 Ki tiles
+    a.gstot = bargs.M / fused_gtile_codes() > (skip_tiles ? 16384 : fused_direct_tiles()) ? fr_gstot[0] : nullptr;
+    fused_gcnt_valid = skip_tiles;
     fr_epoch++;
     a.gstart = gstart;
     a.dir_mask = 0;
@@ -1428,6 +1454,7 @@ int Engine::build_cells_and_table()
                 bargs.plan_inline = (tile_plan == 0 && bargs.active == nullptr && n_col >= 64) ? 1 : 0;
                 if (!bargs.plan_inline) launch_brick_plan(bargs, d_flags, stream);
                 BrickArgs bb = bargs;
+                bb.gcnt = (fused_active && fused_gcnt_valid) ? fr_gcnt : nullptr;
                 if (brick2_off || !brick2) bb.maxh2 = 0;
                 bb.brick2_limit = brick2_limit;
                 launch_tile_build(bb, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,

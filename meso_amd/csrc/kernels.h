@@ -175,6 +175,7 @@ void launch_cell_build(const float4 *coord4, const uint32_t *sorted_key, int key
 struct BrickArgs {
     const int *estart;   // [2M+1] first local index per extended code (border*M + Morton(bin))
     const int *gstart;   // [M+1]  first sorted-ghost slot per Morton(bin)
+    const int *gcnt;     // null, or [M] ghosts per cell: then gstart is valid for ghost cells only (fused rebuild, inline plan)
     int ghost_base;      // == nlocal: ghosts live behind the locals in the merged arrays
     int M;               // Morton codes per section (power of 8)
     int mbin[3];

@@ -535,6 +535,9 @@ struct FusedArgs {
     int *gttot, *gttot_next, *gstot;
     unsigned dir_mask;         // bit d: direction d is a periodic image direction of this rank
     int *gstart;               // out [M+1]
+    int *gcnt_out;             // out, nullable: ghosts per cell [M]; with it only the tiles listed in gorder run
+    const int *gorder;         // [ngorder] tiles (of FR_GTILE ghost cells) that hold at least one ghost cell of the bin grid
+    int ngorder;
     Shift27 sh;
     Center27 ce;
     int *sendlist;             // out: ghost slot -> source atom (new order)

@@ -360,7 +360,9 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
     __shared__ int sdir[FR_GTILE];
     __shared__ int scell[FR_GTILE];                // the source cell's coordinates, 10 bits each
     __shared__ int wsum[FR_THREADS / 64];
-    const int t = blockIdx.x, tid = threadIdx.x;
+    // (gorder: only the tiles that hold ghost cells run - nine tenths of the tiles of a large box are interior; the list builder
+    // then takes a cell's ghosts from (gstart, gcnt) of ghost cells only)
+    const int t = a.gorder ? a.gorder[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const int ntiles = a.M / FR_GTILE;
     const int code0 = t * FR_GTILE;
     int nc = 0;
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
         src0[tid] = first; sdir[tid] = dir; scell[tid] = sb[0] | (sb[1] << 10) | (sb[2] << 20);
     }
     const int base = fr_tile_base(a.gttot, a.gstot, t, wsum);
-    if (t == 0) {
+    if (blockIdx.x == 0) {
         // the rebuild's counts, reported by the tile that starts first: on the device for the kernels that follow, in pinned host
         // memory for the engine (four words: every store to host memory is a trip over the host link)
         int part = 0;
@@ -454,7 +456,10 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
             const int u = __shfl_up(incl, o, 64);
             if (tid >= o) incl += u;
         }
-        if (tid < FR_GTILE) { a.gstart[code0 + tid] = base + incl - c; gl[tid] = incl - c; }
+        if (tid < FR_GTILE) {
+            a.gstart[code0 + tid] = base + incl - c; gl[tid] = incl - c;
+            if (a.gcnt_out) a.gcnt_out[code0 + tid] = c;
+        }
         if (tid == FR_GTILE - 1) gl[FR_GTILE] = incl;
     }
     __syncthreads();
@@ -540,7 +545,7 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
     if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_fr_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
     hipLaunchKernelGGL(k_fr_place, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     if (a.gttot && a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
-    if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(ntg), dim3(FR_THREADS), dyn3, s, a);
+    if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(a.gorder ? a.ngorder : ntg), dim3(FR_THREADS), dyn3, s, a);
     else (void)hipMemsetAsync(a.novf, 0, sizeof(int), s);      // (the ghost kernel clears the overflow count otherwise)
 }
 
