@@ -177,7 +177,13 @@ __device__ inline unsigned long long fr_overflow_member(const unsigned long long
 // ---------------------------------------------------------------------------------------------------------------------------
 // 2: place + gather + ghost emission
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FR_PLACE_THREADS) k_fr_place(FusedArgs a)
+#ifndef FR_PLACE_OCC
+#define FR_PLACE_OCC 8        // waves per SIMD the placing kernel is compiled for: its gather is bound by the bytes in flight per CU
+#endif
+// LISTS: bonded systems - the general gather (topology lists travel too); an instantiation of its own so that its registers do not
+// count against the common path
+template <bool LISTS>
+__global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_fr_place(FusedArgs a)
 {
     extern __shared__ unsigned long long fr_pairs[];      // (sub-cell key << 32) | old index, per pass
     __shared__ int lstart[FR_TILE + 1];
@@ -252,7 +258,7 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS) k_fr_place(FusedArgs a)
         }
         __syncthreads();
         // (whole waves take every trip: the image counting below is a wave-level operation)
-        const bool lists = a.src.bpa > 0 || a.src.apa > 0 || a.src.msp > 0;
+        constexpr bool lists = LISTS;
         for (int p0 = tid; p0 < ((ns + 63) & ~63); p0 += FR_U * FR_PLACE_THREADS) {
             int jj[FR_U], nn[FR_U], cc[FR_U];
             double X[FR_U][3], V[FR_U][3], F[FR_U][3], MS[FR_U];
@@ -542,8 +548,13 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
     const int ntl = 2 * a.M / FR_TILE, ntg = a.M / FR_GTILE;
     if (a.stot) hipLaunchKernelGGL(k_fr_super, dim3((ntl + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.ttot, ntl, a.stot);
     const size_t dyn2 = (size_t)a.lds_cap * 8, dyn3 = (size_t)a.lds_cap;
-    if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_fr_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-    hipLaunchKernelGGL(k_fr_place, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
+    const bool lists = a.src.bpa > 0 || a.src.apa > 0 || a.src.msp > 0;
+    if (dyn2 > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_fr_place<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+        (void)hipFuncSetAttribute((const void *)k_fr_place<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+    }
+    if (lists) hipLaunchKernelGGL(k_fr_place<true>, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
+    else hipLaunchKernelGGL(k_fr_place<false>, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     if (a.gttot && a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
     if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(a.gorder ? a.ngorder : ntg), dim3(FR_THREADS), dyn3, s, a);
     else (void)hipMemsetAsync(a.novf, 0, sizeof(int), s);      // (the ghost kernel clears the overflow count otherwise)

@@ -19,4 +19,4 @@ SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ
 SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
 GRP
-python3 $R/tools/pmc_summary.py $R/gpurun_out/$out pair_dpd tile_build cell_build brick nve merge_xvt permute > $R/gpurun_out/$out.summary.txt
+python3 $R/tools/pmc_summary.py $R/gpurun_out/$out pair_dpd tile_build cell_build brick nve merge_xvt permute k_fr_ > $R/gpurun_out/$out.summary.txt
