@@ -319,12 +319,20 @@ __device__ inline double from_fixed36(u64 a) { return (double)(long long)a * (1.
 // Step boundary of one atom: final_integrate of step s, initial_integrate of step s+1 (fix_nve_meso.cu:62-95,157-178)
 // and, when step s+1 keeps the neighbour table, gpu_merge_xvt for step s+1 (atom_vec_meso.cu:142-167).  One definition
 // for the stand-alone boundary kernel and for the force kernel's epilogue, so both produce the same bits.
-__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz)
+// (pre: the atom's state requested ahead of time by the caller - same values, same arithmetic)
+struct NvePre { double x, y, z, vx, vy, vz, mass; int mask, tag, type; };
+__device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p)
 {
-    double x = a.x[0][i], y = a.x[1][i], z = a.x[2][i];
-    double vx = a.v[0][i], vy = a.v[1][i], vz = a.v[2][i];
-    if (a.mask[i] & a.groupbit) {
-        const double dtfm = a.dtf * rcp_poly(a.mass[i]);
+    p.x = a.x[0][i]; p.y = a.x[1][i]; p.z = a.x[2][i];
+    p.vx = a.v[0][i]; p.vy = a.v[1][i]; p.vz = a.v[2][i];
+    p.mass = a.mass[i]; p.mask = a.mask[i]; p.tag = a.tag[i]; p.type = a.type[i];
+}
+__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre = nullptr)
+{
+    double x = pre ? pre->x : a.x[0][i], y = pre ? pre->y : a.x[1][i], z = pre ? pre->z : a.x[2][i];
+    double vx = pre ? pre->vx : a.v[0][i], vy = pre ? pre->vy : a.v[1][i], vz = pre ? pre->vz : a.v[2][i];
+    if ((pre ? pre->mask : a.mask[i]) & a.groupbit) {
+        const double dtfm = a.dtf * rcp_poly(pre ? pre->mass : a.mass[i]);
         vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // final_integrate, step s
         vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // initial_integrate, step s+1
         x += a.dtv * vx; y += a.dtv * vy; z += a.dtv * vz;
@@ -334,11 +342,11 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
     if (a.merge) {
         float4 c;
         c.x = (float)(x - a.cx); c.y = (float)(y - a.cy); c.z = (float)(z - a.cz);
-        c.w = __uint_as_float((u32)(a.type[i] - 1));
+        c.w = __uint_as_float((u32)((pre ? pre->type : a.type[i]) - 1));
         a.coord4_next[i] = c;
         float4 v;
         v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;
-        v.w = __uint_as_float(signature(a.seed_next, a.tag[i], v.x, v.y, v.z));
+        v.w = __uint_as_float(signature(a.seed_next, pre ? pre->tag : a.tag[i], v.x, v.y, v.z));
         a.veloc4_next[i] = v;
         if (a.img_cnt) {
             // the ghost refresh of step s+1 for my own periodic images (what k_pack_forward computes: same expression, same bits)

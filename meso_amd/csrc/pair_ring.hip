@@ -113,7 +113,19 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (RG_OCC / RG_WAVES > 0 ?
     const bool mine = i < a.end;
     float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
     int n = 0;
-    if (mine) { c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i]; }
+    // the first chunk of the row is requested together with the atom's own data (its address needs the index only; a row past
+    // its count holds stale entries that are never looked at): one memory round trip less at the head of every wave
+    const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);
+    int4 first0 = make_int4(0, 0, 0, 0), first1 = first0;
+    if (mine) {
+        c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i];
+        first0 = rows[(size_t)part * 128]; first1 = rows[(size_t)part * 128 + 1];
+    }
+    // small launches (two or four lanes per atom: every wave's latency chain counts): what the step-boundary epilogue needs is
+    // requested now and waits in registers (16 VGPRs: only the variants with registers to spare)
+    constexpr bool PRE = NPART > 1;
+    NvePre npre;
+    if (PRE && a.fuse_nve && mine && part == 0) nve_prefetch(a.nve, i, npre);
     const int ob = w * APW + slot;                           // my atom's slot in the workgroup's accumulators
     if (part == 0) {
         own_c[slot] = c1;
@@ -221,11 +233,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (RG_OCC / RG_WAVES > 0 ?
         qhead += nb;
     };
 
-    const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);
     // chunk ch of my row: two 16-byte words (lanes past their row: zeros, never used)
     auto ldrow = [&](int ch, int4 &w0, int4 &w1) {
         w0 = make_int4(0, 0, 0, 0); w1 = w0;
-        if (ch < nch) { w0 = rows[(size_t)(ch * NPART + part) * 128]; w1 = rows[(size_t)(ch * NPART + part) * 128 + 1]; }
+        if (ch == 0) { if (nch > 0) { w0 = first0; w1 = first1; } }
+        else if (ch < nch) { w0 = rows[(size_t)(ch * NPART + part) * 128]; w1 = rows[(size_t)(ch * NPART + part) * 128 + 1]; }
     };
     // the entries of one chunk: which of them are looked at, and their coordinate gathers on the way
     auto prep = [&](int ch, const int4 w0, const int4 w1, int (&j)[8], bool (&use)[8], bool (&shb)[8], float4 (&c2)[8]) {
@@ -340,7 +352,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (RG_OCC / RG_WAVES > 0 ?
                     fx += bx; fy += by; fz += bz;
                 }
             }
-            nve_boundary_atom(a.nve, i, fx, fy, fz);
+            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre);
+            else nve_boundary_atom(a.nve, i, fx, fy, fz);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }
