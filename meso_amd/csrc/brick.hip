@@ -211,9 +211,63 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
         // bricks at the faces, edges and corners of the bin grid then form the launch's tail instead of whole bricks
         const int B = (E == 2 && g.order2) ? g.order2[slot] : slot;
         const size_t e0 = (size_t)CODES * B;
-        if (g.estart[e0 + CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + CODES] - g.estart[(size_t)g.M + e0] == 0) return;
+        // (a brick without own atoms leaves; the 2-brick path asks after its bins' loads are on their way - one round trip less)
+        if (E != 2 && g.estart[e0 + CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + CODES] - g.estart[(size_t)g.M + e0] == 0) return;
         const u32 code0 = (u32)e0;
         const int bx0 = (int)compact3(code0), by0 = (int)compact3(code0 >> 1), bz0 = (int)compact3(code0 >> 2);
+        if constexpr (E == 2) {
+            // 2-brick: 64 halo bins, 4 lanes each (256 threads).  Every lane reads its bin's three runs itself (same-address loads
+            // of four lanes), the prefix over the bins is a wave scan of the first lane's total, and the lanes of a bin then
+            // stage its atoms four at a time: no search for the bin of a slot (six dependent LDS reads per staged atom before,
+            // a fifth of the kernel's vector instructions), no run table in LDS.
+            static_assert(E != 2 || TB2_THREADS == 256, "4 lanes per halo bin");
+            const int hbn = tid >> 2, sub = tid & 3;
+            const int qx = bx0 - 1 + (hbn & 3), qy = by0 - 1 + ((hbn >> 2) & 3), qz = bz0 - 1 + (hbn >> 4);
+            int s0 = 0, l0 = 0, s1 = 0, l1 = 0, s2 = 0, l2 = 0;
+            if (qx >= 0 && qx < g.mbin[0] && qy >= 0 && qy < g.mbin[1] && qz >= 0 && qz < g.mbin[2]) {
+                const u32 m = interleave3((u32)qx, (u32)qy, (u32)qz);
+                s0 = g.estart[m]; l0 = g.estart[m + 1] - s0;
+                s1 = g.estart[(size_t)g.M + m]; l1 = g.estart[(size_t)g.M + m + 1] - s1;
+                if (g.gcnt) {
+                    const bool ghostcell = qx == 0 || qx == g.mbin[0] - 1 || qy == 0 || qy == g.mbin[1] - 1 || qz == 0 || qz == g.mbin[2] - 1;
+                    if (ghostcell) { s2 = g.ghost_base + g.gstart[m]; l2 = g.gcnt[m]; }
+                } else { s2 = g.ghost_base + g.gstart[m]; l2 = g.gstart[m + 1] - g.gstart[m]; }
+            }
+            const int nown = g.estart[e0 + CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + CODES] - g.estart[(size_t)g.M + e0];
+            const int tot = l0 + l1 + l2;
+            if (nown == 0) return;
+            int incl = sub == 0 ? tot : 0;
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {            // (the other three lanes of a bin carry zeros: steps 1 and 2 add nothing)
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            // lanes 1..3 of a bin: the inclusive sum of their first lane
+            incl = __shfl(incl, lane & ~3, 64);
+            if (lane == 63) wtot[w] = incl;
+            __syncthreads();
+            int base = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) base += k < w ? wtot[k] : 0;
+            nh = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            const int first = base + incl - tot;
+            if (sub == 0) { hoff[hbn] = first; hloc[hbn] = l0 + l1; }
+            if (tid == 0) hoff[NHB] = nh;
+            if (nh > maxh) {
+                if (tid == 0) atomicMax(overflow, 100000 + (int)(((long)nh * g.maxh + g.maxh2 - 1) / g.maxh2));
+                return;
+            }
+            if (tid == 0 && nh * 4 > maxh * 3) overflow[6] = 1;
+            if (tid == 0 && (long)nh * 27 > (long)g.maxh * 7) atomicMax(overflow + 5, (int)((long)nh * 27 / 8));
+            for (int off = sub; off < tot; off += 4) {
+                const int o1 = off - l0, o2 = o1 - l1;
+                const u32 src = (u32)(o1 < 0 ? s0 + off : o2 < 0 ? s1 + o1 : s2 + o2);
+                const int h = first + off;
+                hgi[h] = src;
+                const float4 c = coord4[src];
+                hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+            }
+        } else {
         int tot = 0;
         if (tid < NHB) {
             const int qx = bx0 - 1 + tid % H, qy = by0 - 1 + (tid / H) % H, qz = bz0 - 1 + tid / (H * H);
@@ -271,6 +325,7 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
             hgi[h] = src;
             const float4 c = coord4[src];
             hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+        }
         }
     } else {
         const int *hdr = g.hdr + (size_t)slot * BRK_HDR_PITCH;

@@ -925,7 +925,7 @@ int Engine::init_params()
                 bargs.maxh2 = ((int)std::ceil((mean2 + 7.0 * std::sqrt(mean2)) * grow) + 63) / 64 * 64;
                 // eight 4-wave workgroups fit a CU whatever they stage up to 20 KB each: the head-room is free (a 4^3-bin
                 // neighbourhood feels a local compression more than a 6^3-bin one does)
-                const int roomy = (20 * 1024 - 4 * 4 * n_col * 2) / 16 / 64 * 64;
+                const int roomy = (20 * 1024 - 1024 - 4 * 4 * n_col * 2) / 16 / 64 * 64;      // (1 KB: the kernel's static LDS)
                 if (bargs.maxh2 < roomy) bargs.maxh2 = roomy;
             }
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
