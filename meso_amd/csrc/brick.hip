@@ -171,6 +171,10 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 #ifndef TB2_THREADS
 #define TB2_THREADS 256      // workgroup of the 2x2x2-brick builder: 4 waves, 2 bins each
 #endif
+#ifndef TB_EXPANDED
+#define TB_EXPANDED 0        // 1: distances in the expanded form on brick-relative coordinates (see the scan); 0: (o - c)^2 on absolute ones
+#endif
+#define TB_ROWPAD 64               // entries behind the last staged row (see the scan step)
 #define TB_ROWCAP_MAX 1024         // rows are staged in LDS at their full capacity n_col (2 bytes per entry)
 
 // E: brick edge in bins.  4: the 4x4x4 brick (64 Morton codes, 6x6x6-bin neighbourhood, 10 waves) of rounds 1-2.  2 (default):
@@ -215,6 +219,9 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
         if (E != 2 && g.estart[e0 + CODES] - g.estart[e0] + g.estart[(size_t)g.M + e0 + CODES] - g.estart[(size_t)g.M + e0] == 0) return;
         const u32 code0 = (u32)e0;
         const int bx0 = (int)compact3(code0), by0 = (int)compact3(code0 >> 1), bz0 = (int)compact3(code0 >> 2);
+        // coordinates are staged relative to the corner of the brick's neighbourhood (see the scan)
+        const float rx = TB_EXPANDED ? g.org[0] + (float)(bx0 - 1) * g.binw[0] : 0.f, ry = TB_EXPANDED ? g.org[1] + (float)(by0 - 1) * g.binw[1] : 0.f,
+                    rz = TB_EXPANDED ? g.org[2] + (float)(bz0 - 1) * g.binw[2] : 0.f;
         if constexpr (E == 2) {
             // 2-brick: 64 halo bins, 4 lanes each (256 threads).  Every lane reads its bin's three runs itself (same-address loads
             // of four lanes), the prefix over the bins is a wave scan of the first lane's total, and the lanes of a bin then
@@ -265,7 +272,7 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                 const int h = first + off;
                 hgi[h] = src;
                 const float4 c = coord4[src];
-                hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+                hx[h] = c.x - rx; hy[h] = c.y - ry; hz[h] = c.z - rz;
             }
         } else {
         int tot = 0;
@@ -324,7 +331,7 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
             else src = (u32)(hs2[lo] + (off - hl1[lo]));
             hgi[h] = src;
             const float4 c = coord4[src];
-            hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+            hx[h] = c.x - rx; hy[h] = c.y - ry; hz[h] = c.z - rz;
         }
         }
     } else {
@@ -333,18 +340,24 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
         if (hdr[2] + hdr[4] == 0) return;
         for (int t = tid; t <= NHB; t += THREADS) hoff[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + t];
         for (int t = tid; t < NHB; t += THREADS) hloc[t] = g.hoff[(size_t)slot * BRK_HOFF_PITCH + BRK_HLOC + t];
+        float4 ref = coord4[g.hmap[(size_t)slot * g.maxh]];          // (any point of the brick serves as the origin)
+        if (!TB_EXPANDED) ref = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int h = tid; h < nh; h += THREADS) {
             const u32 src = g.hmap[(size_t)slot * g.maxh + h];
             hgi[h] = src;
             const float4 c = coord4[src];
-            hx[h] = c.x; hy[h] = c.y; hz[h] = c.z;
+            hx[h] = c.x - ref.x; hy[h] = c.y - ref.y; hz[h] = c.z - ref.z;
         }
     }
     __syncthreads();
-    unsigned short *myrow0 = rowbuf + (size_t)w * TB_G * n_col;
+    unsigned short *myrow0 = rowbuf + (size_t)__builtin_amdgcn_readfirstlane(w) * TB_G * n_col;      // (scalar: row addresses are SALU work)
     auto myrow = [&](int t) { return myrow0 + t * n_col; };
     if (dbg == 1) return;        // timing ablation: staging only
 
+    // Distances in the expanded form |c|^2 - 2 o.c <= rc^2 - |o|^2 on coordinates RELATIVE to the brick's corner (|c| < 8 bin
+    // widths, so the cancellation costs < 1e-4 absolute; rc2 arrives widened by more than that - a list may hold a pair too many
+    // at its outer edge, never one too few, and the force kernel's own test decides): 3 fma + 1 compare per (own atom, batch)
+    // with -2 o and rc^2 - |o|^2 in SGPRs, instead of 3 sub + 3 mul/fma + compare.
     for (int k = w + WAVES * part; k < CODES; k += WAVES * split) {
         const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
                   kz = ((k >> 2) & 1) | (((k >> 5) & 1) << 1);
@@ -353,11 +366,9 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
         const int own0 = __builtin_amdgcn_readfirstlane(hoff[hb]), na = __builtin_amdgcn_readfirstlane(hloc[hb]);
         if (na == 0) continue;
         // the 9 candidate runs of the bin's stencil and their prefix: lanes 0..8 read the two offsets of "their" run in one LDS
-        // round trip, v_readlane moves the 18 values to SGPRs (18 dependent LDS reads + readfirstlane before).  The table lives
-        // only while candidates are loaded - 19 SGPRs that the scan must not pay for with spills (the special-bond variant of
-        // this kernel lost 50 us per build to v_writelane/v_readlane traffic when it stayed alive) - and is rebuilt for the
-        // rare bin with more than 4 batches
-        auto load_cand = [&](int b0, int nb, int *cs, float *cx, float *cy, float *cz) {
+        // round trip, v_readlane moves the 18 values to SGPRs.  The table lives only while candidates are loaded - 19 SGPRs
+        // that the scan must not pay for with spills - and is rebuilt for the rare bin with more than 4 batches
+        auto load_cand = [&](int b0, int nb, int *cs, float *cx, float *cy, float *cz, float *c2) {
             int rstart[9], pre[10];
             pre[0] = 0;
             const int rl = lane < 9 ? lane : 0;
@@ -378,8 +389,9 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                     for (int r = 1; r < 9; r++) base = id >= pre[r] ? rstart[r] - pre[r] : base;
                     const bool valid = id < ncand_;
                     cs[q] = valid ? id + base : 0;
-                    cx[q] = valid ? hx[cs[q]] : 1.0e18f;       // never inside the cutoff
-                    cy[q] = hy[cs[q]]; cz[q] = hz[cs[q]];
+                    cx[q] = hx[cs[q]]; cy[q] = hy[cs[q]]; cz[q] = hz[cs[q]];
+                    c2[q] = valid ? __builtin_fmaf(cx[q], cx[q], __builtin_fmaf(cy[q], cy[q], cz[q] * cz[q])) : 1.0e30f;   // never inside
+                    if (!TB_EXPANDED && !valid) cx[q] = 1.0e18f;
                 }
             }
             return ncand_;
@@ -387,52 +399,56 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
         // candidates of the first 4 batches (256 atoms: the usual stencil holds ~237) stay in registers for all groups
         // of this bin; later batches (denser systems) are reloaded per group
         int cs4[4];
-        float cx4[4], cy4[4], cz4[4];
+        float cx4[4], cy4[4], cz4[4], cq4[4];
 #pragma unroll
-        for (int b = 0; b < 4; b++) { cs4[b] = 0; cx4[b] = 1.0e18f; cy4[b] = cz4[b] = 0.f; }
-        const int ncand = __builtin_amdgcn_readfirstlane(load_cand(0, 4, cs4, cx4, cy4, cz4));
+        for (int b = 0; b < 4; b++) { cs4[b] = 0; cx4[b] = cy4[b] = cz4[b] = 0.f; cq4[b] = 1.0e30f; }
+        const int ncand = __builtin_amdgcn_readfirstlane(load_cand(0, 4, cs4, cx4, cy4, cz4, cq4));
         const int nbatch = (ncand + 63) >> 6;
 
+        float ax_l = 0.f, ay_l = 0.f, az_l = 0.f, th_l = 0.f;
         for (int g0 = 0; g0 < na; g0 += TB_G) {
             const int ng = min(TB_G, na - g0);
-            // own atoms of this group: global index and coordinates, wave-uniform (SGPRs)
-            int gi[TB_G];
-            float ox[TB_G], oy[TB_G], oz[TB_G];
-            {
-                // lanes 0..TB_G-1 read one own atom each (four LDS reads for the whole group), v_readlane moves the values to SGPRs
-                const int tl = own0 + g0 + (lane < ng ? lane : 0);
-                const int gi_l = (int)hgi[tl];
+            if ((g0 & 63) == 0) {
+                // the next 64 own atoms of the bin, one per lane: -2 o and rc^2 - |o|^2, once; a group takes its four by v_readlane
+                const int tl = own0 + g0 + (g0 + lane < na ? lane : 0);
                 const float ox_l = hx[tl], oy_l = hy[tl], oz_l = hz[tl];
+                if (TB_EXPANDED) {
+                    ax_l = -2.f * ox_l; ay_l = -2.f * oy_l; az_l = -2.f * oz_l;
+                    th_l = rc2 - __builtin_fmaf(ox_l, ox_l, __builtin_fmaf(oy_l, oy_l, oz_l * oz_l));
+                } else { ax_l = ox_l; ay_l = oy_l; az_l = oz_l; th_l = rc2; }
+            }
+            float ax[TB_G], ay[TB_G], az[TB_G], th[TB_G];
 #pragma unroll
-                for (int t = 0; t < TB_G; t++) {
-                    gi[t] = 0; ox[t] = oy[t] = oz[t] = 0.f;
-                    if (t < ng) {
-                        gi[t] = __builtin_amdgcn_readlane(gi_l, t);
-                        ox[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox_l), t));
-                        oy[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy_l), t));
-                        oz[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oz_l), t));
-                    }
-                }
+            for (int t = 0; t < TB_G; t++) {
+                const int sl = (g0 & 63) + (t < ng ? t : 0);
+                ax[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax_l), sl));
+                ay[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay_l), sl));
+                az[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az_l), sl));
+                th[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(th_l), sl));
             }
             int nrow[TB_G];
 #pragma unroll
             for (int t = 0; t < TB_G; t++) nrow[t] = 0;
-            // one (own atom, 64-candidate batch) step: distance, lane mask straight from the compares (LLVM predicates: 5 = OLE,
+            // one (own atom, 64-candidate batch) step: 3 fma, lane mask straight from the compares (LLVM predicates: 5 = OLE,
             // 33 = NE), slot of every hit in the atom's LDS row.  No "any hit?" branch: a batch almost always holds one, and
-            // straight-line code lets the chains of the group's atoms overlap.  FULL: all TB_G own atoms present (no branches
-            // at all: 16 independent chains for 4 batches).  Special-bond partners are dropped by k_filter_exclusion afterwards.
-            // (two own atoms per packed fp32 instruction - v_pk_add/mul/fma_f32 with the own coordinates as SGPR pairs - was
-            // measured: 307 -> 312 us; the scan is not bound by the number of distance instructions)
-            auto scan = [&](auto full, const int cs, const float cx, const float cy, const float cz) {
+            // straight-line code lets the chains of the group's atoms overlap.  FULL: all TB_G own atoms present (16 independent
+            // chains for 4 batches).  Special-bond partners are dropped by k_filter_exclusion afterwards.
+            auto scan = [&](auto full, const int cs, const float cx, const float cy, const float cz, const float c2) {
 #pragma unroll
                 for (int t = 0; t < TB_G; t++) {
                     if (decltype(full)::value || t < ng) {
-                        const float dx = ox[t] - cx, dy = oy[t] - cy, dz = oz[t] - cz;
-                        const float d = dx * dx + dy * dy + dz * dz;
-                        const bool hit = (d <= rc2) & (cs != own0 + g0 + t);
-                        const u64 m = __builtin_amdgcn_fcmpf(d, rc2, 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33);
-                        const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)nrow[t]));
-                        if (hit) myrow(t)[min(pos, (u32)(n_col - 1))] = (unsigned short)cs;
+                        float d;
+                        if (TB_EXPANDED) d = __builtin_fmaf(ax[t], cx, __builtin_fmaf(ay[t], cy, __builtin_fmaf(az[t], cz, c2)));
+                        else { const float dx = ax[t] - cx, dy = ay[t] - cy, dz = az[t] - cz; d = dx * dx + dy * dy + dz * dz; }
+                        const u64 m = __builtin_amdgcn_fcmpf(d, th[t], 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33);
+                        const bool hit = (d <= th[t]) & (cs != own0 + g0 + t);
+                        // (row position = entries so far [scalar, SALU work, kept inside the row] + hits in lower lanes [mbcnt x 2,
+                        // shift-add].  The lane part is not clamped - one instruction of eleven per step, 4 % of the kernel: a row
+                        // that overflows writes up to 63 entries into the next row, or into the TB_ROWPAD entries behind the last.
+                        // Every entry written is a valid halo slot, the overflow is reported below and ends the run, as it did.)
+                        const int have = min(nrow[t], n_col - 1);
+                        const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                        if (hit) (myrow(t) + have)[cnt] = (unsigned short)cs;
                         nrow[t] += __popcll(m);
                     }
                 }
@@ -440,35 +456,43 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
             if (nbatch >= 4 && ng == TB_G && dbg != 3) {
                 // the common case (4 full batches, 4 own atoms) without a single branch: 16 independent chains
 #pragma unroll
-                for (int b = 0; b < 4; b++) scan(std::true_type{}, cs4[b], cx4[b], cy4[b], cz4[b]);
+                for (int b = 0; b < 4; b++) scan(std::true_type{}, cs4[b], cx4[b], cy4[b], cz4[b], cq4[b]);
             } else {
 #pragma unroll
                 for (int b = 0; b < 4; b++)
-                    if (b < nbatch && dbg != 3) scan(std::false_type{}, cs4[b], cx4[b], cy4[b], cz4[b]);
+                    if (b < nbatch && dbg != 3) scan(std::false_type{}, cs4[b], cx4[b], cy4[b], cz4[b], cq4[b]);
             }
             for (int b = 4; b < nbatch; b++) {
                 int cs[4];
-                float cx[4], cy[4], cz[4];
-                load_cand(b, 1, cs, cx, cy, cz);
-                scan(std::false_type{}, cs[0], cx[0], cy[0], cz[0]);
+                float cx[4], cy[4], cz[4], cq[4];
+                load_cand(b, 1, cs, cx, cy, cz, cq);
+                scan(std::false_type{}, cs[0], cx[0], cy[0], cz[0], cq[0]);
             }
-            // rows out, lane = entry: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become global
-            // indices, the tail of the last chunk is padded with the atom itself
-#pragma unroll
-            for (int t = 0; t < TB_G; t++) {
-                if (t < ng) {
-                    const int n = nrow[t], i = gi[t];
-                    const int nn = dbg == 2 ? 0 : min(n, n_col);
-                    int *dst = table + row_word8(i, 0, n_col) * 8;
-                    for (int e = lane; e < ((nn + 7) & ~7); e += 64) {
-                        int val = i;
-                        if (e < nn) val = (int)hgi[myrow(t)[e]];
-                        dst[(size_t)(e >> 3) * 512 + (e & 7)] = val;
+            // rows out, 16 lanes per own atom of the group: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become
+            // global indices, the tail of the last chunk is padded with the atom itself
+            {
+                const int t_l = lane >> 4, el = lane & 15;
+                const bool on = t_l < ng;
+                const int n_l = t_l == 0 ? nrow[0] : t_l == 1 ? nrow[1] : t_l == 2 ? nrow[2] : nrow[3];
+                const int i_l = (int)hgi[own0 + g0 + (on ? t_l : 0)];
+                const int nn_l = (dbg == 2 || !on) ? 0 : min(n_l, n_col);
+                const int pad_l = (nn_l + 7) & ~7;
+                // (row_word8(i, 0, n_col) with unsigned factors: one 32 x 32 -> 64 multiply-add)
+                int *dst = table + (((size_t)((u32)i_l >> 6) * (u32)(n_col >> 3)) * 64 + ((u32)i_l & 63u)) * 8 + (el & 7) + (size_t)(el >> 3) * 512;
+                const unsigned short *row_l = myrow0 + t_l * n_col;
+                const int nmax = __builtin_amdgcn_readfirstlane(max(max(nrow[0], nrow[1]), max(nrow[2], nrow[3])));
+                const int padmax = (min(nmax, n_col) + 7) & ~7;
+                for (int e0 = 0; e0 < padmax; e0 += 16) {
+                    const int e = e0 + el;
+                    if (e < pad_l) {
+                        int val = i_l;
+                        if (e < nn_l) val = (int)hgi[row_l[e]];
+                        dst[(size_t)(e0 >> 3) * 512] = val;
                     }
-                    if (lane == 0) {
-                        if (n > n_col) atomicMax(overflow, n);
-                        count[i] = nn;
-                    }
+                }
+                if (on && el == 0) {
+                    if (n_l > n_col) atomicMax(overflow, n_l);
+                    count[i_l] = nn_l;
                 }
             }
         }
@@ -556,7 +580,7 @@ int brick_codes() { return BRK_CODES; }
 int brick_static_maxh() { return BRK_MAXH; }        // capacity of the brick-layout kernels (static LDS arrays)
 int brick_static_maxown() { return BRK_MAXOWN; }
 // largest halo the tile builder can stage: 160 KB of LDS minus its static part (row staging, bin offsets), 16 B per atom
-int tile_build_maxh_limit(int n_col, int) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / 16); }
+int tile_build_maxh_limit(int n_col, int) { return (int)((160 * 1024 - (BRK_WAVES * TB_G * n_col * 2 + TB_ROWPAD * 2 + 2 * (BRK_NHB + 1) * 4 + 1024)) / 16); }
 size_t brick_hoff_pitch() { return BRK_HOFF_PITCH; }
 size_t brick_hdr_pitch() { return BRK_HDR_PITCH; }
 
@@ -655,6 +679,8 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
                        const ExclArgs *excl, int nlocal, int dbg, hipStream_t s)
 {
     if (g.nactive <= 0) return;
+    // (the scan's expanded distance form loses < 1e-4 absolute to cancellation: the list cutoff is widened by more than that)
+    if (TB_EXPANDED) rc2 += 4.0e-4f;
     // few bricks (small boxes, sub-boxes of many ranks): several workgroups share a brick as long as all of them still fit the
     // card in one round (3 workgroups per CU); only the bricks that overlap the bin grid own atoms (measured: 25^3 best with 4
     // workgroups per brick, 32^3 with 2, from 48^3 on with 1)
@@ -664,7 +690,7 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         BrickArgs g2 = g;
         g2.nactive = g.order2 ? g.norder2 : g.M / 8;
         const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
-        const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2;
+        const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2 + TB_ROWPAD * 2;
         if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
         hipLaunchKernelGGL(k_tile_build<2>, tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg);
     } else {
@@ -672,7 +698,7 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     while (split < 4 && occupied * split * 2 <= 900) split *= 2;
     if (dbg >= 100) { split = dbg - 100; dbg = 0; }     // timing experiments: pair_debug 110 + split
     const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
-    const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2;
+    const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2 + TB_ROWPAD * 2;
     if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
     if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipLaunchKernelGGL(k_tile_build<4>, tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg);

@@ -996,7 +996,10 @@ int Engine::init_params()
         }
         bargs.estart = estart; bargs.gstart = gstart; bargs.M = (int)M; bargs.nbricks = (int)(M / brick_codes());
         bargs.hoff = brick_hoff; bargs.hmap = brick_hmap; bargs.hdr = brick_hdr; bargs.own_info = brick_own;
-        for (int d = 0; d < 3; d++) bargs.mbin[d] = geom.mbin[d];
+        for (int d = 0; d < 3; d++) {
+            bargs.mbin[d] = geom.mbin[d];
+            bargs.org[d] = (float)(geom.lo[d] - geom.binsize[d]); bargs.binw[d] = (float)geom.binsize[d];
+        }
     }
     img_ok = true;
     for (int d = 0; d < 3; d++)

@@ -179,6 +179,7 @@ struct BrickArgs {
     int ghost_base;      // == nlocal: ghosts live behind the locals in the merged arrays
     int M;               // Morton codes per section (power of 8)
     int mbin[3];
+    float org[3], binw[3];   // lower corner of bin (0,0,0) and the bin widths (fp32: only the origin of a brick's relative coordinates)
     int nbricks;         // M / 64
     const int *active;   // [nactive] ids of bricks that own atoms; null: identity (every brick, empty ones exit)
     int maxh;            // halo atoms a brick may hold (pitch of hmap, LDS of the tile builder); chosen from the density
