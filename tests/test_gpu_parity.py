@@ -123,6 +123,40 @@ def test_merged_arrays_and_neighbor_sets(Meso, oracle, kernel):
     m.close()
 
 
+@pytest.mark.parametrize("keep", [8, 40])
+def test_neighbor_sets_dilute(Meso, oracle, keep):
+    """Every keep-th atom of the rho = 4 box (rho = 0.5 and 0.1): most bins and many of the nine candidate runs of a bin's
+    stencil are empty - the case the run-start masks of the tile builder have to compact away.  Sets against the oracle's."""
+    from oracle.meso_sim import MesoRefSim
+    L = 9
+    x, v, lo, hi = make_box(L)
+    x, v = x[::keep].copy(), v[::keep].copy()
+    m = Meso()
+    m.read_atoms(x, v, lo, hi)
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=5, check=False)
+    m.pair_style("dpd/meso", 1.0, DP_RUN["seed"])
+    m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    m.timestep(0.005)
+    m.setup()
+    s = MesoRefSim(x, v, lo, hi, every=5)
+    s.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    s.setup()
+    nl = m.counts()[0]
+    c4, v4 = m.merged()
+    tag = m.gather(by_tag=False)[3]
+    count, table = m.neigh_table()
+    assert count.sum() == s.count.sum()
+    ident_dev = np.hstack([c4.view(np.uint32)[:, :3], v4.view(np.uint32)[:, 3:4]])
+    ident_ref = np.hstack([s.c4.view(np.uint32)[:, :3], s.v4.view(np.uint32)[:, 3:4]])
+    ref_of = {tuple(r): i for i, r in enumerate(ident_ref)}
+    for i in range(nl):
+        t = tag[i] - 1
+        assert count[i] == s.count[t]
+        assert sorted(ref_of[tuple(ident_dev[j])] for j in table[i, :count[i]]) == list(s.table[t, :s.count[t]])
+    m.close()
+
+
 @pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-9), ("dpd/fast/meso", 2e-3)])
 def test_forces_vs_meso_oracle(Meso, oracle, style, tol, path):
