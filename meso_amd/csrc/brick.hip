@@ -349,6 +349,9 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
             hx[h] = c.x - ref.x; hy[h] = c.y - ref.y; hz[h] = c.z - ref.z;
         }
     }
+    __shared__ int nextcell;         // (the bin queue of the 2-brick, see the main loop)
+    constexpr bool QUEUE = E == 2;
+    if (QUEUE && tid == 0) nextcell = WAVES;
     __syncthreads();
     unsigned short *myrow0 = rowbuf + (size_t)__builtin_amdgcn_readfirstlane(w) * TB_G * n_col;      // (scalar: row addresses are SALU work)
     auto myrow = [&](int t) { return myrow0 + t * n_col; };
@@ -358,12 +361,26 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
     // widths, so the cancellation costs < 1e-4 absolute; rc2 arrives widened by more than that - a list may hold a pair too many
     // at its outer edge, never one too few, and the force kernel's own test decides): 3 fma + 1 compare per (own atom, batch)
     // with -2 o and rc^2 - |o|^2 in SGPRs, instead of 3 sub + 3 mul/fma + compare.
-    for (int k = w + WAVES * part; k < CODES; k += WAVES * split) {
+    // 2-brick: the waves take the bins from a counter (a wave's first bin is its own number): the atoms per bin vary (9.5 +- 3), the
+    // workgroup's LDS and wave slots are free again only when its slowest wave is done, and a wave with two light bins takes a
+    // third one (32^3: 44 -> 39.5 us per build, 64^3: 180 -> 177).  4-brick: bins dealt out by number, as before.  (The counter is
+    // set before the barrier that ends the staging.)
+    for (int k = QUEUE ? __builtin_amdgcn_readfirstlane(w) : w + WAVES * part; k < CODES; k += QUEUE ? 0 : WAVES * split) {
         const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
                   kz = ((k >> 2) & 1) | (((k >> 5) & 1) << 1);
         const int hb = (kx + 1) + H * ((ky + 1) + H * (kz + 1));
         // wave-uniform values are forced into SGPRs: counters, branches and the own coordinates then stay scalar
         const int own0 = __builtin_amdgcn_readfirstlane(hoff[hb]), na = __builtin_amdgcn_readfirstlane(hloc[hb]);
+        // (the next bin is drawn when this iteration ends, whichever way it ends)
+        struct Next {
+            int &k; int lane; int *q; int kcur;
+            __device__ ~Next() {
+                if (!QUEUE) return;
+                int v = 0;
+                if (lane == 0) v = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                k = __builtin_amdgcn_readfirstlane(v);
+            }
+        } next_{k, lane, &nextcell, k};
         if (na == 0) continue;
         // the 9 candidate runs of the bin's stencil and their prefix: lanes 0..8 read the two offsets of "their" run in one LDS
         // round trip, v_readlane moves the 18 values to SGPRs.  The table lives only while candidates are loaded - 19 SGPRs
