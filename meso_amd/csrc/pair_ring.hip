@@ -47,6 +47,9 @@ namespace meso {
 #ifndef RG_OCC
 #define RG_OCC 20                   // waves per CU the fp32 kernel is compiled for
 #endif
+#ifndef RG_OCC_PARTS
+#define RG_OCC_PARTS 20             // ... the variants with 2 / 4 lanes per atom (small launches: one round of waves; they prefetch the step boundary's inputs)
+#endif
 #ifndef RG_EXEC_GATHER
 #define RG_EXEC_GATHER 0      // measured: lanes switched off for the gather 103 -> 109 us (out-of-range lanes are cheap already)
 #endif
@@ -72,7 +75,7 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 // PLAIN: the noise is the TEA-keyed Gaussian and the conservative force a0 w (dpd/meso, dpd/fast/meso): the wave-uniform
 // switches for dpd/mini, dpd/polyforce and dpd/tableforce (PairArgs::rng / poly / ftab) are compiled out of the hot loop
 template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_, bool PLAIN>
-__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? (RG_OCC / RG_WAVES > 0 ? RG_OCC / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
+__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
 {
 #pragma clang fp contract(fast)
     extern __shared__ double smem[];
