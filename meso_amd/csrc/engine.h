@@ -296,7 +296,8 @@ private:
     int brick2 = 1;                 // option: 2x2x2 bricks in the list builder (0: the 4x4x4 bricks of rounds 1-2)
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
-    bool brick2_off = false;        // a 2-brick neighbourhood neared its LDS stage during this run: 4-bricks from then on
+    bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on
+    int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
     int fused_rebuild = 1;          // option
     bool fused_active = false;      // this rebuild ran the fused path: ghosts sit in slot order, directions in senddir
     bool fused_dirty = false;       // a fused rebuild failed half-way: counters are cleared before the next one

@@ -927,6 +927,7 @@ int Engine::init_params()
                 // neighbourhood feels a local compression more than a 6^3-bin one does)
                 const int roomy = (20 * 1024 - 1024 - 4 * 4 * n_col * 2) / 16 / 64 * 64;      // (1 KB: the kernel's static LDS)
                 if (bargs.maxh2 < roomy) bargs.maxh2 = roomy;
+                if (bargs.maxh2 < brick2_floor) bargs.maxh2 = brick2_floor;      // (grown during the run, see reneighbor)
             }
             // LDS stage of the reorder's ordering pass: the atoms of 128 consecutive extended codes (mean + 6.5 sigma, margin)
             const double m128 = density * 128.0 * binvol * brick_margin * std::max(1.0, (double)brick_maxh_floor / std::max(1.0, mean + 6.5 * std::sqrt(mean)));
@@ -1548,7 +1549,19 @@ int Engine::reneighbor()
     {
         // denser than expected (chains, phase separation): the LDS stage of a brick neighbourhood grows BEFORE it overflows - the
         // high-water mark of the earlier list builds came with the count report (or with the last check_overflow)
-        if (h_flags[6] || h_flags[11]) brick2_off = true;      // (the 2-brick of small boxes neared its stage: 4-bricks from here on)
+        if ((h_flags[6] || h_flags[11]) && !brick2_off) {
+            // a 2-brick neighbourhood passed three quarters of its LDS stage: the stage grows by a quarter (eight workgroups per CU
+            // up to 20 KB, fewer beyond: still ahead of the 4-brick, 176 against 273 us per build at 64^3) as long as five
+            // workgroups fit a CU; only then the 4-brick takes over, whose stage keeps growing on its own
+            const int next = (bargs.maxh2 * 5 / 4 + 63) / 64 * 64;
+            if ((size_t)next * 16 + (size_t)4 * 4 * n_col * 2 + 2048 <= 32 * 1024) {
+                brick2_floor = next;
+                params_ready = false;
+                regrow_only = true;
+            } else brick2_off = true;
+            h_flags[6] = h_flags[11] = 0;
+            HIPCHK(hipMemsetAsync(d_flags + 6, 0, sizeof(int), stream));
+        }
         const int hwm = std::max(h_flags[5], h_flags[10]);
         if (params_ready && neigh_kernel == 1 && (long)hwm * 100 > (long)bargs.maxh * 93) {
             brick_maxh_floor = ((int)(hwm * 1.08) + 63) / 64 * 64;
