@@ -43,6 +43,7 @@ def parse():
                     help="multi-rank transport: rccl (production) or host (gloo point-to-point through host buffers: lets several "
                          "ranks share one GPU, for rehearsing the multi-process flow on a one-GPU box)")
     ap.add_argument("--special-12", type=float, default=0.0, help="--polymer: special_bonds weight of bonded neighbours (1.0: no exclusions; timing ablation)")
+    ap.add_argument("--dump-state", default=None, help="A/B of library builds: save x, v, f of rank 0's atoms (by tag) after the timed region as .npy")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="let several RCCL ranks name the same GPU (a probe: RCCL normally refuses it - the refusal is the result)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
@@ -288,6 +289,10 @@ def main():
     steps_per_s = a.steps / elapsed
 
     T = m.temperature()
+    if a.dump_state:
+        import numpy as np
+        g = m.gather()
+        np.save(a.dump_state, np.hstack([g[0], g[1], g[2]]))
     # the thermostat overshoots to ~1.5 in the first ~100 steps of a cold start and has relaxed to 1 by ~300
     settled = a.warmup + a.steps + a.profile_steps >= 500
     ablation = any(kv.startswith("pair_debug=") and kv != "pair_debug=0" for kv in a.opt)   # timing ablations skip work

@@ -77,7 +77,9 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_, bool PLAIN>
 __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
 {
-#pragma clang fp contract(fast)
+    // (no contraction left to the compiler: the pair evaluation is inlined at every drain point of the light phase, and copies that
+    // fuse different multiply-adds would give one pair two forces that differ in the last bit, depending on which copy - and, for a
+    // pair evaluated from both sides, which side - got it.  The fused operations of the fp32 style are written out below.)
     extern __shared__ double smem[];
     float *cf32 = (float *)smem;
     double *cf64 = smem;
@@ -175,14 +177,14 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                         c_cutinv = UCUT ? (float)a.cf1[P_CUTINV] : cf[4];
                     }
                     const float dx = ci.x - pc2.x, dy = ci.y - pc2.y, dz = ci.z - pc2.z;
-                    const float rsq = dx * dx + dy * dy + dz * dz;
+                    const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     const float rn = PLAIN ? gaussian_tea_fast(__float_as_uint(vi.w), __float_as_uint(pv2.w))
                                            : pair_noise_fast(a.rng, __float_as_uint(vi.w), __float_as_uint(pv2.w));
                     const float rinv = __builtin_amdgcn_rsqf(rsq);
                     const float r = rsq * rinv;
                     const float dvx = vi.x - pv2.x, dvy = vi.y - pv2.y, dvz = vi.z - pv2.z;
-                    const float dot = dx * dvx + dy * dvy + dz * dvz;
-                    const float wc = 1.0f - r * c_cutinv;
+                    const float dot = __builtin_fmaf(dz, dvz, __builtin_fmaf(dy, dvy, dx * dvx));
+                    const float wc = __builtin_fmaf(-r, c_cutinv, 1.0f);
                     float wr = wc;
                     if (!EW1 && c_ew != 1.0f) wr = __builtin_amdgcn_exp2f(c_ew * __builtin_amdgcn_logf(wc));   // powf(wc, s), wc in (0,1)
                     float fcons = c_a0 * wc;
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                         fcons = polyval_f32(wc, a.poly + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * MESO_POLY_PITCH));
                     if (!PLAIN && a.ftab)      // dpd/tableforce/meso (gpu_dpd_tableforce pair_dpd_tableforce_meso.cu:181)
                         fcons = table_force_f32(r * c_cutinv, a.ftab + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * a.ftab_len), a.ftab_len);
-                    float fpair = fcons - (c_gamma * wr * wr * dot * rinv) + (c_sigma * wr * rn * dtis);
+                    float fpair = __builtin_fmaf(c_sigma * wr * rn, dtis, fcons - (c_gamma * wr * wr * dot * rinv));
                     fpair *= rinv;
                     qx = to_fixed(dx * fpair); qy = to_fixed(dy * fpair); qz = to_fixed(dz * fpair);
                 } else {
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
             bool hit;
             if (FAST) {
                 const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
-                const float rsq = dx * dx + dy * dy + dz * dz;
+                const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                 const float cutsq = UCUT ? (float)a.cf1[P_CUTSQ] : cf32[(t1 * a.ntypes + __float_as_uint(c2[q].w)) * 8 + 5];
                 hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & use[q];
             } else {
