@@ -621,8 +621,11 @@ __global__ void __launch_bounds__(64) k_border_hdr(const int *__restrict__ ds, M
     }
 }
 
+// (the record's last int: Morton code of the RECEIVER's ghost cell - this rank's cell of the atom moved by the direction, the grids
+// of two ranks being translates of each other.  The receiver keeps its ghosts in message order and reads the cells' runs off these
+// codes: k_unpack_ghost_runs.)
 __global__ void __launch_bounds__(256) k_pack_border_fixed(AtomSoA a, const int *__restrict__ list, const int *__restrict__ dir_start,
-                                                           MrPlan P, Shift27 sh, const int *__restrict__ d_mr, double *__restrict__ stage_send)
+                                                           MrPlan P, Shift27 sh, const int *__restrict__ d_mr, BinGeom bg, double *__restrict__ stage_send)
 {
     __shared__ int ds[28], dst[27];
     if (threadIdx.x < 28) ds[threadIdx.x] = dir_start[threadIdx.x];
@@ -638,7 +641,14 @@ __global__ void __launch_bounds__(256) k_pack_border_fixed(AtomSoA a, const int 
         o[1] = a.x[1][j] + sh.s[d][1];
         o[2] = a.x[2][j] + sh.s[d][2];
         o[3] = a.v[0][j]; o[4] = a.v[1][j]; o[5] = a.v[2][j];
-        int2 pp = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], 0);
+        const double c[3] = {a.x[0][j], a.x[1][j], a.x[2][j]};
+        const int sd[3] = {d % 3 - 1, (d / 3) % 3 - 1, d / 9 - 1};
+        u32 gq[3];
+        for (int k = 0; k < 3; k++) {
+            const int b = clampi((int)((c[k] - bg.lo[k]) * bg.bininv[k] + 1), 0, bg.mbin[k]);       // (the binning of k_fr_count)
+            gq[k] = (u32)clampi(b - sd[k] * (bg.mbin[k] - 2), 0, bg.mbin[k]);
+        }
+        int2 pp = make_int2(a.tag[j], a.type[j]), r = make_int2(a.mask[j], (int)interleave3(gq[0], gq[1], gq[2]));
         o[6] = *reinterpret_cast<double *>(&pp);
         o[7] = *reinterpret_cast<double *>(&r);
     }
@@ -685,6 +695,57 @@ __global__ void __launch_bounds__(256) k_unpack_border_fixed(AtomSoA a, const do
         double t3 = o[6], t4 = o[7];
         int2 pp = *reinterpret_cast<int2 *>(&t3), r = *reinterpret_cast<int2 *>(&t4);
         a.tag[i] = pp.x; a.type[i] = pp.y; a.mask[i] = r.x;
+    }
+}
+
+// The receiving side of a rebuild in ONE kernel (unpack, ghost binning by count / scan / place / order, merged pairs: 8 launches
+// before): the ghosts stay in message order - the atoms of one source cell are consecutive in a message (the sender's border
+// section is in cell order and the direction lists keep it), and a ghost cell is fed by one source cell of one direction - so a
+// ghost cell is a RUN of consecutive ghosts with one code.  The first atom of a run writes (start, count) of its cell (gcnt
+// cleared before: cells without ghosts stay at 0; a cell that two runs claim is reported, flag 200003); every atom also writes
+// its merged float4 pair (k_merge_ghosts' expressions).  The per-step refresh then scatters without a slot table.
+__global__ void __launch_bounds__(256) k_unpack_ghost_runs(AtomSoA a, const double *__restrict__ stage_recv, MrPlan P, const int *__restrict__ d_mr,
+                                                           int nlocal, double cx, double cy, double cz, u32 seed, float4 *__restrict__ coord4,
+                                                           float4 *__restrict__ veloc4, int *__restrict__ gstart, int *__restrict__ gcnt,
+                                                           int M, int *__restrict__ flags)
+{
+    __shared__ int gb[28];
+    if ((int)threadIdx.x <= P.np) gb[threadIdx.x] = d_mr[MR_GBASE + threadIdx.x];
+    __syncthreads();
+    const int ng = gb[P.np];
+    auto record = [&](int g) {
+        int p = 0;
+        for (int t = 1; t < P.np; t++) p += (g >= gb[t]) ? 1 : 0;
+        return stage_recv + P.base_r[p] + MR_HDR_DOUBLES + BORDER_DOUBLES * (size_t)(g - gb[p]);
+    };
+    auto code_of = [&](int g) { return reinterpret_cast<const int *>(record(g) + 7)[1]; };
+    for (int g = blockDim.x * blockIdx.x + threadIdx.x; g < ng; g += gridDim.x * blockDim.x) {
+        const double *o = record(g);
+        const int i = nlocal + g;
+        const double x = o[0], y = o[1], z = o[2], vx = o[3], vy = o[4], vz = o[5];
+        a.x[0][i] = x; a.x[1][i] = y; a.x[2][i] = z;
+        a.v[0][i] = vx; a.v[1][i] = vy; a.v[2][i] = vz;
+        double t3 = o[6], t4 = o[7];
+        const int2 pp = *reinterpret_cast<int2 *>(&t3), r = *reinterpret_cast<int2 *>(&t4);
+        a.tag[i] = pp.x; a.type[i] = pp.y; a.mask[i] = r.x;
+        float4 c;
+        c.x = (float)(x - cx); c.y = (float)(y - cy); c.z = (float)(z - cz);
+        c.w = __uint_as_float((u32)(pp.y - 1));
+        coord4[g] = c;
+        float4 v;
+        v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;
+        v.w = __uint_as_float(signature(seed, pp.x, v.x, v.y, v.z));
+        veloc4[g] = v;
+        const int code = r.y;
+        if (g == 0 || code_of(g - 1) != code) {
+            int len = 1;
+            while (g + len < ng && code_of(g + len) == code) len++;
+            if ((u32)code >= (u32)M) flags[0] = 200003;
+            else {
+                gstart[code] = g;
+                if (atomicAdd(&gcnt[code], len) != 0) flags[0] = 200003;
+            }
+        }
     }
 }
 
@@ -867,6 +928,7 @@ int Engine::migrate()
 {
     if (nranks == 1) return 0;
     tbegin("migrate");
+    mig_holes = false;
     Decomp D = make_decomp(boxlo, boxhi, prd, procgrid, myloc);
     int *code = gslot;   // scratch (rebuilt later in the rebuild)
     HIPCHK(hipMemsetAsync(d_flags + 3, 0, sizeof(int), stream));
@@ -1078,15 +1140,25 @@ int Engine::migrate_inband()
             else S.src[p] = P.base_r[p] + MIG_HDR_DOUBLES;
         }
         for (int p = np; p < 27; p++) S.gbase[p] = run;
-        // compact the stayers (their order is preserved; the reorder follows anyway), then append the arrivals
-        if (nstay != nlocal) {
+        // The stayers are NOT compacted when the reorder that follows is the counting one (rebuild.hip): its count skips the
+        // leavers by their migration code and walks the arrivals behind the old atoms - no copy of every atom for the few that left
+        // (k_permute_atoms: 131 k atoms x 200 B per rebuild).  Otherwise (sorting reorder; arrays that have to grow first, which
+        // would drop the codes): compact, then append.
+        const bool holes = reorder_fuses((long)nlocal + nrecv_tot) && nlocal + nrecv_tot + 1 <= nmax && nlocal > 0;
+        int base = nstay;
+        if (holes) {
+            mig_holes = true;
+            mig_nold = nlocal;
+            mig_span = nlocal + nrecv_tot;
+            base = nlocal;
+        } else if (nstay != nlocal) {
             launch_permute_atoms(cur, alt, sendlist + ds[13], nstay, 1, stream);
             std::swap(cur, alt);
         }
-        TRY(ensure_capacity(nstay + nrecv_tot + 1));
+        if (!holes) TRY(ensure_capacity(nstay + nrecv_tot + 1));
         if (nrecv_tot > 0)
             hipLaunchKernelGGL(k_unpack_migrate_from, dim3((nrecv_tot + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv,
-                               (const double *)stage2_recv, S, d_mass_type, nstay, ms);
+                               (const double *)stage2_recv, S, d_mass_type, base, ms);
         nlocal = nstay + nrecv_tot;
     }
     if (getenv("MESO_DEBUG_BUILD") && rank == 0 && (again_s || again_r)) fprintf(stderr, "migration: %ld message(s) of rank 0 sent again so far\n", mig_resends);
@@ -1232,7 +1304,7 @@ int Engine::halo_borders_multi_async()
     Shift27 sh;
     for (int d = 0; d < 27; d++) for (int k = 0; k < 3; k++) sh.s[d][k] = shift27[3 * d + k];
     if (bound_s > 0)
-        hipLaunchKernelGGL(k_pack_border_fixed, dim3((bound_s + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start, P, sh, d_mr,
+        hipLaunchKernelGGL(k_pack_border_fixed, dim3((bound_s + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start, P, sh, d_mr, geom,
                            (double *)stage_send);
     std::vector<void *> sb(np), rb(np);
     std::vector<size_t> sn(np), rn(np);
@@ -1244,7 +1316,26 @@ int Engine::halo_borders_multi_async()
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
     hipLaunchKernelGGL(k_border_unpack_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, nmax - nlocal - 1, d_mr, d_flags,
                        h_flags_dev + 64);
-    if (bound_r > 0)
+    // ghosts in message order, their cells as runs (one kernel instead of unpack + count + scan + place + order + merge) when the
+    // list builder reads (start, count) per ghost cell: the tile builder with the plan in its prologue, bins no narrower than the
+    // ghost cutoff (a ghost cell is then fed by one source cell)
+    bool runs = border_runs && neigh_kernel == 1 && tile_fits && n_col <= tile_build_rowcap() && tile_plan == 0 && n_col >= 64;
+    for (int d = 0; d < 3; d++) runs = runs && geom.binsize[d] >= cutghost;
+    if (runs) {
+        if (mr_gcnt_n < bargs.M + 1) {
+            if (mr_gcnt) (void)hipFree(mr_gcnt);
+            mr_gcnt = nullptr;
+            mr_gcnt_n = bargs.M + 1;
+            HIPCHK(hipMalloc((void **)&mr_gcnt, (size_t)mr_gcnt_n * sizeof(int)));
+        }
+        HIPCHK(hipMemsetAsync(mr_gcnt, 0, (size_t)(bargs.M + 1) * sizeof(int), stream));
+        if (bound_r > 0)
+            hipLaunchKernelGGL(k_unpack_ghost_runs, dim3((bound_r + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv, P, d_mr, nlocal,
+                               0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
+                               premix_tea<64>((u32)seed, (u32)ntimestep), coord4 + nlocal, veloc4 + nlocal, gstart, mr_gcnt, bargs.M, d_flags);
+        mr_runs = true;
+        ghosts_binned = true;
+    } else if (bound_r > 0)
         hipLaunchKernelGGL(k_unpack_border_fixed, dim3((bound_r + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv, P, d_mr,
                            nlocal);
     // the report (flag, bulk count, direction starts: k_border_scan; per-peer counts: the two header kernels) is in pinned memory
@@ -1329,7 +1420,7 @@ int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
         P.np = np;
         for (int p = 0; p <= np; p++) P.gbase[p] = peer_recv_base[p];
         hipLaunchKernelGGL(k_scatter_ghost, dim3((nghost + 255) / 256), dim3(256), 0, side, (const float4 *)stage_recv, P,
-                           layout >= 1 ? gslot : nullptr, nghost, coord4 + nlocal, veloc4 + nlocal);
+                           (layout >= 1 && !mr_runs) ? gslot : nullptr, nghost, coord4 + nlocal, veloc4 + nlocal);
     }
     HIPCHK(hipEventRecord(ev_halo, side));
     if (!async) HIPCHK(hipStreamWaitEvent(stream, ev_halo, 0));
@@ -1342,7 +1433,7 @@ int Engine::merge_new_ghosts(uint32_t sd)
 {
     if (nghost <= 0) return 0;
     tbegin("halo");
-    hipLaunchKernelGGL(k_merge_ghosts, dim3((nghost + 255) / 256), dim3(256), 0, stream, cur, nlocal, nghost, pending_nghost_dev(), layout >= 1 ? gslot : nullptr,
+    hipLaunchKernelGGL(k_merge_ghosts, dim3((nghost + 255) / 256), dim3(256), 0, stream, cur, nlocal, nghost, pending_nghost_dev(), (layout >= 1 && !mr_runs) ? gslot : nullptr,
                        0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), sd, coord4 + nlocal, veloc4 + nlocal);
     tend("halo");
     return 0;

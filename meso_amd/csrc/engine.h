@@ -297,6 +297,13 @@ private:
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on
+    bool mig_holes = false;         // several ranks: the migration left its leavers in place (holes) and appended the arrivals behind the
+    int mig_span = 0, mig_nold = 0; // old atoms: the reorder's count walks mig_span atoms and skips the leavers among the first mig_nold
+    bool reorder_fuses(long n) const;
+    int border_runs = 1;            // option: several ranks keep a rebuild's ghosts in message order and read the ghost cells as runs (comm.hip)
+    bool mr_runs = false;           // ... this rebuild did
+    int *mr_gcnt = nullptr;         // [M+1] ghosts per ghost cell of that form (gstart holds the starts)
+    int mr_gcnt_n = 0;
     int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
     int fused_rebuild = 1;          // option
     bool fused_active = false;      // this rebuild ran the fused path: ghosts sit in slot order, directions in senddir

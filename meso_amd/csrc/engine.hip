@@ -87,7 +87,7 @@ void Engine::free_all()
     for (int k = 0; k < 2; k++) { dfree(fr_ttot[k]); dfree(fr_stot[k]); dfree(fr_gttot[k]); dfree(fr_gstot[k]); }
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
-    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot);
+    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(mr_gcnt);
     dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own); dfree(brick_order2);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
@@ -336,6 +336,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
     if (key == "tile_plan") { tile_plan = (int)val; return 0; }
+    if (key == "border_runs") { border_runs = (int)val; return 0; }      // several ranks: ghosts in message order, cells as runs (0: unpack + binning chain)
     if (key == "reorder_cap") { reorder_cap_user = (int)val; return 0; }      // tests: force the ordering pass off its LDS stage
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }
     if (key == "async_counts") { async_counts = (int)val; return 0; }
@@ -599,7 +600,7 @@ int Engine::rebuild_topology()
 {
     if (!have_bonds) return 0;
     const int *ng_dev = pending_nghost_dev();     // nghost is a launch bound while the counts travel
-    launch_tag_cell(cur.tag, fused_active ? nullptr : gslot, nlocal, nghost, ng_dev, tagc, stream);
+    launch_tag_cell(cur.tag, (fused_active || mr_runs) ? nullptr : gslot, nlocal, nghost, ng_dev, tagc, stream);
     HIPCHK(hipMemsetAsync(tagmap, 0x7f, ((size_t)maxtag + 2) * sizeof(int), stream));
     launch_set_map(tagc, nlocal, nghost, ng_dev, maxtag, tagbits, tagmap, stream);
     // (d_flags[4] counts partners that are neither local nor ghost; it stays set until check_overflow reports it)
@@ -1048,10 +1049,14 @@ void Engine::range(int r, int &beg, int &end) const
 // ------------------------------------------------------------------------------------------------
 
 // MesoAtom::sort_local (atom_meso.cu:343-384) + transfer_post_sort, all device resident
+// the locals' reorder as count + place/gather of the fused rebuild (n: atoms the count walks)
+bool Engine::reorder_fuses(long n) const { return !reorder_sort && fused_rebuild && neigh_kernel == 1 && n < (1L << 27); }
+
 int Engine::reorder_locals()
 {
     merged_in_reorder = false;
     if (nlocal == 0) {
+        mig_holes = false;
         n_bulk = 0;
         launch_estart(rkey, 0, reorder_sub_bits(geom), 2 * bargs.M, estart, stream);   // an empty rank: all zero
         return 0;
@@ -1062,7 +1067,7 @@ int Engine::reorder_locals()
     if (!reorder_sort) {
         // counting per extended code instead of a comparison sort (kernels.hip): ~8 launches instead of ~28; estart - first
         // index of every extended code ([border][Morton(bin)]), the border section starts at estart[M] = n_bulk - is the scan
-        if (fused_rebuild && neigh_kernel == 1 && (long)nlocal < (1L << 27)) {
+        if (reorder_fuses(mig_holes ? mig_span : nlocal)) {
             // count + place/gather (rebuild.hip, the locals' half of the fused rebuild): two launches for count, scan x2, place,
             // order and gather; estart and the merged pairs come with it (several ranks, and the first rebuild of one rank)
             TRY(fused_alloc());
@@ -1070,6 +1075,7 @@ int Engine::reorder_locals()
             fused_locals_args(a);
             fr_epoch++;
             launch_fused_rebuild(a, stream);
+            mig_holes = false;
             if (!async_ok()) HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
             gathered = true;
         } else {
@@ -1227,7 +1233,8 @@ void Engine::fused_locals_args(FusedArgs &a)
 {
     memset(&a, 0, sizeof a);
     a.src = cur; a.dst = alt;
-    a.n = nlocal;
+    a.n = mig_holes ? mig_span : nlocal;
+    a.skip = mig_holes ? gslot : nullptr; a.skip_n = mig_nold;      // (gslot: the migration's code array, see migrate)
     a.with_f = permute_forces ? 1 : 0;
     a.wrap = wrap_in_reorder ? 1 : 0;
     for (int d = 0; d < 3; d++) {
@@ -1441,7 +1448,7 @@ int Engine::build_cells_and_table()
         {
             // (several ranks: the border message carried the velocities, the ghosts' merged pairs are built locally)
             // (fused rebuild: the ghosts' merged pairs and the image table were written with the ghosts)
-            const int rc_fwd = fused_active ? 0 : (nranks > 1 ? merge_new_ghosts(sd_now) : halo_forward_seed(sd_now));
+            const int rc_fwd = (fused_active || mr_runs) ? 0 : (nranks > 1 ? merge_new_ghosts(sd_now) : halo_forward_seed(sd_now));
             if (fused_active && images_on()) images_ready = true;
             build_images_now = false;
             if (rc_fwd) return rc_fwd;
@@ -1458,7 +1465,7 @@ int Engine::build_cells_and_table()
                 bargs.plan_inline = (tile_plan == 0 && bargs.active == nullptr && n_col >= 64) ? 1 : 0;
                 if (!bargs.plan_inline) launch_brick_plan(bargs, d_flags, stream);
                 BrickArgs bb = bargs;
-                bb.gcnt = (fused_active && fused_gcnt_valid) ? fr_gcnt : nullptr;
+                bb.gcnt = (fused_active && fused_gcnt_valid) ? fr_gcnt : (mr_runs ? mr_gcnt : nullptr);
                 if (brick2_off || !brick2) bb.maxh2 = 0;
                 bb.brick2_limit = brick2_limit;
                 launch_tile_build(bb, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,
@@ -1578,6 +1585,7 @@ int Engine::reneighbor()
     TRY(migrate());
     ghosts_binned = false;
     fused_active = false;
+    mr_runs = false;
     if (fused_ok()) {
         TRY(rebuild_fused());
     } else if (async_ok() && overlap_rebuild && nlocal > 0) {

@@ -95,7 +95,7 @@ __device__ inline int fr_block_sum(int v, int *wsum)
 __global__ void __launch_bounds__(256) k_fr_count(FusedArgs a)
 {
     const int i = blockDim.x * blockIdx.x + threadIdx.x;
-    const bool valid = i < a.n;
+    const bool valid = i < a.n && !(a.skip && i < a.skip_n && a.skip[i] != 13);
     u32 e = 0, key = 0;
     if (valid) {
         double c[3] = {a.src.x[0][i], a.src.x[1][i], a.src.x[2][i]};

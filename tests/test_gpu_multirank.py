@@ -172,6 +172,12 @@ def test_borders_without_host_round_trip_equal_the_synchronous_path(every):
     for k in range(3):
         assert np.array_equal(a[1][k], c[1][k])
     assert a[2] == c[2]
+    # the receiving side in one kernel (ghosts stay in message order, the list builder reads the ghost cells as runs of equal cell
+    # codes the sender wrote: default) against the unpack + count + scan + place + order + merge chain (border_runs 0)
+    d = _run_ranks(8, (2, 2, 2), 12, "dpd/fast/meso", 3.0, 23, every=every, opts=(("border_runs", 0),))
+    for k in range(3):
+        assert np.array_equal(a[1][k], d[1][k])
+    assert a[2] == d[2]
 
 
 def test_border_message_capacity_is_checked():
