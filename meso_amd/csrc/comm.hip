@@ -500,10 +500,89 @@ __global__ void __launch_bounds__(256) k_pack_migrate_fixed(AtomSoA a, const int
     }
 }
 
+// ---- the migration's sending side in two launches (code, count, scan x 2, direction starts, fill, header, pack: 8 before) ----
+// Few atoms leave (a few hundred of 131 k per rebuild): the kernel that finds them appends them to their direction's list with an
+// atomic, and the packing kernel restores the order of the counting chain by ranking every leaver among its direction's list
+// (index order), so messages - and with them the arrival order on the peer - are what they were, run after run.  A list holds
+// lc entries; a direction that overflows it belongs to a message that overflows its capacity (lc >= every capacity) and is sent
+// again exactly, from the lists of the counting chain, which are then built on demand (build_mig_lists).
+__global__ void __launch_bounds__(256) k_mig_scan(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                  Decomp D, int n, int *__restrict__ code, int *__restrict__ lost, int *__restrict__ cnt,
+                                                  int *__restrict__ lst, int lc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double c[3] = {x[i], y[i], z[i]};
+    int s[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        int o = owner_loc(D, d, c[d]);
+        int t = o - D.myloc[d];
+        if (t > 1) t -= D.pg[d];
+        if (t < -1) t += D.pg[d];
+        if (t > 1 || t < -1) { atomicAdd(lost, 1); t = 0; }
+        s[d] = t;
+    }
+    const int cd = (s[0] + 1) + 3 * (s[1] + 1) + 9 * (s[2] + 1);
+    code[i] = cd;
+    if (cd != 13) {
+        const int pos = atomicAdd(&cnt[cd], 1);
+        if (pos < lc) lst[(size_t)cd * lc + pos] = i;
+    }
+}
+
+// grid (blocks, 27): direction blockIdx.y.  Block (0, 0) also writes the peers' headers, the direction slots (dst_dev) and the
+// direction starts the host reads after the exchange (the segment of direction 13 = the atoms that stay)
+__global__ void __launch_bounds__(256) k_mig_pack(AtomSoA a, const int *__restrict__ cnt_dev, const int *__restrict__ lst, int lc, int n,
+                                                  MigPlan P, int *__restrict__ dst_dev, int *__restrict__ dir_start, int ms,
+                                                  double *__restrict__ stage_send)
+{
+    __shared__ int cnt[27], dst[27];
+    const int t = threadIdx.x;
+    if (t < 27) cnt[t] = t == 13 ? 0 : cnt_dev[t];
+    __syncthreads();
+    if (t < P.np) {
+        int fill = 0;
+        int *hdr = reinterpret_cast<int *>(stage_send + P.base_s[t]);
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int d = 0; d < 27; d++) {
+            const bool mine = P.pidx[d] == t;
+            if (first) hdr[d] = mine ? cnt[d] : 0;
+            if (mine) { dst[d] = fill; fill += cnt[d]; }
+        }
+    }
+    if (t < 27 && P.pidx[t] < 0) dst[t] = 0;
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (t < 27) dst_dev[t] = dst[t];
+        if (t == 0) {
+            int leave = 0;
+            for (int d = 0; d < 27; d++) leave += cnt[d];
+            int run = 0;
+            for (int d = 0; d < 27; d++) { dir_start[d] = run; run += d == 13 ? n - leave : cnt[d]; }
+            dir_start[27] = run;
+        }
+    }
+    const int d = blockIdx.y, p = P.pidx[d];
+    if (d == 13 || p < 0) return;
+    const int m = min(cnt[d], lc);
+    const int *l = lst + (size_t)d * lc;
+    for (int k = blockDim.x * blockIdx.x + t; k < m; k += gridDim.x * blockDim.x) {
+        const int i = l[k];
+        int rank = 0;
+        for (int e = 0; e < m; e++) rank += l[e] < i ? 1 : 0;
+        const int q = dst[d] + rank;
+        if (q >= P.cap_s[p]) continue;                      // (the whole message follows in the second exchange)
+        pack_migrant(a, i, ms, stage_send + P.base_s[p] + MIG_HDR_DOUBLES + (size_t)ms * q);
+    }
+}
+
 // what each peer announces in its header: report[t] = migrants from peer t (also beyond the capacity)
-__global__ void __launch_bounds__(64) k_mig_read_hdr(const double *__restrict__ stage_recv, MigPlan P, int *__restrict__ report)
+// (clear: the leavers' counters of k_mig_scan, for the next rebuild)
+__global__ void __launch_bounds__(64) k_mig_read_hdr(const double *__restrict__ stage_recv, MigPlan P, int *__restrict__ report, int *__restrict__ clear)
 {
     const int t = threadIdx.x;
+    if (clear && t < 27) clear[t] = 0;
     if (t < P.np) {
         const int *hdr = reinterpret_cast<const int *>(stage_recv + P.base_r[t]);
         int n = 0;
@@ -933,6 +1012,13 @@ int Engine::migrate()
     int *code = gslot;   // scratch (rebuilt later in the rebuild)
     HIPCHK(hipMemsetAsync(d_flags + 3, 0, sizeof(int), stream));
     int nchunk = (nlocal + 255) / 256;
+    mig_lists_built = false;
+    if (async_counts && mig_caps_ready && mig_slim) {
+        // (leavers' lists by atomics, ranked when packed: migrate_inband)
+        int rc = migrate_inband();
+        tend("migrate");
+        return rc;
+    }
     if (nlocal > 0) {
         hipLaunchKernelGGL(k_migrate_code, dim3(nchunk), dim3(256), 0, stream, cur.x[0], cur.x[1], cur.x[2], D, nlocal, code,
                            d_flags + 3);
@@ -943,6 +1029,7 @@ int Engine::migrate()
     } else {
         HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
     }
+    mig_lists_built = true;
     if (async_counts && mig_caps_ready) { int rc = migrate_inband(); tend("migrate"); return rc; }
     // one host round trip: the "lost atoms" flag, my direction starts and the counts the peers announce arrive together
     HIPCHK(hipMemcpyAsync(h_flags + 3, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1016,6 +1103,21 @@ void Engine::mig_update_caps(const std::vector<int> &send_n, const std::vector<i
 // counts, and an exact resend in a second exchange for the (rare) message that did not fit - zero-size messages are not posted, so
 // that exchange costs nothing when nobody needs it, and the two ranks of a message decide alike (the sender knows its count, the
 // receiver reads it in the header).  Called with the migration lists built (sendlist, d_dir_start).
+// the direction-major list of every local atom (sendlist, d_dir_start) from the migration codes: the counting chain, on demand
+// when the slim front of the in-band migration ran (a message to send again exactly; stayers to compact for a sorting reorder)
+int Engine::build_mig_lists()
+{
+    if (mig_lists_built) return 0;
+    mig_lists_built = true;
+    const int nchunk = (nlocal + 255) / 256;
+    if (nlocal <= 0) return 0;
+    launch_border_count_code(gslot, 0, nlocal, chunk_count, nchunk, stream);
+    HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
+    launch_dir_starts(chunk_offset, nchunk, d_dir_start, stream);
+    launch_border_fill_code(gslot, 0, nlocal, chunk_offset, nchunk, sendlist, stream);
+    return 0;
+}
+
 int Engine::migrate_inband()
 {
     const int np = (int)peers.size();
@@ -1036,10 +1138,30 @@ int Engine::migrate_inband()
     if (!d_mr) { HIPCHK(hipMalloc((void **)&d_mr, 128 * sizeof(int))); HIPCHK(hipMemsetAsync(d_mr, 0, 128 * sizeof(int), stream)); }
     if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
     int *dst_dev = d_mr + 96;           // [96..122]: slot of each direction's segment inside its peer's payload
+    if (!mig_lists_built) {
+        // the slim front: k_mig_scan + k_mig_pack
+        int lc = 64;
+        for (int p = 0; p < np; p++) lc = std::max(lc, mig_cap_s[p]);
+        if (mig_lst_n < 27 * lc) {
+            if (mig_lst) (void)hipFree(mig_lst);
+            mig_lst = nullptr;
+            mig_lst_n = 27 * lc * 2;
+            HIPCHK(hipMalloc((void **)&mig_lst, (size_t)mig_lst_n * sizeof(int)));
+        }
+        if (!mig_cnt) { HIPCHK(hipMalloc((void **)&mig_cnt, 32 * sizeof(int))); HIPCHK(hipMemsetAsync(mig_cnt, 0, 32 * sizeof(int), stream)); }
+        if (nlocal > 0) {
+            Decomp D = make_decomp(boxlo, boxhi, prd, procgrid, myloc);
+            hipLaunchKernelGGL(k_mig_scan, dim3((nlocal + 255) / 256), dim3(256), 0, stream, cur.x[0], cur.x[1], cur.x[2], D, nlocal, gslot, d_flags + 3,
+                               mig_cnt, mig_lst, lc);
+        }
+        hipLaunchKernelGGL(k_mig_pack, dim3(std::max(1, std::min(8, (lc + 255) / 256)), 27), dim3(256), 0, stream, cur, mig_cnt, mig_lst, lc, nlocal, P,
+                           dst_dev, d_dir_start, ms, (double *)stage_send);
+    } else {
     hipLaunchKernelGGL(k_mig_hdr, dim3(1), dim3(64), 0, stream, d_dir_start, P, dst_dev, (double *)stage_send);
     if (nlocal > 0)
         hipLaunchKernelGGL(k_pack_migrate_fixed, dim3(std::max(1, std::min((nlocal + 255) / 256, (bound_s + 255) / 256))), dim3(256), 0, stream,
                            cur, sendlist, d_dir_start, P, dst_dev, ms, (double *)stage_send);
+    }
     std::vector<void *> sb(np), rb(np);
     std::vector<size_t> sn(np), rn(np);
     for (int p = 0; p < np; p++) {
@@ -1049,7 +1171,8 @@ int Engine::migrate_inband()
     xchg_what = "migration (fixed capacity)";
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
     // the one host round trip: lost-atom flag, my direction starts, the counts in the peers' headers
-    hipLaunchKernelGGL(k_mig_read_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, h_flags_dev + 128);      // (slots of its own)
+    hipLaunchKernelGGL(k_mig_read_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, h_flags_dev + 128,      // (slots of its own)
+                       mig_lists_built ? nullptr : mig_cnt);
     HIPCHK(hipMemcpyAsync(h_flags + 3, d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(h_flags + 16, d_dir_start, 28 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -1101,6 +1224,7 @@ int Engine::migrate_inband()
             }
         }
         if (again_s) {
+            TRY(build_mig_lists());
             // exact pack of the directions whose peer needs the resend (k_pack_migrate over the whole list, others go nowhere)
             std::vector<int> fill(sbase);
             int h_dst[27];
@@ -1152,6 +1276,7 @@ int Engine::migrate_inband()
             mig_span = nlocal + nrecv_tot;
             base = nlocal;
         } else if (nstay != nlocal) {
+            TRY(build_mig_lists());
             launch_permute_atoms(cur, alt, sendlist + ds[13], nstay, 1, stream);
             std::swap(cur, alt);
         }

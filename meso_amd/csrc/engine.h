@@ -297,6 +297,11 @@ private:
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on
+    int mig_slim = 1;               // option: leavers' lists by atomics + ranking (2 launches) instead of the counting chain (8)
+    bool mig_lists_built = false;   // this rebuild's direction-major list of all atoms exists (sendlist, d_dir_start)
+    int *mig_cnt = nullptr, *mig_lst = nullptr;
+    int mig_lst_n = 0;
+    int build_mig_lists();
     bool mig_holes = false;         // several ranks: the migration left its leavers in place (holes) and appended the arrivals behind the
     int mig_span = 0, mig_nold = 0; // old atoms: the reorder's count walks mig_span atoms and skips the leavers among the first mig_nold
     bool reorder_fuses(long n) const;

@@ -87,7 +87,7 @@ void Engine::free_all()
     for (int k = 0; k < 2; k++) { dfree(fr_ttot[k]); dfree(fr_stot[k]); dfree(fr_gttot[k]); dfree(fr_gstot[k]); }
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
-    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(mr_gcnt);
+    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(mr_gcnt); dfree(mig_cnt); dfree(mig_lst);
     dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own); dfree(brick_order2);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
@@ -336,6 +336,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
     if (key == "tile_plan") { tile_plan = (int)val; return 0; }
+    if (key == "mig_slim") { mig_slim = (int)val; return 0; }
     if (key == "border_runs") { border_runs = (int)val; return 0; }      // several ranks: ghosts in message order, cells as runs (0: unpack + binning chain)
     if (key == "reorder_cap") { reorder_cap_user = (int)val; return 0; }      // tests: force the ordering pass off its LDS stage
     if (key == "pair_npart") { pair_npart = (int)val; return 0; }

@@ -178,6 +178,12 @@ def test_borders_without_host_round_trip_equal_the_synchronous_path(every):
     for k in range(3):
         assert np.array_equal(a[1][k], d[1][k])
     assert a[2] == d[2]
+    # the migration's sending side in two launches (leavers appended to their direction's list by atomics, ranked when packed:
+    # default) against the count / scan / fill chain (mig_slim 0): the same messages in the same order
+    e = _run_ranks(8, (2, 2, 2), 12, "dpd/fast/meso", 3.0, 23, every=every, opts=(("mig_slim", 0),))
+    for k in range(3):
+        assert np.array_equal(a[1][k], e[1][k])
+    assert a[2] == e[2]
 
 
 def test_border_message_capacity_is_checked():
