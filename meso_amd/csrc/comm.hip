@@ -733,6 +733,82 @@ __global__ void __launch_bounds__(256) k_pack_border_fixed(AtomSoA a, const int 
     }
 }
 
+// border lists, message headers and the packed records in ONE launch behind count + scan (k_border_fill, k_border_hdr and
+// k_pack_border_fixed were three): every block works out the direction slots from the direction starts (27 additions per peer),
+// block 0 also writes the headers and the report; an atom's record goes into the message at the moment its list entry is written
+__global__ void __launch_bounds__(256) k_border_fill_pack(AtomSoA a, int beg, int end, Slabs sl, const int *__restrict__ chunk_offset, int nchunk,
+                                                          int *__restrict__ sendlist, const int *__restrict__ dir_start, MrPlan P, Shift27 sh,
+                                                          int *__restrict__ d_mr, BinGeom bg, double *__restrict__ stage_send,
+                                                          int *__restrict__ flags, int *__restrict__ report)
+{
+    __shared__ int wave_tot[27][4];
+    __shared__ int ds[28], dst[27];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < 28) ds[t] = dir_start[t];
+    if (t < 27) dst[t] = 0;
+    __syncthreads();
+    if (t < P.np) {
+        int fill = 0;
+        int *hdr = reinterpret_cast<int *>(stage_send + P.base_s[t]);
+        for (int d = 0; d < 27; d++) {
+            const bool mine = P.pidx[d] == t;
+            const int c = ds[d + 1] - ds[d];
+            if (blockIdx.x == 0) hdr[d] = mine ? c : 0;
+            if (mine) { dst[d] = fill; fill += c; }
+        }
+        if (blockIdx.x == 0) {
+            d_mr[32 + t] = fill;
+            report[32 + t] = fill;
+            if (fill > P.cap_s[t]) flags[0] = 200002;
+        }
+    }
+    const int i = beg + blockIdx.x * 256 + t;
+    int fl = 0;
+    double c[3] = {0.0, 0.0, 0.0};
+    if (i < end) {
+        c[0] = a.x[0][i]; c[1] = a.x[1][i]; c[2] = a.x[2][i];
+        fl = near_flags(c[0], c[1], c[2], sl.lo, sl.hi);
+    }
+#pragma unroll 1
+    for (int dir = 0; dir < 27; dir++) {
+        const u64 m = __ballot(dir != 13 && fl && in_dir(fl, dir));
+        if (lane == 0) wave_tot[dir][w] = __popcll(m);
+    }
+    __syncthreads();                        // direction slots, wave totals
+    if (blockIdx.x == 0 && t < 27) d_mr[t] = dst[t];
+    if (!fl) return;
+    // the atom's part of its records, once
+    const double vx = a.v[0][i], vy = a.v[1][i], vz = a.v[2][i];
+    const int2 pp = make_int2(a.tag[i], a.type[i]);
+    const int mk = a.mask[i];
+    int b[3];
+    for (int k = 0; k < 3; k++) b[k] = clampi((int)((c[k] - bg.lo[k]) * bg.bininv[k] + 1), 0, bg.mbin[k]);       // (the binning of k_fr_count)
+#pragma unroll 1
+    for (int dir = 0; dir < 27; dir++) {
+        if (dir == 13) continue;
+        const bool hit = in_dir(fl, dir);
+        const u64 m = __ballot(hit);
+        if (!hit) continue;
+        int base = chunk_offset[dir * nchunk + blockIdx.x];
+        for (int k = 0; k < w; k++) base += wave_tot[dir][k];
+        const int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+        sendlist[slot] = i;
+        const int p = P.pidx[dir];
+        if (p < 0) continue;
+        const int q = dst[dir] + (slot - ds[dir]);
+        if (q >= P.cap_s[p]) continue;                      // (flagged above)
+        double *o = stage_send + P.base_s[p] + MR_HDR_DOUBLES + BORDER_DOUBLES * (size_t)q;
+        o[0] = c[0] + sh.s[dir][0]; o[1] = c[1] + sh.s[dir][1]; o[2] = c[2] + sh.s[dir][2];
+        o[3] = vx; o[4] = vy; o[5] = vz;
+        const int sd[3] = {dir % 3 - 1, (dir / 3) % 3 - 1, dir / 9 - 1};
+        u32 gq[3];
+        for (int k = 0; k < 3; k++) gq[k] = (u32)clampi(b[k] - sd[k] * (bg.mbin[k] - 2), 0, bg.mbin[k]);
+        int2 pq = pp, r = make_int2(mk, (int)interleave3(gq[0], gq[1], gq[2]));
+        o[6] = *reinterpret_cast<double *>(&pq);
+        o[7] = *reinterpret_cast<double *>(&r);
+    }
+}
+
 __global__ void __launch_bounds__(64) k_border_unpack_hdr(const double *__restrict__ stage_recv, MrPlan P, int room, int *__restrict__ d_mr,
                                                           int *__restrict__ flags, int *__restrict__ report)
 {
@@ -1424,13 +1500,20 @@ int Engine::halo_borders_multi_async()
         for (int k = 0; k < 28; k++) h_flags[16 + k] = 0;
         h_flags[8] = 0; h_flags[9] = n_bulk;
     }
-    hipLaunchKernelGGL(k_border_hdr, dim3(1), dim3(64), 0, stream, d_dir_start, P, d_mr, (double *)stage_send, d_flags, h_flags_dev + 64);
-    if (nchunk > 0) launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
     Shift27 sh;
     for (int d = 0; d < 27; d++) for (int k = 0; k < 3; k++) sh.s[d][k] = shift27[3 * d + k];
+    if (nchunk > 0 && border_fused) {
+        Slabs sl;
+        for (int d = 0; d < 3; d++) { sl.lo[d] = slab_lo[d]; sl.hi[d] = slab_hi[d]; }
+        hipLaunchKernelGGL(k_border_fill_pack, dim3(nchunk), dim3(256), 0, stream, cur, beg, end, sl, chunk_offset, nchunk, sendlist, d_dir_start, P, sh,
+                           d_mr, geom, (double *)stage_send, d_flags, h_flags_dev + 64);
+    } else {
+    hipLaunchKernelGGL(k_border_hdr, dim3(1), dim3(64), 0, stream, d_dir_start, P, d_mr, (double *)stage_send, d_flags, h_flags_dev + 64);
+    if (nchunk > 0) launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
     if (bound_s > 0)
         hipLaunchKernelGGL(k_pack_border_fixed, dim3((bound_s + 255) / 256), dim3(256), 0, stream, cur, sendlist, d_dir_start, P, sh, d_mr, geom,
                            (double *)stage_send);
+    }
     std::vector<void *> sb(np), rb(np);
     std::vector<size_t> sn(np), rn(np);
     for (int p = 0; p < np; p++) {
