@@ -297,9 +297,6 @@ private:
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on
-    int count_in_pair = 1;          // option: one rank, rebuild known in advance: the step before it counts for the rebuild in the force kernel's epilogue
-    bool count_early = false;       // ... the last force launch did
-    unsigned count_early_gen = 0, fr_gen = 0;     // (generation of the fused rebuild's counters: a reset in between voids the early count)
     int border_fused = 1;           // option: border lists + headers + records in one launch behind count + scan (0: fill, header, pack)
     int mig_slim = 1;               // option: leavers' lists by atomics + ranking (2 launches) instead of the counting chain (8)
     bool mig_lists_built = false;   // this rebuild's direction-major list of all atoms exists (sendlist, d_dir_start)

@@ -336,7 +336,6 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
     if (key == "tile_plan") { tile_plan = (int)val; return 0; }
-    if (key == "count_in_pair") { count_in_pair = (int)val; return 0; }      // 0: the rebuild's count always in its own launch
     if (key == "border_fused") { border_fused = (int)val; return 0; }
     if (key == "mig_slim") { mig_slim = (int)val; return 0; }
     if (key == "border_runs") { border_runs = (int)val; return 0; }      // several ranks: ghosts in message order, cells as runs (0: unpack + binning chain)
@@ -1227,7 +1226,6 @@ int Engine::fused_alloc()
         HIPCHK(hipMemsetAsync(rcount, 0, (2 * M + 1) * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(fr_novf, 0, sizeof(int), stream));
         fused_dirty = false;
-        fr_gen++;                  // (a count the force kernel ran ahead of its rebuild is gone with this)
     }
     return 0;
 }
@@ -1276,8 +1274,6 @@ int Engine::rebuild_fused()
     if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
     FusedArgs a;
     fused_locals_args(a);
-    a.count_done = (count_early && count_early_gen == fr_gen) ? 1 : 0;      // (the previous step's force kernel counted: run loop)
-    count_early = false;
     const int par = (int)(fr_epoch & 1u);
     a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
     // (the separate-plan option reads gstart by differences: every tile runs then)
@@ -1592,12 +1588,6 @@ int Engine::reneighbor()
     ghosts_binned = false;
     fused_active = false;
     mr_runs = false;
-    if (count_early && !fused_ok()) {
-        // the previous step counted for a fused rebuild that will not run: its counters are cleared (every path shares them)
-        count_early = false;
-        fused_dirty = true;
-        TRY(fused_alloc());
-    }
     if (fused_ok()) {
         TRY(rebuild_fused());
     } else if (async_ok() && overlap_rebuild && nlocal > 0) {
@@ -1835,26 +1825,6 @@ int Engine::run(int nsteps)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
                                   0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
                                   premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
-        // one rank, rebuild known in advance (neigh_modify check no): the epilogue of this step also runs the rebuild's count of the
-        // locals - the new positions are in its registers - and the rebuild starts with the placing kernel (rebuild_fused)
-        p.fc.on = 0;
-        count_early = false;
-        if (boundary_in_pair && next_rebuild && !dist_check && count_in_pair && nranks == 1 && !split && fused_ok() && params_ready &&
-            !reorder_sort) {
-            if (fused_alloc() == 0) {
-                FusedArgs fa;
-                fused_locals_args(fa);
-                FrCountArgs &c = p.fc;
-                c.on = 1;
-                c.wrap = 1;          // (reneighbor: wrap_in_reorder on one rank)
-                for (int d = 0; d < 3; d++) { c.boxlo[d] = boxlo[d]; c.boxhi[d] = boxhi[d]; c.per[d] = periodic[d]; }
-                c.g = fa.g; c.sl = fa.sl; c.sub_bits = fa.sub_bits; c.M = fa.M;
-                c.cnt = fa.cnt; c.cap = fa.cap; c.bucket = fa.bucket; c.ovf = fa.ovf; c.novf = fa.novf; c.ovf_cap = fa.ovf_cap;
-                c.ttot = fa.ttot; c.flags = fa.flags; c.image = cur.image; c.tile = fused_tile_codes();
-                count_early = true;
-                count_early_gen = fr_gen;
-            }
-        }
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
         if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }

@@ -14,26 +14,6 @@ struct BinGeom {
     int nbin;
 };
 
-// border slabs of a sub-box (near_flags, meso_device.h)
-struct Slabs { double lo[3], hi[3]; };
-// the rebuild's count of the locals run by the force kernel's step boundary (fr_count_body, meso_device.h)
-struct FrCountArgs {
-    int on;
-    int wrap;
-    double boxlo[3], boxhi[3];
-    int per[3];
-    BinGeom g;
-    Slabs sl;
-    int sub_bits, M;
-    int *cnt, cap;
-    unsigned long long *bucket, *ovf;
-    int *novf, ovf_cap;
-    int *ttot;
-    int *flags;
-    int *image;
-    int tile;                  // codes per tile (FR_TILE)
-};
-
 // SoA views (device pointers)
 struct AtomSoA {
     double *x[3], *v[3], *f[3];
@@ -175,7 +155,6 @@ struct PairArgs {
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;
     NveArgs nve;
-    FrCountArgs fc;       // with fuse_nve, fc.on: the step in front of a rebuild known in advance also runs the rebuild's count (rebuild.hip)
     BondArgs bond;        // with fuse_nve: this atom's bond forces are computed in the epilogue and added before the step boundary
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);

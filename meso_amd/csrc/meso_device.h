@@ -327,7 +327,7 @@ __device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p)
     p.vx = a.v[0][i]; p.vy = a.v[1][i]; p.vz = a.v[2][i];
     p.mass = a.mass[i]; p.mask = a.mask[i]; p.tag = a.tag[i]; p.type = a.type[i];
 }
-__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre = nullptr, double *xout = nullptr)
+__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre = nullptr)
 {
     double x = pre ? pre->x : a.x[0][i], y = pre ? pre->y : a.x[1][i], z = pre ? pre->z : a.x[2][i];
     double vx = pre ? pre->vx : a.v[0][i], vy = pre ? pre->vy : a.v[1][i], vz = pre ? pre->vz : a.v[2][i];
@@ -339,7 +339,6 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
         a.v[0][i] = vx; a.v[1][i] = vy; a.v[2][i] = vz;
         a.x[0][i] = x; a.x[1][i] = y; a.x[2][i] = z;
     }
-    if (xout) { xout[0] = x; xout[1] = y; xout[2] = z; }
     if (a.merge) {
         float4 c;
         c.x = (float)(x - a.cx); c.y = (float)(y - a.cy); c.z = (float)(z - a.cz);
@@ -423,6 +422,7 @@ __device__ inline void permute_one(const AtomSoA &src, const AtomSoA &dst, int j
 }
 
 // border slabs: near_flags bit 2d = near the low face of dim d (sent down), bit 2d+1 = near the high face (sent up)
+struct Slabs { double lo[3], hi[3]; };
 __device__ inline int near_flags(double cx, double cy, double cz, const double *sl, const double *sh)
 {
     int f = 0;
@@ -517,63 +517,7 @@ struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0
 struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction
 
 // Arguments of the three-launch rebuild of one rank (rebuild.hip)
-// The locals' count of the fused rebuild (rebuild.hip) as a function of one atom: wrap into the periodic box (MesoDomain::pbc), extended
-// code [border][Morton(bin)], sub-cell key, rank inside the code from one atomic per run of equal codes in the wave, (key, index) word
-// into the code's bucket, tile totals.  Called by k_fr_count - and by the force kernel's step boundary on the step in front of a
-// rebuild that is known in advance (neigh_modify check no): the new position is in registers there, and the rebuild starts one
-// launch and one read of the coordinates shorter.  EVERY lane of a wave calls it (valid: the lane holds an atom); lanes hold
-// consecutive atoms.  A: FusedArgs or FrCountArgs (the same field names).
-template <class A>
-__device__ inline void fr_count_body(const A &a, double *const *x, int *image, int tile, int i, bool valid, double c0, double c1, double c2)
-{
-    u32 e = 0, key = 0;
-    if (valid) {
-        double c[3] = {c0, c1, c2};
-        if (a.wrap) {
-            const int img = image[i];
-            int im[3] = {img & 1023, (img >> 10) & 1023, img >> 20};
-            bool moved = false;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                if (!a.per[d]) continue;
-                const double p = a.boxhi[d] - a.boxlo[d];
-                if (c[d] < a.boxlo[d]) { c[d] += p; im[d] = (im[d] - 1) & 1023; moved = true; }
-                if (c[d] >= a.boxhi[d]) { c[d] -= p; c[d] = fmax(c[d], a.boxlo[d]); im[d] = (im[d] + 1) & 1023; moved = true; }
-            }
-            if (moved) {
-                x[0][i] = c[0]; x[1][i] = c[1]; x[2][i] = c[2];
-                image[i] = im[0] | (im[1] << 10) | (im[2] << 20);
-            }
-        }
-        const int res = 1 << (a.sub_bits / 3);
-        u32 b[3], sc[3];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            b[d] = (u32)clampi((int)((c[d] - a.g.lo[d]) * a.g.bininv[d] + 1), 0, a.g.mbin[d]);
-            sc[d] = (u32)clampi((int)((c[d] - a.g.lo[d] - ((double)b[d] - 1) * a.g.binsize[d]) * (res * a.g.bininv[d])), 0, res);
-        }
-        e = interleave3(b[0], b[1], b[2]);
-        key = interleave3(sc[0], sc[1], sc[2]);      // sub-cell Morton key: the order inside the cell (gpu_build_reorder_keypair)
-        const bool border = c[0] <= a.sl.lo[0] || c[0] >= a.sl.hi[0] || c[1] <= a.sl.lo[1] || c[1] >= a.sl.hi[1] || c[2] <= a.sl.lo[2] ||
-                            c[2] >= a.sl.hi[2];
-        if (border) e += (u32)a.M;
-    }
-    // rank inside the code, one atomic per run of equal codes; tile totals: one atomic per tile and wave
-    const int rank = run_rank(e, valid, a.cnt);
-    wave_group_add(e / (u32)tile, valid, a.ttot);
-    if (!valid) return;
-    // (sub-cell key, old index) travels as one word: the placing kernel orders a cell without touching the coordinates
-    const unsigned long long ent = ((unsigned long long)key << 32) | (u32)i;
-    if (rank < a.cap) a.bucket[(size_t)e * a.cap + rank] = ent;
-    else {
-        const int o = atomicAdd(a.novf, 1);
-        if (o < a.ovf_cap) { a.ovf[2 * o] = (unsigned long long)e; a.ovf[2 * o + 1] = ent; }
-        else atomicMax(a.flags, 300000);
-    }
-}
-
 struct FusedArgs {
-    int count_done;            // the count ran in the force kernel's step boundary already (FrCountArgs): k_fr_count is not launched
     const int *skip;           // several ranks: migration code of every atom below skip_n (13 = stays); leavers are holes the count skips,
     int skip_n;                // arrivals sit behind skip_n - the stayers are not compacted before the reorder
     AtomSoA src, dst;          // old order -> new order (ghosts go behind the n locals of dst)

@@ -337,7 +337,6 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
-    double xn[3] = {0.0, 0.0, 0.0};  // the atom's position after the step boundary (fc.on)
     if (mine && part == 0) {
         double fx, fy, fz;
         if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
@@ -358,14 +357,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                     fx += bx; fy += by; fz += bz;
                 }
             }
-            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre, xn);
-            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, xn);
+            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre);
+            else nve_boundary_atom(a.nve, i, fx, fy, fz);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }
-    // the step in front of a rebuild: the rebuild's count of the locals, on the positions just written (every lane of the wave takes
-    // part: the rank inside a code is a wave operation; lanes hold consecutive atoms)
-    if (a.fuse_nve && a.fc.on) fr_count_body(a.fc, a.nve.x, a.fc.image, a.fc.tile, i, mine && part == 0, xn[0], xn[1], xn[2]);
 }
 
 // the instantiation the last launch ran, spelled as rocprofv3 prints it: bench.py attaches profile-derived numbers to its line

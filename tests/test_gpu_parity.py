@@ -682,10 +682,7 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
     for opts in ((("async_counts", 0), ("ghost_epilogue", 0)), (), (("fused_rebuild", 0),), (("overlap_rebuild", 1),),
                  (("async_grid_scale", 0.05), ("fused_rebuild", 0)), (("overlap_rebuild", 1), ("async_grid_scale", 0.05)),
                  (("ghost_epilogue", 0),), (("ghost_epilogue", 0), ("fused_rebuild", 0)), (("ghost_epilogue", 1), ("async_counts", 0)),
-                 (("fused_cap", 2),), (("fused_cap", 2), ("reorder_cap", 64), ("ghost_epilogue", 0)),
-                 # count_in_pair: the rebuild's count of the locals run by the previous step's force kernel (default) or by its own launch;
-                 # with two-atom buckets the early count goes through the overflow list as well
-                 (("count_in_pair", 0),), (("count_in_pair", 0), ("ghost_epilogue", 0)), (("fused_cap", 2), ("count_in_pair", 0))):
+                 (("fused_cap", 2),), (("fused_cap", 2), ("reorder_cap", 64), ("ghost_epilogue", 0))):
         m, _ = _engine(Meso, 16, style=style, opts=opts)
         m.run(23)
         res.append(m.gather())
