@@ -190,8 +190,11 @@ void Engine::comm_free()
 // ------------------------------------------------------------------------------------------------
 // exchange primitive: device buffers, one message per peer each way
 // ------------------------------------------------------------------------------------------------
+// rbuf2 != null: every message is two halves of equal size (the per-step ghost refresh: coordinates, then velocities) and its
+// second half is delivered to rbuf2[k] - straight into the two merged arrays, no scatter kernel behind the exchange.  With RCCL
+// the halves travel as two send/recv pairs of the same group (matched in order per peer).
 int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf,
-                 const size_t *rbytes)
+                 const size_t *rbytes, void *const *rbuf2)
 {
     hipStream_t stream = xs ? xs : this->stream;   // exchange stream (the side stream during overlapped refreshes)
     if (transport == 1) {
@@ -199,15 +202,27 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
         bool any = false;
         for (int k = 0; k < np; k++) {
             if (peer[k] == rank) {
-                if (rbytes[k]) HIPCHK(hipMemcpyAsync(rbuf[k], sbuf[k], rbytes[k], hipMemcpyDeviceToDevice, stream));
+                if (rbytes[k] && !rbuf2) HIPCHK(hipMemcpyAsync(rbuf[k], sbuf[k], rbytes[k], hipMemcpyDeviceToDevice, stream));
+                if (rbytes[k] && rbuf2) {
+                    HIPCHK(hipMemcpyAsync(rbuf[k], sbuf[k], rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
+                    HIPCHK(hipMemcpyAsync(rbuf2[k], (const char *)sbuf[k] + rbytes[k] / 2, rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
+                }
             } else if (sbytes[k] || rbytes[k]) any = true;
         }
         if (any) {
             if (ncclGroupStart() != ncclSuccess) return fail(5, "ncclGroupStart failed");
             for (int k = 0; k < np; k++) {
                 if (peer[k] == rank) continue;
-                if (sbytes[k] && ncclSend(sbuf[k], sbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclSend failed");
-                if (rbytes[k] && ncclRecv(rbuf[k], rbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclRecv failed");
+                if (!rbuf2) {
+                    if (sbytes[k] && ncclSend(sbuf[k], sbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclSend failed");
+                    if (rbytes[k] && ncclRecv(rbuf[k], rbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclRecv failed");
+                } else {
+                    const size_t hs = sbytes[k] / 2, hr = rbytes[k] / 2;
+                    if (hs && (ncclSend(sbuf[k], hs, ncclChar, peer[k], c, stream) != ncclSuccess ||
+                               ncclSend((const char *)sbuf[k] + hs, hs, ncclChar, peer[k], c, stream) != ncclSuccess)) return fail(5, "ncclSend failed");
+                    if (hr && (ncclRecv(rbuf[k], hr, ncclChar, peer[k], c, stream) != ncclSuccess ||
+                               ncclRecv(rbuf2[k], hr, ncclChar, peer[k], c, stream) != ncclSuccess)) return fail(5, "ncclRecv failed");
+                }
             }
             if (ncclGroupEnd() != ncclSuccess) return fail(5, "ncclGroupEnd failed");
         }
@@ -251,7 +266,11 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
                     }
                 }
             if (!from) return fail(5, "local transport: peer did not post a message");
-            HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k], hipMemcpyDeviceToDevice, stream));
+            if (!rbuf2) HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k], hipMemcpyDeviceToDevice, stream));
+            else {
+                HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipMemcpyAsync(rbuf2[k], (const char *)from + rbytes[k] / 2, rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
+            }
         }
         if (acct) t2 = clk::now();
         HIPCHK(hipStreamSynchronize(stream));
@@ -272,8 +291,14 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
         if (acct) t1 = clk::now();
         if (host_exchange(host_exchange_user, np, peer, sp.data(), sbytes, rp.data(), rbytes)) return fail(5, "host exchange failed");
         if (acct) t2 = clk::now();
-        for (int k = 0; k < np; k++)
-            if (rbytes[k]) HIPCHK(hipMemcpyAsync(rbuf[k], hr[k].data(), rbytes[k], hipMemcpyHostToDevice, stream));
+        for (int k = 0; k < np; k++) {
+            if (!rbytes[k]) continue;
+            if (!rbuf2) HIPCHK(hipMemcpyAsync(rbuf[k], hr[k].data(), rbytes[k], hipMemcpyHostToDevice, stream));
+            else {
+                HIPCHK(hipMemcpyAsync(rbuf[k], hr[k].data(), rbytes[k] / 2, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipMemcpyAsync(rbuf2[k], hr[k].data() + rbytes[k] / 2, rbytes[k] / 2, hipMemcpyHostToDevice, stream));
+            }
+        }
         HIPCHK(hipStreamSynchronize(stream));
         if (acct) book(t0, t1, t2, clk::now());
         return 0;
@@ -1620,10 +1645,18 @@ int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
     HIPCHK(hipStreamWaitEvent(side, ev_pack, 0));
     xs = side;
     xchg_what = "ghost refresh";
-    int rc = xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data());
+    // ghosts in message order (this rebuild's ghost stage left them so: mr_runs): the halves of every message go straight into the
+    // merged arrays - no scatter kernel
+    const bool direct = mr_runs && refresh_direct;
+    std::vector<void *> rb2;
+    if (direct) {
+        rb2.resize(np);
+        for (int p = 0; p < np; p++) { rb[p] = coord4 + nlocal + peer_recv_base[p]; rb2[p] = veloc4 + nlocal + peer_recv_base[p]; }
+    }
+    int rc = xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data(), direct ? rb2.data() : nullptr);
     xs = nullptr;
     if (rc) return rc;
-    if (nghost > 0) {
+    if (nghost > 0 && !direct) {
         PeerTab P;
         P.np = np;
         for (int p = 0; p <= np; p++) P.gbase[p] = peer_recv_base[p];

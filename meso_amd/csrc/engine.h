@@ -139,7 +139,7 @@ private:
     int check_overflow();
     double reduce_global_sum(double v);
     // multi-rank (comm.hip)
-    int xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf, const size_t *rbytes);
+    int xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf, const size_t *rbytes, void *const *rbuf2 = nullptr);
     int merge_new_ghosts(uint32_t sd);
     // several ranks, borders without a host round trip (comm.hip): fixed-capacity messages, counts in band
     std::vector<int> mr_cap_s, mr_cap_r;          // ghosts per peer message, from the counts of the previous rebuild (same on both sides)
@@ -297,6 +297,7 @@ private:
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on
+    int refresh_direct = 1;         // option: the per-step ghost refresh is received straight into the merged arrays when the ghosts are in message order
     int border_fused = 1;           // option: border lists + headers + records in one launch behind count + scan (0: fill, header, pack)
     int mig_slim = 1;               // option: leavers' lists by atomics + ranking (2 launches) instead of the counting chain (8)
     bool mig_lists_built = false;   // this rebuild's direction-major list of all atoms exists (sendlist, d_dir_start)

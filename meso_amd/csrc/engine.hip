@@ -336,6 +336,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
     if (key == "tile_plan") { tile_plan = (int)val; return 0; }
+    if (key == "refresh_direct") { refresh_direct = (int)val; return 0; }
     if (key == "border_fused") { border_fused = (int)val; return 0; }
     if (key == "mig_slim") { mig_slim = (int)val; return 0; }
     if (key == "border_runs") { border_runs = (int)val; return 0; }      // several ranks: ghosts in message order, cells as runs (0: unpack + binning chain)
