@@ -764,10 +764,11 @@ __global__ void __launch_bounds__(256) k_pack_border_fixed(AtomSoA a, const int 
 __global__ void __launch_bounds__(256) k_border_fill_pack(AtomSoA a, int beg, int end, Slabs sl, const int *__restrict__ chunk_offset, int nchunk,
                                                           int *__restrict__ sendlist, const int *__restrict__ dir_start, MrPlan P, Shift27 sh,
                                                           int *__restrict__ d_mr, BinGeom bg, double *__restrict__ stage_send,
-                                                          int *__restrict__ flags, int *__restrict__ report)
+                                                          int *__restrict__ flags, int *__restrict__ report, int *__restrict__ img_cnt,
+                                                          int *__restrict__ img, int *__restrict__ vofs_out)
 {
     __shared__ int wave_tot[27][4];
-    __shared__ int ds[28], dst[27];
+    __shared__ int ds[28], dst[27], pfill[27], pbase[27];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t < 28) ds[t] = dir_start[t];
     if (t < 27) dst[t] = 0;
@@ -781,6 +782,7 @@ __global__ void __launch_bounds__(256) k_border_fill_pack(AtomSoA a, int beg, in
             if (blockIdx.x == 0) hdr[d] = mine ? c : 0;
             if (mine) { dst[d] = fill; fill += c; }
         }
+        pfill[t] = fill;
         if (blockIdx.x == 0) {
             d_mr[32 + t] = fill;
             report[32 + t] = fill;
@@ -801,7 +803,20 @@ __global__ void __launch_bounds__(256) k_border_fill_pack(AtomSoA a, int beg, in
     }
     __syncthreads();                        // direction slots, wave totals
     if (blockIdx.x == 0 && t < 27) d_mr[t] = dst[t];
+    // img != null: the atom's slots in the PER-STEP refresh messages (peer-major staging of float4 pairs: [coordinates of peer p]
+    // [velocities of peer p], as fill_dirtab lays it out) go into its image table - the force kernel's step boundary then writes
+    // the refresh itself (nve_boundary_atom) and k_pack_forward_multi is not launched
+    if (!img_cnt) img = nullptr;          // (both or neither)
+    if (img) {
+        if (t == 0) {
+            int run = 0;
+            for (int q = 0; q < P.np; q++) { pbase[q] = run; run += pfill[q]; }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && t < 27) vofs_out[t] = P.pidx[t] >= 0 ? pfill[P.pidx[t]] : 0;
+    }
     if (!fl) return;
+    int nimg = 0;
     // the atom's part of its records, once
     const double vx = a.v[0][i], vy = a.v[1][i], vz = a.v[2][i];
     const int2 pp = make_int2(a.tag[i], a.type[i]);
@@ -821,6 +836,8 @@ __global__ void __launch_bounds__(256) k_border_fill_pack(AtomSoA a, int beg, in
         const int p = P.pidx[dir];
         if (p < 0) continue;
         const int q = dst[dir] + (slot - ds[dir]);
+        if (img && nimg < 8) img[(size_t)i * 8 + nimg] = (2 * pbase[p] + q) | (dir << 26);
+        nimg++;
         if (q >= P.cap_s[p]) continue;                      // (flagged above)
         double *o = stage_send + P.base_s[p] + MR_HDR_DOUBLES + BORDER_DOUBLES * (size_t)q;
         o[0] = c[0] + sh.s[dir][0]; o[1] = c[1] + sh.s[dir][1]; o[2] = c[2] + sh.s[dir][2];
@@ -831,6 +848,10 @@ __global__ void __launch_bounds__(256) k_border_fill_pack(AtomSoA a, int beg, in
         int2 pq = pp, r = make_int2(mk, (int)interleave3(gq[0], gq[1], gq[2]));
         o[6] = *reinterpret_cast<double *>(&pq);
         o[7] = *reinterpret_cast<double *>(&r);
+    }
+    if (img) {
+        img_cnt[i] = nimg;
+        if (nimg > 8) flags[0] = 200004;      // (more than 8 directions: a sub-box narrower than two ghost cutoffs - excluded on the host)
     }
 }
 
@@ -1530,8 +1551,13 @@ int Engine::halo_borders_multi_async()
     if (nchunk > 0 && border_fused) {
         Slabs sl;
         for (int d = 0; d < 3; d++) { sl.lo[d] = slab_lo[d]; sl.hi[d] = slab_hi[d]; }
+        // (the reorder cleared the image counters of every atom when mr_img: fused_locals_args)
+        const bool rec = mr_img_wanted() && img_zero_gen == img_alloc_gen;      // (... and the arrays were not regrown since)
+        if (rec && !d_vofs) { HIPCHK(hipMalloc((void **)&d_vofs, 32 * sizeof(int))); }
         hipLaunchKernelGGL(k_border_fill_pack, dim3(nchunk), dim3(256), 0, stream, cur, beg, end, sl, chunk_offset, nchunk, sendlist, d_dir_start, P, sh,
-                           d_mr, geom, (double *)stage_send, d_flags, h_flags_dev + 64);
+                           d_mr, geom, (double *)stage_send, d_flags, h_flags_dev + 64, rec ? img_cnt : nullptr, rec ? img : nullptr, d_vofs);
+        mr_images_ready = rec;
+        mr_img_stage = stage_send;
     } else {
     hipLaunchKernelGGL(k_border_hdr, dim3(1), dim3(64), 0, stream, d_dir_start, P, d_mr, (double *)stage_send, d_flags, h_flags_dev + 64);
     if (nchunk > 0) launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
@@ -1629,7 +1655,10 @@ int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
     TRY(resolve_counts());      // (the tables of the refresh come from the counts of the last rebuild)
     tbegin("halo");
     int np = (int)peers.size();
-    if (nsend > 0)
+    // (fwd_packed: the previous step's force kernel wrote this refresh into the staging - run loop)
+    const bool packed = fwd_packed && stage_send == mr_img_stage;
+    fwd_packed = false;
+    if (nsend > 0 && !packed)
         hipLaunchKernelGGL(k_pack_forward_multi, dim3((nsend + 255) / 256), dim3(256), 0, stream, cur, sendlist, nsend,
                            fwd_tab_host(), sd, (float4 *)stage_send);
     std::vector<void *> sb(np), rb(np);

@@ -297,6 +297,15 @@ private:
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on
+    int refresh_epilogue = 1;       // option: several ranks - the per-step refresh messages are written by the force kernel's step boundary (image
+                                    // tables from the rebuild's border kernel) instead of k_pack_forward_multi
+    bool mr_images_ready = false;   // ... this rebuild recorded the tables
+    bool fwd_packed = false;        // ... the last force launch wrote the next refresh
+    void *mr_img_stage = nullptr;   // (the staging the tables point into: a regrown staging voids them)
+    int *d_vofs = nullptr;
+    double *d_center27 = nullptr;
+    bool mr_img_wanted() const;
+    unsigned img_alloc_gen = 0, img_zero_gen = 0;
     int refresh_direct = 1;         // option: the per-step ghost refresh is received straight into the merged arrays when the ghosts are in message order
     int border_fused = 1;           // option: border lists + headers + records in one launch behind count + scan (0: fill, header, pack)
     int mig_slim = 1;               // option: leavers' lists by atomics + ranking (2 launches) instead of the counting chain (8)

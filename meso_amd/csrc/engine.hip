@@ -87,7 +87,7 @@ void Engine::free_all()
     for (int k = 0; k < 2; k++) { dfree(fr_ttot[k]); dfree(fr_stot[k]); dfree(fr_gttot[k]); dfree(fr_gstot[k]); }
     if (sort_temp) (void)hipFree(sort_temp);
     sort_temp = nullptr;
-    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(mr_gcnt); dfree(mig_cnt); dfree(mig_lst);
+    dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(mr_gcnt); dfree(mig_cnt); dfree(mig_lst); dfree(d_vofs); dfree(d_center27);
     dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own); dfree(brick_order2);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
@@ -336,6 +336,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "ghost_sort") { ghost_sort = (int)val; return 0; }
     if (key == "reorder_sort") { reorder_sort = (int)val; return 0; }
     if (key == "tile_plan") { tile_plan = (int)val; return 0; }
+    if (key == "refresh_epilogue") { refresh_epilogue = (int)val; return 0; }
     if (key == "refresh_direct") { refresh_direct = (int)val; return 0; }
     if (key == "border_fused") { border_fused = (int)val; return 0; }
     if (key == "mig_slim") { mig_slim = (int)val; return 0; }
@@ -435,6 +436,8 @@ int Engine::alloc_atoms(int cap)
     HIPCHK(regrow(img_cnt, 0, c, stream)); HIPCHK(regrow(img, 0, c * 8, stream));
     HIPCHK(regrow(senddir, 0, c, stream)); HIPCHK(regrow(fr_scratch, 0, c, stream));
     images_ready = false;
+    mr_images_ready = false;
+    img_alloc_gen++;            // (image counters cleared by a reorder before this are gone: halo_borders_multi_async)
     send_cap = cap;
     chunk_cap = (cap + 255) / 256 + 1;
     HIPCHK(regrow(chunk_count, 0, (size_t)27 * chunk_cap + 1, stream));
@@ -851,6 +854,8 @@ int Engine::init_params()
     build_peer_tables();
     if (!d_shift27) HIPCHK(dalloc(d_shift27, 81));
     HIPCHK(hipMemcpy(d_shift27, shift27, 81 * sizeof(double), hipMemcpyHostToDevice));
+    if (!d_center27) HIPCHK(dalloc(d_center27, 81));
+    HIPCHK(hipMemcpy(d_center27, center27, 81 * sizeof(double), hipMemcpyHostToDevice));
 
     // bins aligned with the sub-box, one ghost layer each side
     double subvol = 1.0;
@@ -1260,8 +1265,19 @@ void Engine::fused_locals_args(FusedArgs &a)
     a.mg.cx = 0.5 * (subhi[0] + sublo[0]); a.mg.cy = 0.5 * (subhi[1] + sublo[1]); a.mg.cz = 0.5 * (subhi[2] + sublo[2]);
     a.mg.seed = premix_tea<64>((u32)seed, (u32)ntimestep);
     a.mg.inverse = nullptr;
-    a.mg.zero = images_on() ? img_cnt : nullptr;
+    a.mg.zero = (images_on() || mr_img_wanted()) ? img_cnt : nullptr;
+    img_zero_gen = img_alloc_gen;
     a.flags = d_flags;
+}
+
+// several ranks: the rebuild's border kernel records every border atom's slots in the per-step refresh messages, and the force
+// kernel's step boundary writes the refresh (sub-boxes at least two ghost cutoffs wide: at most 7 directions per atom)
+bool Engine::mr_img_wanted() const
+{
+    if (!(refresh_epilogue && nranks > 1 && border_fused && mr_async_ok() && fuse_pair && fuse_step && ring_selected() && reorder_fuses(nlocal))) return false;
+    for (int d = 0; d < 3; d++)
+        if (!(subhi[d] - sublo[d] > 2.0 * cutghost)) return false;
+    return true;
 }
 
 int Engine::rebuild_fused()
@@ -1589,6 +1605,8 @@ int Engine::reneighbor()
     ghosts_binned = false;
     fused_active = false;
     mr_runs = false;
+    mr_images_ready = false;
+    fwd_packed = false;
     if (fused_ok()) {
         TRY(rebuild_fused());
     } else if (async_ok() && overlap_rebuild && nlocal > 0) {
@@ -1829,6 +1847,13 @@ int Engine::run(int nsteps)
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
         if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }
+        // several ranks: the epilogue writes the next step's refresh messages into the send staging (tables from the rebuild's
+        // border kernel); bulk atoms have no entries, so with the bulk/border split only the border launch writes
+        const bool mr_img_step = boundary_in_pair && !next_rebuild && nranks > 1 && mr_images_ready && stage_send == mr_img_stage;
+        if (mr_img_step) {
+            p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27;
+            p.nve.img_c4 = (float4 *)stage_send; p.nve.img_v4 = (float4 *)stage_send; p.nve.img_vofs = d_vofs; p.nve.img_center = d_center27;
+        }
         // bulk atoms have no ghost partners: their forces are computed while the ghosts are in flight
         for (int part = 0; part < (split ? 2 : 1); part++) {
             p.beg = split ? (part == 0 ? 0 : n_split) : 0;
@@ -1849,6 +1874,7 @@ int Engine::run(int nsteps)
             initial_done = true;
             merged = !next_rebuild;
             ghosts_by_epilogue = img_step;
+            fwd_packed = mr_img_step;
         } else if (fuse_step && it + 1 < nsteps) {
             // one pass for final(s) + initial(s+1); the merge for s+1 rides along when s+1 provably keeps the table
             tbegin("nve");
@@ -1858,7 +1884,9 @@ int Engine::run(int nsteps)
             tend("nve");
             initial_done = true;
             merged = !next_rebuild;
+            fwd_packed = false;
         } else {
+            fwd_packed = false;
             TRY(nve_final());
             initial_done = false;
             merged = false;

@@ -116,6 +116,12 @@ struct NveArgs {
     // k_pack_forward launch).  img_cnt[i] images, img[8 i + m] = destination index | direction << 26; null: disabled
     const int *img_cnt, *img;
     const double *img_shift;      // [27][3] period shifts
+    // where the images go: the merged arrays of the next step (one rank, dest = ghost index) or - several ranks - the send staging of
+    // the per-step ghost refresh (dest = slot of the coordinates, the velocities img_vofs[d] slots behind; img_center: the receiver's
+    // centre per direction [27][3], null: this rank's own) - what k_pack_forward_multi would pack, without its launch
+    float4 *img_c4, *img_v4;
+    const int *img_vofs;
+    const double *img_center;
 };
 NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,
                       float4 *veloc4_next, double cx, double cy, double cz, uint32_t seed_next);

@@ -348,7 +348,7 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
         v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;
         v.w = __uint_as_float(signature(a.seed_next, pre ? pre->tag : a.tag[i], v.x, v.y, v.z));
         a.veloc4_next[i] = v;
-        if (a.img_cnt) {
+        if (a.img_cnt && !a.img_center) {
             // the ghost refresh of step s+1 for my own periodic images (what k_pack_forward computes: same expression, same bits)
             const int ni = min(a.img_cnt[i], 8);
             for (int m = 0; m < ni; m++) {
@@ -361,6 +361,21 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
                 g.w = c.w;
                 a.coord4_next[dest] = g;
                 a.veloc4_next[dest] = v;
+            }
+        } else if (a.img_cnt) {
+            // several ranks: the atom's records in the per-step refresh messages (what k_pack_forward_multi packs: the receiver's
+            // centre per direction, velocities img_vofs[d] slots behind the coordinates in the peer's block of the send staging)
+            const int ni = min(a.img_cnt[i], 8);
+            for (int m = 0; m < ni; m++) {
+                const int e = a.img[(size_t)i * 8 + m];
+                const int d = e >> 26, dest = e & 0x03FFFFFF;
+                float4 g;
+                g.x = (float)((x + a.img_shift[3 * d]) - a.img_center[3 * d]);
+                g.y = (float)((y + a.img_shift[3 * d + 1]) - a.img_center[3 * d + 1]);
+                g.z = (float)((z + a.img_shift[3 * d + 2]) - a.img_center[3 * d + 2]);
+                g.w = c.w;
+                a.img_c4[dest] = g;
+                a.img_v4[dest + a.img_vofs[d]] = v;
             }
         }
     }

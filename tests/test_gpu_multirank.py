@@ -181,8 +181,9 @@ def test_borders_without_host_round_trip_equal_the_synchronous_path(every):
     # the migration's sending side in two launches (leavers appended to their direction's list by atomics, ranked when packed:
     # default) against the count / scan / fill chain (mig_slim 0): the same messages in the same order; likewise the border lists,
     # headers and records written by one kernel (default) against fill + header + pack (border_fused 0), and the per-step ghost
-    # refresh received straight into the merged arrays (default) against exchange + scatter kernel (refresh_direct 0)
-    e = _run_ranks(8, (2, 2, 2), 12, "dpd/fast/meso", 3.0, 23, every=every, opts=(("mig_slim", 0), ("border_fused", 0), ("refresh_direct", 0)))
+    # refresh received straight into the merged arrays (default) against exchange + scatter kernel (refresh_direct 0) and written by
+    # the force kernel's step boundary (default) against k_pack_forward_multi (refresh_epilogue 0)
+    e = _run_ranks(8, (2, 2, 2), 12, "dpd/fast/meso", 3.0, 23, every=every, opts=(("mig_slim", 0), ("border_fused", 0), ("refresh_direct", 0), ("refresh_epilogue", 0)))
     for k in range(3):
         assert np.array_equal(a[1][k], e[1][k])
     assert a[2] == e[2]
