@@ -531,13 +531,30 @@ __global__ void __launch_bounds__(256) k_pack_migrate_fixed(AtomSoA a, const int
 // (index order), so messages - and with them the arrival order on the peer - are what they were, run after run.  A list holds
 // lc entries; a direction that overflows it belongs to a message that overflows its capacity (lc >= every capacity) and is sent
 // again exactly, from the lists of the counting chain, which are then built on demand (build_mig_lists).
-__global__ void __launch_bounds__(256) k_mig_scan(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                                                  Decomp D, int n, int *__restrict__ code, int *__restrict__ lost, int *__restrict__ cnt,
-                                                  int *__restrict__ lst, int lc)
+// (pb.on: MesoDomain::pbc of the atom first - the k_pbc launch of the rebuild; lost atoms are counted in cnt[28], which
+// k_mig_pack hands to the flag word the host reads and k_mig_read_hdr clears with the counters: no memset launch)
+struct PbcArgs { int on; double lo[3], hi[3]; int per[3]; int *image; };
+__global__ void __launch_bounds__(256) k_mig_scan(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                                  Decomp D, int n, int *__restrict__ code, int *__restrict__ cnt,
+                                                  int *__restrict__ lst, int lc, PbcArgs pb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double c[3] = {x[i], y[i], z[i]};
+    int *lost = cnt + 28;
+    double c[3] = {x[i], y[i], z[i]};
+    if (pb.on) {
+        const int img = pb.image[i];
+        int im[3] = {img & 1023, (img >> 10) & 1023, img >> 20};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if (!pb.per[d]) continue;
+            const double p = pb.hi[d] - pb.lo[d];
+            if (c[d] < pb.lo[d]) { c[d] += p; im[d] = (im[d] - 1) & 1023; }
+            if (c[d] >= pb.hi[d]) { c[d] -= p; c[d] = fmax(c[d], pb.lo[d]); im[d] = (im[d] + 1) & 1023; }
+        }
+        x[i] = c[0]; y[i] = c[1]; z[i] = c[2];
+        pb.image[i] = im[0] | (im[1] << 10) | (im[2] << 20);
+    }
     int s[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -560,7 +577,7 @@ __global__ void __launch_bounds__(256) k_mig_scan(const double *__restrict__ x, 
 // direction starts the host reads after the exchange (the segment of direction 13 = the atoms that stay)
 __global__ void __launch_bounds__(256) k_mig_pack(AtomSoA a, const int *__restrict__ cnt_dev, const int *__restrict__ lst, int lc, int n,
                                                   MigPlan P, int *__restrict__ dst_dev, int *__restrict__ dir_start, int ms,
-                                                  double *__restrict__ stage_send)
+                                                  double *__restrict__ stage_send, int *__restrict__ lost_out)
 {
     __shared__ int cnt[27], dst[27];
     const int t = threadIdx.x;
@@ -581,6 +598,7 @@ __global__ void __launch_bounds__(256) k_mig_pack(AtomSoA a, const int *__restri
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         if (t < 27) dst_dev[t] = dst[t];
         if (t == 0) {
+            *lost_out = cnt_dev[28];
             int leave = 0;
             for (int d = 0; d < 27; d++) leave += cnt[d];
             int run = 0;
@@ -607,7 +625,7 @@ __global__ void __launch_bounds__(256) k_mig_pack(AtomSoA a, const int *__restri
 __global__ void __launch_bounds__(64) k_mig_read_hdr(const double *__restrict__ stage_recv, MigPlan P, int *__restrict__ report, int *__restrict__ clear)
 {
     const int t = threadIdx.x;
-    if (clear && t < 27) clear[t] = 0;
+    if (clear && t < 32) clear[t] = 0;
     if (t < P.np) {
         const int *hdr = reinterpret_cast<const int *>(stage_recv + P.base_r[t]);
         int n = 0;
@@ -765,8 +783,10 @@ __global__ void __launch_bounds__(256) k_border_fill_pack(AtomSoA a, int beg, in
                                                           int *__restrict__ sendlist, const int *__restrict__ dir_start, MrPlan P, Shift27 sh,
                                                           int *__restrict__ d_mr, BinGeom bg, double *__restrict__ stage_send,
                                                           int *__restrict__ flags, int *__restrict__ report, int *__restrict__ img_cnt,
-                                                          int *__restrict__ img, int *__restrict__ vofs_out)
+                                                          int *__restrict__ img, int *__restrict__ vofs_out, int *__restrict__ zero, int nzero)
 {
+    // (zero: the ghost-cell counts the receiving kernel of this rebuild starts from - cleared here, ahead of the exchange)
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nzero; k += gridDim.x * blockDim.x) zero[k] = 0;
     __shared__ int wave_tot[27][4];
     __shared__ int ds[28], dst[27], pfill[27], pbase[27];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1132,15 +1152,15 @@ int Engine::migrate()
     mig_holes = false;
     Decomp D = make_decomp(boxlo, boxhi, prd, procgrid, myloc);
     int *code = gslot;   // scratch (rebuilt later in the rebuild)
-    HIPCHK(hipMemsetAsync(d_flags + 3, 0, sizeof(int), stream));
     int nchunk = (nlocal + 255) / 256;
     mig_lists_built = false;
-    if (async_counts && mig_caps_ready && mig_slim) {
+    if (mig_slim_now()) {
         // (leavers' lists by atomics, ranked when packed: migrate_inband)
         int rc = migrate_inband();
         tend("migrate");
         return rc;
     }
+    HIPCHK(hipMemsetAsync(d_flags + 3, 0, sizeof(int), stream));
     if (nlocal > 0) {
         hipLaunchKernelGGL(k_migrate_code, dim3(nchunk), dim3(256), 0, stream, cur.x[0], cur.x[1], cur.x[2], D, nlocal, code,
                            d_flags + 3);
@@ -1225,6 +1245,9 @@ void Engine::mig_update_caps(const std::vector<int> &send_n, const std::vector<i
 // counts, and an exact resend in a second exchange for the (rare) message that did not fit - zero-size messages are not posted, so
 // that exchange costs nothing when nobody needs it, and the two ranks of a message decide alike (the sender knows its count, the
 // receiver reads it in the header).  Called with the migration lists built (sendlist, d_dir_start).
+// the slim front of the migration runs this rebuild (it also wraps the atoms: reneighbor then skips k_pbc)
+bool Engine::mig_slim_now() const { return nranks > 1 && async_counts && mig_caps_ready && mig_slim; }
+
 // the direction-major list of every local atom (sendlist, d_dir_start) from the migration codes: the counting chain, on demand
 // when the slim front of the in-band migration ran (a message to send again exactly; stayers to compact for a sorting reorder)
 int Engine::build_mig_lists()
@@ -1273,11 +1296,15 @@ int Engine::migrate_inband()
         if (!mig_cnt) { HIPCHK(hipMalloc((void **)&mig_cnt, 32 * sizeof(int))); HIPCHK(hipMemsetAsync(mig_cnt, 0, 32 * sizeof(int), stream)); }
         if (nlocal > 0) {
             Decomp D = make_decomp(boxlo, boxhi, prd, procgrid, myloc);
-            hipLaunchKernelGGL(k_mig_scan, dim3((nlocal + 255) / 256), dim3(256), 0, stream, cur.x[0], cur.x[1], cur.x[2], D, nlocal, gslot, d_flags + 3,
-                               mig_cnt, mig_lst, lc);
+            PbcArgs pb;
+            pb.on = 1;          // (the rebuild's wrap: reneighbor skipped k_pbc for this path)
+            for (int d = 0; d < 3; d++) { pb.lo[d] = boxlo[d]; pb.hi[d] = boxhi[d]; pb.per[d] = periodic[d]; }
+            pb.image = cur.image;
+            hipLaunchKernelGGL(k_mig_scan, dim3((nlocal + 255) / 256), dim3(256), 0, stream, cur.x[0], cur.x[1], cur.x[2], D, nlocal, gslot,
+                               mig_cnt, mig_lst, lc, pb);
         }
         hipLaunchKernelGGL(k_mig_pack, dim3(std::max(1, std::min(8, (lc + 255) / 256)), 27), dim3(256), 0, stream, cur, mig_cnt, mig_lst, lc, nlocal, P,
-                           dst_dev, d_dir_start, ms, (double *)stage_send);
+                           dst_dev, d_dir_start, ms, (double *)stage_send, d_flags + 3);
     } else {
     hipLaunchKernelGGL(k_mig_hdr, dim3(1), dim3(64), 0, stream, d_dir_start, P, dst_dev, (double *)stage_send);
     if (nlocal > 0)
@@ -1533,7 +1560,7 @@ int Engine::halo_borders_multi_async()
     const int nchunk = (end - beg + 255) / 256;
     const int *nb_dev = estart + bargs.M;
     if (nchunk > 0) {
-        launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream);
+        launch_border_count(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_count, nchunk, stream, novf_pending ? fr_novf : nullptr);
         if (!launch_border_scan(chunk_count, chunk_offset, nchunk, d_dir_start, nb_dev, beg, std::min(bound_s, send_cap), d_flags, h_flags_dev, stream)) {
             HIPCHK(exclusive_scan_i32(sort_temp, sort_temp_bytes, chunk_count, chunk_offset, 27 * nchunk + 1, stream));
             launch_dir_starts_check(chunk_offset, nchunk, d_dir_start, nb_dev, beg, std::min(bound_s, send_cap), d_flags, stream);
@@ -1543,8 +1570,22 @@ int Engine::halo_borders_multi_async()
         }
     } else {
         HIPCHK(hipMemsetAsync(d_dir_start, 0, 28 * sizeof(int), stream));
+        if (novf_pending) HIPCHK(hipMemsetAsync(fr_novf, 0, sizeof(int), stream));
         for (int k = 0; k < 28; k++) h_flags[16 + k] = 0;
         h_flags[8] = 0; h_flags[9] = n_bulk;
+    }
+    novf_pending = false;
+    // ghosts in message order, their cells as runs (one kernel instead of unpack + count + scan + place + order + merge) when the
+    // list builder reads (start, count) per ghost cell: the tile builder with the plan in its prologue, bins no narrower than the
+    // ghost cutoff (a ghost cell is then fed by one source cell)
+    bool runs = border_runs && neigh_kernel == 1 && tile_fits && n_col <= tile_build_rowcap() && tile_plan == 0 && n_col >= 64;
+    for (int d = 0; d < 3; d++) runs = runs && geom.binsize[d] >= cutghost;
+    bool gcnt_cleared = false;
+    if (runs && mr_gcnt_n < bargs.M + 1) {
+        if (mr_gcnt) (void)hipFree(mr_gcnt);
+        mr_gcnt = nullptr;
+        mr_gcnt_n = bargs.M + 1;
+        HIPCHK(hipMalloc((void **)&mr_gcnt, (size_t)mr_gcnt_n * sizeof(int)));
     }
     Shift27 sh;
     for (int d = 0; d < 27; d++) for (int k = 0; k < 3; k++) sh.s[d][k] = shift27[3 * d + k];
@@ -1555,7 +1596,9 @@ int Engine::halo_borders_multi_async()
         const bool rec = mr_img_wanted() && img_zero_gen == img_alloc_gen;      // (... and the arrays were not regrown since)
         if (rec && !d_vofs) { HIPCHK(hipMalloc((void **)&d_vofs, 32 * sizeof(int))); }
         hipLaunchKernelGGL(k_border_fill_pack, dim3(nchunk), dim3(256), 0, stream, cur, beg, end, sl, chunk_offset, nchunk, sendlist, d_dir_start, P, sh,
-                           d_mr, geom, (double *)stage_send, d_flags, h_flags_dev + 64, rec ? img_cnt : nullptr, rec ? img : nullptr, d_vofs);
+                           d_mr, geom, (double *)stage_send, d_flags, h_flags_dev + 64, rec ? img_cnt : nullptr, rec ? img : nullptr, d_vofs,
+                           runs ? mr_gcnt : nullptr, runs ? bargs.M + 1 : 0);
+        gcnt_cleared = runs;
         mr_images_ready = rec;
         mr_img_stage = stage_send;
     } else {
@@ -1575,19 +1618,9 @@ int Engine::halo_borders_multi_async()
     TRY(xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data()));
     hipLaunchKernelGGL(k_border_unpack_hdr, dim3(1), dim3(64), 0, stream, (const double *)stage_recv, P, nmax - nlocal - 1, d_mr, d_flags,
                        h_flags_dev + 64);
-    // ghosts in message order, their cells as runs (one kernel instead of unpack + count + scan + place + order + merge) when the
-    // list builder reads (start, count) per ghost cell: the tile builder with the plan in its prologue, bins no narrower than the
-    // ghost cutoff (a ghost cell is then fed by one source cell)
-    bool runs = border_runs && neigh_kernel == 1 && tile_fits && n_col <= tile_build_rowcap() && tile_plan == 0 && n_col >= 64;
-    for (int d = 0; d < 3; d++) runs = runs && geom.binsize[d] >= cutghost;
     if (runs) {
-        if (mr_gcnt_n < bargs.M + 1) {
-            if (mr_gcnt) (void)hipFree(mr_gcnt);
-            mr_gcnt = nullptr;
-            mr_gcnt_n = bargs.M + 1;
-            HIPCHK(hipMalloc((void **)&mr_gcnt, (size_t)mr_gcnt_n * sizeof(int)));
-        }
-        HIPCHK(hipMemsetAsync(mr_gcnt, 0, (size_t)(bargs.M + 1) * sizeof(int), stream));
+        // (the ghost-cell counts were cleared by the border kernel ahead of the exchange, or are now)
+        if (!gcnt_cleared) HIPCHK(hipMemsetAsync(mr_gcnt, 0, (size_t)(bargs.M + 1) * sizeof(int), stream));
         if (bound_r > 0)
             hipLaunchKernelGGL(k_unpack_ghost_runs, dim3((bound_r + 255) / 256), dim3(256), 0, stream, cur, (const double *)stage_recv, P, d_mr, nlocal,
                                0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),

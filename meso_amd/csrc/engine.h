@@ -313,6 +313,8 @@ private:
     int *mig_cnt = nullptr, *mig_lst = nullptr;
     int mig_lst_n = 0;
     int build_mig_lists();
+    bool mig_slim_now() const;
+    bool novf_pending = false;      // the fused reorder left its overflow count for the border count kernel to clear
     bool mig_holes = false;         // several ranks: the migration left its leavers in place (holes) and appended the arrivals behind the
     int mig_span = 0, mig_nold = 0; // old atoms: the reorder's count walks mig_span atoms and skips the leavers among the first mig_nold
     bool reorder_fuses(long n) const;

@@ -1082,7 +1082,10 @@ int Engine::reorder_locals()
             FusedArgs a;
             fused_locals_args(a);
             fr_epoch++;
+            // (several ranks without a host round trip in the ghost stage: the border count that follows clears the overflow count)
+            a.novf_later = (nranks > 1 && mr_async_ok()) ? 1 : 0;
             launch_fused_rebuild(a, stream);
+            novf_pending = a.novf_later != 0;
             mig_holes = false;
             if (!async_ok()) HIPCHK(hipMemcpyAsync(d_flags + 1, estart + bargs.M, sizeof(int), hipMemcpyDeviceToDevice, stream));
             gathered = true;
@@ -1600,7 +1603,7 @@ int Engine::reneighbor()
     TRY(init_params());
     // one rank: nothing happens between the wrap and the reorder, which reads the coordinates anyway - wrapped there
     wrap_in_reorder = nranks == 1 && !reorder_sort && nlocal > 0;
-    if (!wrap_in_reorder) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);
+    if (!wrap_in_reorder && !mig_slim_now()) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);      // (the slim migration front wraps)
     TRY(migrate());
     ghosts_binned = false;
     fused_active = false;

@@ -75,7 +75,7 @@ void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s
 // ---- halo: border lists + pack (comm_meso.cu:41-186, atom_vec_dpd_atomic_meso.cu:61-244) --------------
 // 26 directions d = (dx+1) + 3*(dy+1) + 9*(dz+1), centre (13) unused.
 void launch_border_count(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi,
-                         const int *dim_active, int *chunk_count /*[27][nchunk]*/, int nchunk, hipStream_t s);
+                         const int *dim_active, int *chunk_count /*[27][nchunk]*/, int nchunk, hipStream_t s, int *clear = nullptr);
 void launch_border_fill(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi,
                         const int *dim_active, const int *chunk_offset /*[27][nchunk] exclusive, global*/,
                         int nchunk, int *sendlist, hipStream_t s);

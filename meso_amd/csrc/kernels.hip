@@ -568,10 +568,11 @@ void launch_invert_perm(const int *perm_from, int *perm_to, int n, hipStream_t s
 __global__ void __launch_bounds__(BORDER_CHUNK) k_border_count(const double *__restrict__ x,
                                                                const double *__restrict__ y,
                                                                const double *__restrict__ z, int beg, int end,
-                                                               Slabs sl, int *__restrict__ chunk_count, int nchunk)
+                                                               Slabs sl, int *__restrict__ chunk_count, int nchunk, int *__restrict__ clear)
 {
     // per-wave ballots for all 27 directions, ONE barrier, then 27 threads add the wave totals
     __shared__ int wave_tot[27][BORDER_CHUNK / 64];
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;      // (a word the previous kernels are done with: no memset launch)
     int i = beg + blockIdx.x * BORDER_CHUNK + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int flags = 0;
@@ -645,13 +646,16 @@ void launch_border_fill_code(const int *code, int beg, int end, const int *chunk
 }
 
 void launch_border_count(const AtomSoA &a, int beg, int end, const double *slab_lo, const double *slab_hi, const int *,
-                         int *chunk_count, int nchunk, hipStream_t s)
+                         int *chunk_count, int nchunk, hipStream_t s, int *clear)
 {
-    if (nchunk <= 0) return;
+    if (nchunk <= 0) {
+        if (clear) (void)hipMemsetAsync(clear, 0, sizeof(int), s);
+        return;
+    }
     Slabs sl;
     for (int d = 0; d < 3; d++) { sl.lo[d] = slab_lo[d]; sl.hi[d] = slab_hi[d]; }
     hipLaunchKernelGGL(k_border_count, dim3(nchunk), dim3(BORDER_CHUNK), 0, s, a.x[0], a.x[1], a.x[2], beg, end, sl,
-                       chunk_count, nchunk);
+                       chunk_count, nchunk, clear);
 }
 
 __global__ void __launch_bounds__(BORDER_CHUNK) k_border_fill(const double *__restrict__ x,

@@ -533,6 +533,7 @@ struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiv
 
 // Arguments of the three-launch rebuild of one rank (rebuild.hip)
 struct FusedArgs {
+    int novf_later;            // no ghost stage: the overflow count is cleared by the caller's next kernel, not by a memset launch
     const int *skip;           // several ranks: migration code of every atom below skip_n (13 = stays); leavers are holes the count skips,
     int skip_n;                // arrivals sit behind skip_n - the stayers are not compacted before the reorder
     AtomSoA src, dst;          // old order -> new order (ghosts go behind the n locals of dst)

@@ -557,7 +557,8 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
     else hipLaunchKernelGGL(k_fr_place<false>, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     if (a.gttot && a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
     if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(a.gorder ? a.ngorder : ntg), dim3(FR_THREADS), dyn3, s, a);
-    else (void)hipMemsetAsync(a.novf, 0, sizeof(int), s);      // (the ghost kernel clears the overflow count otherwise)
+    else if (!a.novf_later) (void)hipMemsetAsync(a.novf, 0, sizeof(int), s);      // (the ghost kernel clears the overflow count otherwise;
+                                                                                  // novf_later: the caller's next kernel does)
 }
 
 int fused_direct_tiles() { return FR_DIRECT_TILES; }
