@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     }
     // small launches (two or four lanes per atom: every wave's latency chain counts): what the step-boundary epilogue needs is
     // requested now and waits in registers (16 VGPRs: only the variants with registers to spare)
-    constexpr bool PRE = NPART > 1;
+#ifndef RG_PRE_ALL
+#define RG_PRE_ALL 0          // measured: the prefetch in the one-lane variant too (93 VGPRs): 64^3 unchanged, 48^3 -2.3 %
+#endif
+    constexpr bool PRE = NPART > 1 || (RG_PRE_ALL && FAST && TY == 0);
     NvePre npre;
     if (PRE && a.fuse_nve && mine && part == 0) nve_prefetch(a.nve, i, npre);
     const int ob = w * APW + slot;                           // my atom's slot in the workgroup's accumulators
