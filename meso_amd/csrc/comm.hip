@@ -610,6 +610,14 @@ __global__ void __launch_bounds__(256) k_mig_pack(AtomSoA a, const int *__restri
     if (d == 13 || p < 0) return;
     const int m = min(cnt[d], lc);
     const int *l = lst + (size_t)d * lc;
+    // (the direction's list in LDS when it fits: the ranking loop then reads one LDS word per step, the same for every lane)
+    __shared__ int ll[2048];
+    const bool staged = m <= 2048;
+    if (staged) {
+        for (int e = t; e < m; e += blockDim.x) ll[e] = l[e];
+        __syncthreads();
+        l = ll;
+    }
     for (int k = blockDim.x * blockIdx.x + t; k < m; k += gridDim.x * blockDim.x) {
         const int i = l[k];
         int rank = 0;
@@ -957,10 +965,23 @@ __global__ void __launch_bounds__(256) k_unpack_ghost_runs(AtomSoA a, const doub
         v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;
         v.w = __uint_as_float(signature(seed, pp.x, v.x, v.y, v.z));
         veloc4[g] = v;
+        // run heads and lengths from the wave's own lanes where they can be had there (consecutive lanes hold consecutive ghosts): the
+        // predecessor's code by shuffle, the next head inside the wave from the ballot of heads; memory only across wave boundaries
         const int code = r.y;
-        if (g == 0 || code_of(g - 1) != code) {
-            int len = 1;
-            while (g + len < ng && code_of(g + len) == code) len++;
+        const int lane = threadIdx.x & 63;
+        const int up = __shfl_up(code, 1, 64);
+        const bool head = g == 0 || (lane == 0 ? code_of(g - 1) : up) != code;
+        const unsigned long long hm = __ballot(head);
+        if (head) {
+            const unsigned long long later = lane == 63 ? 0ull : hm >> (lane + 1);
+            int len;
+            if (later) len = __ffsll((long long)later);               // the next head is `len` lanes on
+            else {
+                // the run reaches the end of the wave's ghosts: the rest of it, if any, lies with the next wave
+                const int last = min(g + (63 - lane), ng - 1);        // last ghost of this wave's lanes
+                len = last - g + 1;
+                while (g + len < ng && code_of(g + len) == code) len++;
+            }
             if ((u32)code >= (u32)M) flags[0] = 200003;
             else {
                 gstart[code] = g;
