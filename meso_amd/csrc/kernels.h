@@ -157,6 +157,7 @@ struct PairArgs {
     const float *poly;    // dpd/polyforce/meso: [ntypes^2][MESO_POLY_PITCH] conservative-force polynomials; null otherwise
     int rng;              // fp32 styles: 0 TEA Gaussian (dpd/fast/meso), 1 logistic map (dpd/mini/meso), 2 TEA uniform (tableforce)
     int npart;            // ring kernel: lanes per atom (0: chosen from the launch size; 1, 2, 4)
+    int lds_veloc;        // ring kernel (set by its launcher): in-group partners' velocity records from the workgroup's LDS copy
     int share;            // ring kernel: Newton pairing inside a workgroup allowed (end == nlocal or a multiple of 256)
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;

@@ -128,6 +128,9 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     }
     // small launches (two or four lanes per atom: every wave's latency chain counts): what the step-boundary epilogue needs is
     // requested now and waits in registers (16 VGPRs: only the variants with registers to spare)
+#ifndef RG_LDS_VELOC
+#define RG_LDS_VELOC 1        // in-group partners' velocity records from the workgroup's LDS copy (one-lane variant only, see issue())
+#endif
 #ifndef RG_PRE_ALL
 #define RG_PRE_ALL 0          // measured: the prefetch in the one-lane variant too (93 VGPRs): 64^3 unchanged, 48^3 -2.3 %
 #endif
@@ -235,7 +238,19 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
             if (WIDE) pm = ringm[(qhead + lane) & (RG_RING - 1)];
             const u32 joff = (WIDE ? pe : (pe & RG_INDEX_MASK)) << 4;
             if (!NT1) pc2.w = __uint_as_float((u32)ringt[(qhead + lane) & (RG_RING - 1)]);     // (a fourth gather per hit before)
-            pv2 = buf_load4(rv, joff);
+            if (RG_LDS_VELOC && NPART_ == 1 && FAST && a.lds_veloc) {
+            // a partner of this workgroup's group (the pairs evaluated once for both, 64 % of the hits) has its velocity record in
+            // the LDS copy of the wave that owns it: those lanes read it there and give the gather an out-of-range offset (one lane
+            // per atom, launches of several rounds of waves: 64^3 fused launch 121.9 -> 119.7 us, +1.2 % steps/s; 48^3 44.7 -> 46.6 us
+            // alone and two lanes per atom 19.0 -> 20.4 us, so not there: PairArgs::lds_veloc, set by the launcher from the size;
+            // the fp64 style lost 4 % with it at 64^3: fp32 kernels only)
+            const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0;
+            const u32 pl = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;                // (in-group: < NB)
+            const u32 pw = inwg ? pl / (u32)APW : (u32)w, ps = inwg ? pl % (u32)APW : (u32)(lane % APW);
+            const float4 vl = *(const float4 *)((const char *)own_v + ((long)pw - (long)w) * (long)per_wave + (size_t)ps * 16);
+            const float4 vg = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
+            pv2 = inwg ? vl : vg;
+            } else pv2 = buf_load4(rv, joff);
         }
         pn = nb;
         qhead += nb;
@@ -376,6 +391,8 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
 {
     int n = p.end - p.beg;
     if (n <= 0) return;
+    PairArgs pl = p;
+    pl.lds_veloc = n >= 700000 ? 1 : 0;      // (see issue(): pays from about two rounds of waves on)
     const bool nt1 = p.ntypes == 1;
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * (fast ? 8 * 4 : N_COEFF * 8);
     // more than 2^25 atoms (locals + ghosts): the record word cannot hold owner lane, pairing flag and index any more
@@ -404,10 +421,10 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     const bool plain = p.rng == 0 && !p.poly && !p.ftab;
 #define RG_LAUNCH2(F, A, B, C, P)                                                                               \
     do {                                                                                                        \
-        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0, P>), grid, block, sm, s, p);               \
-        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P>), grid, block, sm, s, p);    \
-        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P>), grid, block, sm, s, p);    \
-        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P>), grid, block, sm, s, p);                    \
+        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0, P>), grid, block, sm, s, pl);               \
+        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P>), grid, block, sm, s, pl);    \
+        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P>), grid, block, sm, s, pl);    \
+        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P>), grid, block, sm, s, pl);                    \
     } while (0)
     // (the fp64 style has no variants: always "plain")
 #define RG_LAUNCH(F, A, B, C)                                   \
