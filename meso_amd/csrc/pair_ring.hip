@@ -97,12 +97,15 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     }
     const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (NT1 ? 0 : RG_RING) + (WIDE ? RG_RING : 0);
+    const size_t per_wave = RG_RING * 16 + (NT1 ? 0 : RG_RING) + (WIDE ? RG_RING : 0);
     u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
-    char *wb = (char *)smem + off + 3 * 64 * RG_WAVES * 8 + (size_t)w * per_wave;      // (accumulator area sized for NPART = 1)
-    float4 *own_c = (float4 *)wb;
-    float4 *own_v = own_c + 64;
-    float4 *ring = own_v + 64;          // (partner x, y, z, record word): the coordinate is not gathered twice
+    // the workgroup's atoms, coordinate and velocity records, by group-local index (wave w owns [64 w, 64 w + 64): one lane per atom):
+    // own_c / own_v are this wave's part; a partner of another wave of the group is looked up in own_v_all (issue())
+    float4 *own_c_all = (float4 *)((char *)smem + off + 3 * 64 * RG_WAVES * 8);      // (accumulator area sized for NPART = 1)
+    float4 *own_v_all = own_c_all + 64 * RG_WAVES;
+    float4 *own_c = own_c_all + 64 * w, *own_v = own_v_all + 64 * w;
+    char *wb = (char *)(own_v_all + 64 * RG_WAVES) + (size_t)w * per_wave;
+    float4 *ring = (float4 *)wb;        // (partner x, y, z, record word): the coordinate is not gathered twice
     unsigned char *ringt = (unsigned char *)(ring + RG_RING);     // several types: the partner's type next to its record
     unsigned char *ringm = ringt + (NT1 ? 0 : RG_RING);           // WIDE: owner lane | pairing flag << 6
 
@@ -246,8 +249,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
             // the fp64 style lost 4 % with it at 64^3: fp32 kernels only)
             const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0;
             const u32 pl = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;                // (in-group: < NB)
-            const u32 pw = inwg ? pl / (u32)APW : (u32)w, ps = inwg ? pl % (u32)APW : (u32)(lane % APW);
-            const float4 vl = *(const float4 *)((const char *)own_v + ((long)pw - (long)w) * (long)per_wave + (size_t)ps * 16);
+            const float4 vl = own_v_all[inwg ? pl : (u32)(64 * w + lane)];           // (one lane per atom: group-local index = slot)
             const float4 vg = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
             pv2 = inwg ? vl : vg;
             } else pv2 = buf_load4(rv, joff);
