@@ -1296,8 +1296,9 @@ int Engine::rebuild_fused()
     fused_locals_args(a);
     const int par = (int)(fr_epoch & 1u);
     a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
-    // (the separate-plan option reads gstart by differences: every tile runs then)
-    const bool skip_tiles = tile_plan == 0 && fr_ngorder > 0;
+    // (the separate plan kernel - option tile_plan, and rows narrower than 64 entries, whose stage cannot lend the inline plan its
+    // run tables - reads gstart by differences: every tile runs then.  The same predicate as plan_inline in build_cells_and_table.)
+    const bool skip_tiles = tile_plan == 0 && n_col >= 64 && fr_ngorder > 0;
     a.gorder = skip_tiles ? fr_gorder : nullptr; a.ngorder = fr_ngorder; a.gcnt_out = skip_tiles ? fr_gcnt : nullptr;
     // few tiles run: each adds up the tile totals in front of it directly (no supertile launch) up to 16 Ki tiles
     a.gstot = bargs.M / fused_gtile_codes() > (skip_tiles ? 16384 : fused_direct_tiles()) ? fr_gstot[0] : nullptr;

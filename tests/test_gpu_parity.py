@@ -694,6 +694,42 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
             assert np.array_equal(a, b)
 
 
+def test_short_cutoff_rows_of_32_survive_several_fused_rebuilds(Meso, oracle):
+    """cutoff 0.5 + skin 0.2: rows of 32 entries (n_col < 64), for which the list builder's inline plan is off and the separate plan
+    kernel reads the ghost starts of EVERY halo bin by differences - the fused rebuild must then write all of them (ADVICE r3:
+    with the ghost tiles skipped, entries of an earlier rebuild survived from the second rebuild on).  23 steps (4 rebuilds):
+    default path == chain of launches (fused_rebuild 0) bit for bit, neighbour sets after the last rebuild == the oracle's."""
+    from oracle.meso_sim import MesoRefSim
+    L = 10
+    x, v, lo, hi = make_box(L)
+    res = []
+    for opts in ((), (("fused_rebuild", 0),), (("async_counts", 0), ("ghost_epilogue", 0))):
+        m = Meso()
+        for k, val in opts:
+            m.set_option(k, val)
+        m.read_atoms(x, v, lo, hi); m.neighbor(0.2); m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style("dpd/meso", 0.5, DP_RUN["seed"]); m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 0.5); m.timestep(0.005)
+        m.setup()
+        assert m.neigh_info()["n_col"] == 32
+        m.run(21)          # the force of step 21 is computed on the list of step 20's rebuild
+        res.append((m.gather(), m.gather(by_tag=False)[3], m.neigh_table(), m.counts()[0]))
+        m.close()
+    for other in res[1:]:
+        for a, b in zip(res[0][0][:3], other[0][:3]):
+            assert np.array_equal(a, b)
+    s = MesoRefSim(x, v, lo, hi, skin=0.2, every=5)
+    s.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 0.5)
+    s.setup(); s.run(21)
+    (xg, vg, fg, _, _), tag, (count, table), nl = res[0]
+    d = xg - s.x
+    d -= np.round(d / (hi - lo)) * (hi - lo)
+    assert np.abs(d).max() < 1e-9 and np.abs(fg - s.f).max() <= 1e-8 * np.abs(s.f).max()
+    # rows by tag: the device's entries are storage indices (locals: tag of the atom; ghosts: the tag of their source)
+    assert count.sum() == s.count.sum()
+    for i in range(nl):
+        assert count[i] == s.count[tag[i] - 1]
+
+
 def test_neigh_modify_check_yes_rebuilds_on_displacement_only(Meso):
     """neigh_modify delay 0 every 1 check yes (Neighbor::decide + check_distance, src/neighbor.cpp:1216-1300): the list is
     rebuilt only when some atom has moved half the skin - far fewer rebuilds than `check no`, the same sigma = 0 trajectory
