@@ -46,7 +46,10 @@ def parse():
     ap.add_argument("--dump-state", default=None, help="A/B of library builds: save x, v, f of rank 0's atoms (by tag) after the timed region as .npy")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="let several RCCL ranks name the same GPU (a probe: RCCL normally refuses it - the refusal is the result)")
-    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable); the line then says \"ablation\": true")
+    ap.add_argument("--other-boxes", default="25,48",
+                    help="after the timed region of the default workload (64^3, 1 GPU): short passes of the other boxes of the reference's "
+                         "protocol (README.md:27-35: case 25 / 48 / 64), reported under \"other_boxes\"; '' = none")
     return ap.parse_args()
 
 
@@ -124,6 +127,45 @@ def cpu_baseline(L, x, v, lo, hi, every, steps):
     except Exception as e:      # noqa: BLE001 - the baseline must never break the bench line
         out["reference_one_core"] = {"error": repr(e)[:200]}
     return out
+
+
+def other_box(Meso, make_box, L, a):
+    """One of the other boxes of the reference's protocol (README.md:27-35, example/simple/stat.sh:3), same deck and options: W warm-up
+    steps, K steps timed between device synchronisations.  Not the headline: a record the driver can see."""
+    x, v, lo, hi = make_box(L)
+    m = Meso(0)
+    for kv in a.opt:
+        k, val = kv.split("=")
+        m.set_option(k, float(val))
+    m.read_atoms(x, v, lo, hi)
+    m.neighbor(0.3)
+    m.neigh_modify(delay=0, every=a.every, check=False)
+    m.pair_style(a.style, 1.0, 419084618)
+    m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    m.timestep(0.005)
+    m.setup()
+    m.run(max(a.warmup, 300))           # (past the thermostat's start-up overshoot)
+    m.sync()
+    t0 = time.perf_counter()
+    m.run(a.steps)
+    m.sync()
+    dt = time.perf_counter() - t0
+    out = {"box": L, "natoms": len(x), "value": a.steps / dt, "unit": "timesteps/s", "steps": a.steps, "ms_per_step": 1e3 * dt / a.steps,
+           "M_particle_steps_per_s": a.steps / dt * len(x) / 1e6, "temperature_end": m.temperature(), "kernel_variant": m.pair_kernel_name()}
+    m.close()
+    return out
+
+
+def _kernel_source_hash():
+    """Hash of the force kernel's sources: a committed profile names the hash it was collected for (tools/update_profiles.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pair_ring.hip", "meso_device.h", "kernels.h"):
+        try:
+            h.update(open(os.path.join(ROOT, "meso_amd", "csrc", f), "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
 
 
 def self_launch(a):
@@ -307,8 +349,10 @@ def main():
     variant = m.pair_kernel_name()
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "force_kernel_profile.json")))
+        # (... and the same SOURCE: the instantiation's name survives a change of its body - ADVICE r3)
         if (L == tj.get("box") and a.style == tj.get("style") and a.gpus == 1 and variant
-                and _norm_kernel(tj.get("kernel_variant", "")) == _norm_kernel(variant)):
+                and _norm_kernel(tj.get("kernel_variant", "")) == _norm_kernel(variant)
+                and tj.get("kernel_source_hash") == _kernel_source_hash()):
             traffic = tj["traffic_bytes_per_launch"]
             traffic_source = "profiles/force_kernel_profile.json (%s; collected at %s)" % (tj.get("source", "rocprofv3 --pmc"), tj.get("head", "?"))
             # what the counters of the same profile say bounds the kernel (not HBM): profile-derived, not measured in this run
@@ -341,7 +385,16 @@ def main():
                      "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "kernel_variant": variant, "bytes_per_launch": b_pair_only,
                      "us_per_launch": t_alone * 1e6, "fused": fused_rec, "limiter_from_profile": limiter},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
+        # the whole step against the whole-step floor of SURVEY.md 8(d) (context, not the graded figure): pair 195 + merge 88 + NVE
+        # 108 + 84 + list build 175 / 5 = 510 B per particle-step at fp32 with a rebuild every 5 steps
+        "whole_step": {"bytes_per_particle": 510, "bytes_per_step": 510.0 * n, "achieved": 510.0 * n * steps_per_s / 1e9, "unit": "GB/s",
+                       "frac": 510.0 * n * steps_per_s / 1e9 / HBM_PEAK_GBS,
+                       "note": "SURVEY.md 8(d) floor for fp32, rebuild every 5; whole job over %d GPU(s)" % a.gpus},
+        # any engine option passed on the command line reaches the timed region: the line says so
+        "ablation": bool(a.opt),
     }
+    if a.opt:
+        line["options"] = list(a.opt)
     if world > 1:
         line["n_ranks_seen"] = m.comm_count()      # ncclCommCount of the engine's communicator
     if xstats:
@@ -351,6 +404,16 @@ def main():
         line["exchange_us_per_step"] = {k: {"calls": v["calls"], "device": 1e3 * v["ms_device"] / a.profile_steps, "wire_and_peer_wait": 1e3 * v["ms_wire"] / a.profile_steps,
                                             "back": 1e3 * v["ms_back"] / a.profile_steps, "bytes_per_call": v["bytes"] / max(v["calls"], 1)}
                                         for k, v in xstats.items()}
+    # north_star: throughput on the 25^3 / 48^3 / 64^3 boxes - the other two as short passes behind the timed region (N = 1, the
+    # default workload only), so that they reach the driver's record
+    if rank == 0 and a.gpus == 1 and L == 64 and bonds is None and a.other_boxes:
+        m.close()
+        line["other_boxes"] = []
+        for ob_l in [int(t) for t in a.other_boxes.split(",") if t]:
+            try:
+                line["other_boxes"].append(other_box(Meso, make_box, ob_l, a))
+            except Exception as e:      # noqa: BLE001 - must never break the headline
+                line["other_boxes"].append({"box": ob_l, "error": repr(e)[:200]})
     # CPU baseline: timed on rank 0 at N = 1 only; the N > 1 lines of the same box re-use that sample (scratch file)
     cache = os.path.join(ROOT, "gpurun_out", "cpu_baseline_%d_%d.json" % (L, a.every))
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and bonds is None:

@@ -176,6 +176,12 @@ int meso_neigh_info(meso_ctx *ctx, int *n_col, int *max_count, double *avg_count
 /* row-major copy of the neighbour table: table[i*stride + p], rows of atoms in device order */
 int meso_neigh_download(meso_ctx *ctx, int *count, int *table, int stride);
 int meso_merged_download(meso_ctx *ctx, float *coord4, float *veloc4, int nall);
+/* tagged rows (round 4; no counterpart in the reference, whose rows keep "core from the front, skin from the back",
+ * neigh_build_meso.cu:91-115): *tagged = 1 when the table in use carries, above the 25 index bits of an entry, its distance shell
+ * at build time (bits 28..30: 0 = r^2 < base, s >= 1: r^2 in [base + (s-1)/k, base + s/k)), the mirror bit (31: partner in the same
+ * aligned group of `group` atoms, lower index) and the pair-once bit (25: same group, higher index).  raw != NULL: the table as
+ * stored, bits included, laid out like meso_neigh_download's. */
+int meso_neigh_tags(meso_ctx *ctx, int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride);
 /* per-phase device time (ms, HIP events on the engine's stream) accumulated since the last reset;
  * names: "pair","neigh","nve","merge","halo","reorder","bin","total_steps" */
 int meso_timer_reset(meso_ctx *ctx);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "meso_compute_pressure": (_i, [_vp, C.POINTER(_d)]),
     "meso_neigh_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_d), C.POINTER(_i64)]),
     "meso_neigh_download": (_i, [_vp, _vp, _vp, _i]),
+    "meso_neigh_tags": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), _vp, _i]),
     "meso_merged_download": (_i, [_vp, _vp, _vp, _i]),
     "meso_timer_reset": (_i, [_vp]),
     "meso_timer_get": (_i, [_vp, _cp, C.POINTER(_d), C.POINTER(_i64)]),
@@ -102,6 +103,8 @@ def load():
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("MESO_LIB") and not hasattr(lib, name):
+                continue              # A/B timing against an OLDER build (tools/ab_boxes.sh): entry points added since are simply absent
             fn = getattr(lib, name)   # AttributeError if the .so does not export the symbol
             fn.restype = res
             fn.argtypes = args

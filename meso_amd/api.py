@@ -337,6 +337,18 @@ class Meso:
         self._ck(self.lib.meso_neigh_download(self._h, _p(count), _p(table), stride))
         return count, table
 
+    def neigh_tags(self, raw=False, stride=None):
+        """Tag geometry of the table in use (meso_neigh_tags); raw=True: also the table as stored, shell / pairing bits included."""
+        t, g = C.c_int(), C.c_int()
+        b, k, e = C.c_double(), C.c_double(), C.c_double()
+        stride = self.neigh_info()["n_col"] if stride is None else stride
+        tab = np.zeros((self.counts()[0], stride), np.int32) if raw else None
+        self._ck(self.lib.meso_neigh_tags(self._h, C.byref(t), C.byref(g), C.byref(b), C.byref(k), C.byref(e), _p(tab) if raw else None, stride))
+        out = {"tagged": bool(t.value), "group": g.value, "base": b.value, "k": k.value, "eps": e.value}
+        if raw:
+            out["table"] = tab.view(np.uint32)
+        return out
+
     def merged(self):
         nl, ng, _ = self.counts()
         c4 = np.empty((nl + ng, 4), np.float32)

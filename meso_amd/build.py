@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libmeso_hip.so")
-SOURCES = ["kernels.hip", "pair_ring.hip", "brick.hip", "rebuild.hip", "bond.hip", "sort.hip", "engine.hip", "restart.hip", "comm.hip", "script.hip", "capi.hip"]
+SOURCES = ["pair_ring.hip", "pair_ring_dp.hip", "kernels.hip", "brick.hip", "rebuild.hip", "bond.hip", "sort.hip", "engine.hip", "restart.hip", "comm.hip", "script.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -21,12 +21,14 @@ def _deps(src):
         if f.endswith(".h"):
             d.append(os.path.join(CSRC, f))
     d.append(os.path.join(HERE, "..", "include", "meso_hip.h"))
+    if src == "pair_ring_dp.hip":
+        d.append(os.path.join(CSRC, "pair_ring.hip"))
     return d
 
 
 # per-file flags.  pair_ring.hip: the SLP vectoriser packs two of the three coordinate differences of a distance into v_pk_*_f32
 # and pays two v_mov per entry for the register pairs (7 instead of 6 instructions, profiles/r03_isa_pair_ring.txt): 103 -> 101 us
-EXTRA = {"pair_ring.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"pair_ring.hip": ["-fno-slp-vectorize"], "pair_ring_dp.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src):

@@ -183,12 +183,15 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 // gain as well although 8 atoms are staged per own atom instead of 3.4 (staging is a small part; the finer grain hides the
 // staging latency of one workgroup behind the scans of the seven others): 32^3 77 -> 52 us, 64^3 303 -> 265, 128^3 2257 -> 1784.
 // The 4-brick remains the fallback when a 2-brick neighbourhood nears its LDS stage (which does not grow).
-template <int E>
+template <int E, bool TAGS>
 __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3 : 2) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
                                                               int n_col, int *__restrict__ count, int *__restrict__ table,
-                                                              int *__restrict__ overflow, int split, int dbg)
+                                                              int *__restrict__ overflow, int split, int dbg, RowTagArgs tg)
 {
 #pragma clang fp contract(fast)
+    // shell walk (see RowTagArgs, kernels.h): the launch's first workgroup opens a new displacement account for the list
+    if (tg.disp && blockIdx.x == 0)
+        for (int k = threadIdx.x; k < MESO_DISP_SLOTS * MESO_DISP_SUB; k += blockDim.x) tg.disp[(size_t)k * MESO_DISP_PITCH] = 0.f;
     constexpr int CODES = E * E * E, H = E + 2, NHB = H * H * H, THREADS = E == 4 ? BRK_THREADS : TB2_THREADS, WAVES = THREADS / 64;
     const int maxh = E == 4 ? g.maxh : g.maxh2;
     // staged neighbourhood, SoA (candidate reads are consecutive slots); sized at launch for g.maxh halo atoms, so denser
@@ -465,7 +468,16 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                         // Every entry written is a valid halo slot, the overflow is reported below and ends the run, as it did.)
                         const int have = min(nrow[t], n_col - 1);
                         const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                        if (hit) (myrow(t) + have)[cnt] = (unsigned short)cs;
+                        // the entry's distance shell at build time rides in the top three bits of its 16-bit slot (tg.on; slots < 8192):
+                        // shell 0 = inside the cutoff, s >= 1: d in [base + (s - 1) / k, base + s / k).  v_cvt_u32_f32 saturates
+                        // negative arguments to 0 (written as an instruction: the C conversion is undefined there); 3 VALU per step
+                        u32 ent = (u32)cs;
+                        if (TAGS) {
+                            u32 sh;
+                            asm("v_cvt_u32_f32 %0, %1" : "=v"(sh) : "v"(__builtin_fmaf(d, tg.k, tg.off)));
+                            ent |= sh << 13;
+                        }
+                        if (hit) (myrow(t) + have)[cnt] = (unsigned short)ent;
                         nrow[t] += __popcll(m);
                     }
                 }
@@ -502,8 +514,19 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                 for (int e0 = 0; e0 < padmax; e0 += 16) {
                     const int e = e0 + el;
                     if (e < pad_l) {
-                        int val = i_l;
-                        if (e < nn_l) val = (int)hgi[row_l[e]];
+                        int val = TAGS ? (int)((u32)i_l | MESO_ROW_PAD) : i_l;
+                        if (e < nn_l) {
+                            const u32 ent = row_l[e];
+                            if (TAGS) {
+                                // shell into bits 28..30; Newton-pairing class of the entry for the force kernel's groups of
+                                // (1 << tg.gshift) atoms: same group and lower index = mirrored (bit 31: never looked at by a pairing
+                                // launch), same group and higher = evaluated once for both (bit 25)
+                                const u32 j = hgi[ent & 0x1FFFu];
+                                const bool same = ((j ^ (u32)i_l) >> tg.gshift) == 0u, lower = j < (u32)i_l;
+                                const u32 fl = same ? (lower ? MESO_ROW_MIRROR : MESO_ROW_SHARED) : 0u;
+                                val = (int)(j | ((ent & 0xE000u) << 15) | fl);
+                            } else val = (int)hgi[ent];
+                        }
                         dst[(size_t)(e0 >> 3) * 512] = val;
                     }
                 }
@@ -629,8 +652,9 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
 // even on a deck without a single exclusion (scalar-register spills of the larger kernel) and a third of its occupancy
 // while the tags of the neighbourhood were staged in LDS.
 __global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nlocal, int n_col, int *__restrict__ count,
-                                                          int *__restrict__ table)
+                                                          int *__restrict__ table, u32 imask)
 {
+    // (imask: the index bits of an entry - tagged rows carry shell and pairing bits above them, which travel with a kept entry)
     // FOUR atoms at a time per wave, 16 lanes each: the filter is a chain of dependent memory round trips per atom (special
     // list and count, row entries, their tags), so its speed is the number of atoms in flight (one atom per wave: 250 us on a
     // melt of 1 M chain beads, four: see profiles/r02_notes.md)
@@ -669,7 +693,7 @@ __global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nloca
             const int e = e0 + l16;
             const bool in = e < n;
             const int j = in ? row[(size_t)(e >> 3) * 512 + (e & 7)] : i;
-            const int tg = ex.tagc[j];
+            const int tg = ex.tagc[(u32)j & imask];
             bool keep = in;
             for (int sp = 0; sp < min(nspmax, 16); sp++) keep = keep & (__shfl(sp_l, (lane & 48) + sp, 64) != tg);
             for (int sp = 16; sp < nsp; sp++) keep = keep & (ex.special[(size_t)i * ex.msp + sp] != tg);
@@ -680,7 +704,7 @@ __global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nloca
         }
         if (on) {
             const int e = nout + l16;
-            if (e < ((nout + 7) & ~7)) row[(size_t)(e >> 3) * 512 + (e & 7)] = i;
+            if (e < ((nout + 7) & ~7)) row[(size_t)(e >> 3) * 512 + (e & 7)] = (int)((u32)i | ~imask);     // (tagged rows: MESO_ROW_PAD)
             if (l16 == 0) count[i] = nout;
         }
     }
@@ -692,10 +716,15 @@ void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s)
     hipLaunchKernelGGL(k_brick_plan, dim3(brick_grid(g)), dim3(256), 0, s, g, overflow);
 }
 
+// largest LDS stage (halo atoms) whose slots leave room for the three shell bits of a staged row entry
+int tile_build_tag_slots() { return 8192; }
+
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
-                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s)
+                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s, const RowTagArgs *tags)
 {
     if (g.nactive <= 0) return;
+    RowTagArgs tg = {};
+    if (tags) tg = *tags;
     // (the scan's expanded distance form loses < 1e-4 absolute to cancellation: the list cutoff is widened by more than that)
     if (TB_EXPANDED) rc2 += 4.0e-4f;
     // few bricks (small boxes, sub-boxes of many ranks): several workgroups share a brick as long as all of them still fit the
@@ -708,8 +737,13 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         g2.nactive = g.order2 ? g.norder2 : g.M / 8;
         const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
         const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2 + TB_ROWPAD * 2;
-        if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-        hipLaunchKernelGGL(k_tile_build<2>, tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg);
+        if (tg.on) {
+            if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+            hipLaunchKernelGGL((k_tile_build<2, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, tg);
+        } else {
+            if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+            hipLaunchKernelGGL((k_tile_build<2, false>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, tg);
+        }
     } else {
     int split = 1;
     while (split < 4 && occupied * split * 2 <= 900) split *= 2;
@@ -717,12 +751,18 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
     const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2 + TB_ROWPAD * 2;
     if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
-    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    hipLaunchKernelGGL(k_tile_build<4>, tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg);
+    if (tg.on) {
+        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((k_tile_build<4, true>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, tg);
+    } else {
+        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((k_tile_build<4, false>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, tg);
+    }
     }
     if (excl && excl->tagc && nlocal > 0) {
         const int nw = (nlocal + 63) / 64;                                  // one wave per 64 consecutive atoms
-        hipLaunchKernelGGL(k_filter_exclusion, dim3((nw + 3) / 4), dim3(256), 0, s, *excl, nlocal, n_col, count, table);
+        hipLaunchKernelGGL(k_filter_exclusion, dim3((nw + 3) / 4), dim3(256), 0, s, *excl, nlocal, n_col, count, table,
+                           tg.on ? MESO_ROW_INDEX : 0xFFFFFFFFu);
     }
 }
 

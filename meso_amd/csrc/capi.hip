@@ -100,7 +100,8 @@ int meso_comm_count(meso_ctx *ctx, int *nranks_seen)
 int meso_pair_kernel_name(meso_ctx *ctx, char *buf, int nbuf)
 {
     if (!ctx || !buf || nbuf <= 0) return 1;
-    snprintf(buf, (size_t)nbuf, "%s", meso::pair_ring_last_variant());
+    CTX(ctx);
+    snprintf(buf, (size_t)nbuf, "%s", E.pair_variant);
     return 0;
 }
 
@@ -245,6 +246,12 @@ int meso_xchg_stats(meso_ctx *ctx, char *buf, int nbuf)
     if (!ctx || !ctx->eng || !buf || nbuf <= 0) return set_err(MESO_ERR_ARG, "null argument");
     snprintf(buf, (size_t)nbuf, "%s", ctx->eng->xchg_report().c_str());
     return 0;
+}
+int meso_neigh_tags(meso_ctx *ctx, int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride)
+{
+    CTX(ctx);
+    if (!tagged || !group || !base || !k || !eps) return set_err(MESO_ERR_ARG, "null argument");
+    RET(E.neigh_tags(tagged, group, base, k, eps, raw, stride));
 }
 int meso_neigh_download(meso_ctx *ctx, int *count, int *table, int stride)
 {

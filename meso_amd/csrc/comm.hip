@@ -193,36 +193,45 @@ void Engine::comm_free()
 // rbuf2 != null: every message is two halves of equal size (the per-step ghost refresh: coordinates, then velocities) and its
 // second half is delivered to rbuf2[k] - straight into the two merged arrays, no scatter kernel behind the exchange.  With RCCL
 // the halves travel as two send/recv pairs of the same group (matched in order per peer).
+// The pieces of one message: the whole of it, or - rbuf2 given: the per-step refresh received straight into the merged arrays - its two
+// halves (coordinates, velocities), which land in two different arrays on the receiving side and therefore travel as two transfers.
+// ONE definition for every transport: the in-process and host transports copy exactly the pieces RCCL sends and receives, so the
+// multi-rank tests (which cannot run RCCL with two ranks on the one GPU of the test box) exercise the same sizes and offsets.
+struct XPiece { void *p; size_t n; };
+static inline int xchg_pieces(void *buf, void *buf2, size_t bytes, bool split, XPiece out[2])
+{
+    if (!bytes) return 0;
+    if (!split) { out[0] = {buf, bytes}; return 1; }
+    out[0] = {buf, bytes / 2};
+    out[1] = {buf2 ? buf2 : (void *)((char *)buf + bytes / 2), bytes / 2};
+    return 2;
+}
+
 int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf,
                  const size_t *rbytes, void *const *rbuf2)
 {
     hipStream_t stream = xs ? xs : this->stream;   // exchange stream (the side stream during overlapped refreshes)
+    const bool split = rbuf2 != nullptr;
     if (transport == 1) {
         ncclComm_t c = (ncclComm_t)nccl;
         bool any = false;
         for (int k = 0; k < np; k++) {
             if (peer[k] == rank) {
-                if (rbytes[k] && !rbuf2) HIPCHK(hipMemcpyAsync(rbuf[k], sbuf[k], rbytes[k], hipMemcpyDeviceToDevice, stream));
-                if (rbytes[k] && rbuf2) {
-                    HIPCHK(hipMemcpyAsync(rbuf[k], sbuf[k], rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
-                    HIPCHK(hipMemcpyAsync(rbuf2[k], (const char *)sbuf[k] + rbytes[k] / 2, rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
-                }
+                XPiece sp[2], rp[2];
+                const int ns = xchg_pieces(sbuf[k], nullptr, rbytes[k], split, sp), nr = xchg_pieces(rbuf[k], split ? rbuf2[k] : nullptr, rbytes[k], split, rp);
+                for (int q = 0; q < nr && q < ns; q++) HIPCHK(hipMemcpyAsync(rp[q].p, sp[q].p, rp[q].n, hipMemcpyDeviceToDevice, stream));
             } else if (sbytes[k] || rbytes[k]) any = true;
         }
         if (any) {
             if (ncclGroupStart() != ncclSuccess) return fail(5, "ncclGroupStart failed");
             for (int k = 0; k < np; k++) {
                 if (peer[k] == rank) continue;
-                if (!rbuf2) {
-                    if (sbytes[k] && ncclSend(sbuf[k], sbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclSend failed");
-                    if (rbytes[k] && ncclRecv(rbuf[k], rbytes[k], ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclRecv failed");
-                } else {
-                    const size_t hs = sbytes[k] / 2, hr = rbytes[k] / 2;
-                    if (hs && (ncclSend(sbuf[k], hs, ncclChar, peer[k], c, stream) != ncclSuccess ||
-                               ncclSend((const char *)sbuf[k] + hs, hs, ncclChar, peer[k], c, stream) != ncclSuccess)) return fail(5, "ncclSend failed");
-                    if (hr && (ncclRecv(rbuf[k], hr, ncclChar, peer[k], c, stream) != ncclSuccess ||
-                               ncclRecv(rbuf2[k], hr, ncclChar, peer[k], c, stream) != ncclSuccess)) return fail(5, "ncclRecv failed");
-                }
+                XPiece sp[2], rp[2];
+                const int ns = xchg_pieces(sbuf[k], nullptr, sbytes[k], split, sp), nr = xchg_pieces(rbuf[k], split ? rbuf2[k] : nullptr, rbytes[k], split, rp);
+                for (int q = 0; q < ns; q++)
+                    if (ncclSend(sp[q].p, sp[q].n, ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclSend failed");
+                for (int q = 0; q < nr; q++)
+                    if (ncclRecv(rp[q].p, rp[q].n, ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclRecv failed");
             }
             if (ncclGroupEnd() != ncclSuccess) return fail(5, "ncclGroupEnd failed");
         }
@@ -266,11 +275,10 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
                     }
                 }
             if (!from) return fail(5, "local transport: peer did not post a message");
-            if (!rbuf2) HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k], hipMemcpyDeviceToDevice, stream));
-            else {
-                HIPCHK(hipMemcpyAsync(rbuf[k], from, rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
-                HIPCHK(hipMemcpyAsync(rbuf2[k], (const char *)from + rbytes[k] / 2, rbytes[k] / 2, hipMemcpyDeviceToDevice, stream));
-            }
+            XPiece sp[2], rp[2];
+            const int ns = xchg_pieces(const_cast<void *>(from), nullptr, rbytes[k], split, sp), nr = xchg_pieces(rbuf[k], split ? rbuf2[k] : nullptr, rbytes[k], split, rp);
+            if (ns != nr) return fail(5, "local transport: a message and its receive are cut differently");
+            for (int q = 0; q < nr; q++) HIPCHK(hipMemcpyAsync(rp[q].p, sp[q].p, rp[q].n, hipMemcpyDeviceToDevice, stream));
         }
         if (acct) t2 = clk::now();
         HIPCHK(hipStreamSynchronize(stream));
@@ -293,11 +301,9 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
         if (acct) t2 = clk::now();
         for (int k = 0; k < np; k++) {
             if (!rbytes[k]) continue;
-            if (!rbuf2) HIPCHK(hipMemcpyAsync(rbuf[k], hr[k].data(), rbytes[k], hipMemcpyHostToDevice, stream));
-            else {
-                HIPCHK(hipMemcpyAsync(rbuf[k], hr[k].data(), rbytes[k] / 2, hipMemcpyHostToDevice, stream));
-                HIPCHK(hipMemcpyAsync(rbuf2[k], hr[k].data() + rbytes[k] / 2, rbytes[k] / 2, hipMemcpyHostToDevice, stream));
-            }
+            XPiece sp[2], rp[2];
+            const int ns = xchg_pieces(hr[k].data(), nullptr, rbytes[k], split, sp), nr = xchg_pieces(rbuf[k], split ? rbuf2[k] : nullptr, rbytes[k], split, rp);
+            for (int q = 0; q < nr && q < ns; q++) HIPCHK(hipMemcpyAsync(rp[q].p, sp[q].p, rp[q].n, hipMemcpyHostToDevice, stream));
         }
         HIPCHK(hipStreamSynchronize(stream));
         if (acct) book(t0, t1, t2, clk::now());

@@ -91,6 +91,7 @@ public:
     int tally_ev();
     void launch_pair(PairArgs &p, int ev);
     bool ring_selected() const;
+    char pair_variant[128] = "";    // instantiation of the force kernel THIS engine launched last (meso_pair_kernel_name)
 
     // computes
     int compute_temp(double *t);
@@ -99,7 +100,8 @@ public:
 
     // introspection
     int neigh_info(int *n_col, int *max_count, double *avg, int64_t *nbuild);
-    int neigh_download(int *count, int *table, int stride);
+    int neigh_download(int *count, int *table, int stride, bool raw = false);
+    int neigh_tags(int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride);
     int merged_download(float *c4, float *v4, int nall);
     int timer_reset();
     int timer_get(const std::string &name, double *ms, int64_t *calls);
@@ -323,6 +325,16 @@ private:
     int *mr_gcnt = nullptr;         // [M+1] ghosts per ghost cell of that form (gstart holds the starts)
     int mr_gcnt_n = 0;
     int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
+    // tagged rows + displacement account (RowTagArgs, kernels.h): the force kernel walks only the row entries that can be inside
+    // the cutoff on the current step
+    int shell_walk = 0;             // option: 1 tagged rows, pruned walk; 2 tagged rows, every shell walked (A/B of the queue form alone); 0 (default:
+                                    // measured faster at every size, profiles/r04_notes.md) plain rows
+    float *d_disp = nullptr;        // [MESO_DISP_SLOTS][MESO_DISP_STEP] max |v|^2 per step since the list was built (MESO_DISP_SUB copies per step)
+    bool rows_tagged = false;       // the table in use carries tags
+    int tag_group = 0;              // ... built for this pairing group of the force kernel
+    float shell_base = 0.f, shell_k = 0.f, shell_eps = 0.f;
+    float *disp_slot() const { return (d_disp && ago >= 0 && ago < MESO_DISP_SLOTS) ? d_disp + (size_t)ago * MESO_DISP_STEP : nullptr; }
+    void pair_shell_args(PairArgs &p, bool walk) const;
     int fused_rebuild = 1;          // option
     bool fused_active = false;      // this rebuild ran the fused path: ghosts sit in slot order, directions in senddir
     bool fused_dirty = false;       // a fused rebuild failed half-way: counters are cleared before the next one

@@ -80,7 +80,7 @@ void Engine::free_all()
     dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc); dfree(tagbits);
     dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
-    dfree(pair_count); dfree(pair_table);
+    dfree(pair_count); dfree(pair_table); dfree(d_disp);
     dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(img_cnt); dfree(img); dfree(d_shift27);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
     dfree(fr_bucket); dfree(fr_ovf); dfree(fr_novf); dfree(fr_scratch); dfree(senddir); dfree(fr_gorder); dfree(fr_gcnt);
@@ -315,6 +315,7 @@ int Engine::pair_coeff_table(int i, int j, double gamma, double sigma, int len, 
 int Engine::set_option(const std::string &key, double val)
 {
     if (key == "fused_rebuild") { fused_rebuild = (int)val; return 0; }
+    if (key == "shell_walk") { shell_walk = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }               // 0: never the 2x2x2 bricks of small boxes
     if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
@@ -1269,7 +1270,7 @@ void Engine::fused_locals_args(FusedArgs &a)
     a.mg.seed = premix_tea<64>((u32)seed, (u32)ntimestep);
     a.mg.inverse = nullptr;
     a.mg.zero = (images_on() || mr_img_wanted()) ? img_cnt : nullptr;
-    img_zero_gen = img_alloc_gen;
+    if (a.mg.zero) img_zero_gen = img_alloc_gen;      // (only a gather that clears the counters vouches for them)
     a.flags = d_flags;
 }
 
@@ -1491,12 +1492,35 @@ int Engine::build_cells_and_table()
                 bb.gcnt = (fused_active && fused_gcnt_valid) ? fr_gcnt : (mr_runs ? mr_gcnt : nullptr);
                 if (brick2_off || !brick2) bb.maxh2 = 0;
                 bb.brick2_limit = brick2_limit;
+                // tagged rows (RowTagArgs): shell at build time + pairing class in every entry, while indices fit 25 bits and the
+                // staged neighbourhood's slots 13; the shells split [base, r_list^2) evenly in r^2, base = the largest cutoff plus
+                // the rounding of the merged fp32 coordinates (|x| up to half the sub-box: 4 ulp + 1e-5)
+                RowTagArgs tg = {};
+                rows_tagged = false;
+                const long nall_bound = counts_pending ? (long)nmax : (long)nlocal + nghost;
+                if (shell_walk && ring_selected() && nall_bound < (1L << 25) && std::max(bb.maxh, bb.maxh2) <= tile_build_tag_slots()) {
+                    double ext = 0.0;
+                    for (int d = 0; d < 3; d++) ext = std::max(ext, 0.5 * (subhi[d] - sublo[d]) + cutghost);
+                    shell_eps = (float)(4.0 * ext * 1.1920929e-7 + 1.0e-5);
+                    const double rb = cutmax + 2.0 * shell_eps;
+                    shell_base = (float)(rb * rb);
+                    shell_k = (float)(6.9 / ((cutmax + skin) * (cutmax + skin) * 1.0001 - (double)shell_base));
+                    if (!d_disp) { HIPCHK(dalloc(d_disp, (size_t)MESO_DISP_SLOTS * MESO_DISP_STEP)); HIPCHK(hipMemsetAsync(d_disp, 0, (size_t)MESO_DISP_SLOTS * MESO_DISP_STEP * sizeof(float), stream)); }
+                    tag_group = pair_ring_group_for(nlocal, pair_npart);
+                    tg.on = 1; tg.k = shell_k; tg.off = (float)(1.0 - (double)shell_base * (double)shell_k);
+                    tg.gshift = 0;
+                    while ((1 << tg.gshift) < tag_group) tg.gshift++;
+                    tg.disp = d_disp;
+                    rows_tagged = skin > 0.0;
+                    if (!rows_tagged) tg = RowTagArgs{};
+                }
                 launch_tile_build(bb, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,
-                                  pair_debug >= 10 ? pair_debug - 10 : 0, stream);
+                                  pair_debug >= 10 ? pair_debug - 10 : 0, stream, rows_tagged ? &tg : nullptr);
                 tend("neigh");
                 nbuild++;
                 return 0;
             }
+            rows_tagged = false;
             launch_bin_ranges(estart, gstart, bargs.M, nlocal, binrange, stream);
             launch_cell_build(coord4, rkey, reorder_sub_bits(geom), binrange, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count, pair_table,
                               d_flags, have_bonds ? &ex : nullptr, stream);
@@ -1650,7 +1674,7 @@ int Engine::decide(int *rebuild)
 int Engine::nve_initial()
 {
     tbegin("nve");
-    launch_nve_initial(cur, 0.5 * dt, dt, groupbit, nlocal, stream);
+    launch_nve_initial(cur, 0.5 * dt, dt, groupbit, nlocal, stream, disp_slot());
     tend("nve");
     return 0;
 }
@@ -1688,6 +1712,9 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.nall = (int)std::min<long>(counts_pending ? (long)nmax : (long)nlocal + nghost, (1L << 28) - 1);
     p.rng = pair_rng;
     p.npart = pair_npart;
+    p.tagged = rows_tagged ? 1 : 0;
+    p.tag_group = tag_group;
+    if (rows_tagged) p.npart = 4 * 64 / tag_group;      // every launch of the interval pairs inside the groups the rows were tagged for
     p.poly = pair_poly ? d_poly : nullptr;
     p.ftab = pair_ftab ? d_ftab : nullptr;
     p.ftab_len = ftab_len;
@@ -1698,7 +1725,16 @@ void Engine::launch_pair(PairArgs &p, int ev)
     for (int t = 0; t < ntypes * ntypes; t++) p.uniform_cut &= coeff[(size_t)t * 7 + P_CUT] == coeff[P_CUT] ? 1 : 0;
     // two kernels: the ring kernel (both styles) and the lane-per-atom kernel that also books energy and virial
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
-    else launch_pair_dpd_ring(p, pair_style, stream);
+    else launch_pair_dpd_ring(p, pair_style, stream, pair_variant);
+}
+
+// the shell geometry of the table in use; walk: the caller's step is covered by the displacement account (one rank: the ghosts
+// are this rank's own atoms, and every step boundary since the build booked its fastest atom)
+void Engine::pair_shell_args(PairArgs &p, bool walk) const
+{
+    p.disp = nullptr; p.disp_n = -1;
+    p.shell_rc = (float)cutmax; p.shell_dt = (float)dt; p.shell_eps = shell_eps; p.shell_base = shell_base; p.shell_k = shell_k;
+    if (walk && rows_tagged && shell_walk == 1 && nranks == 1 && d_disp && ago >= 0 && ago <= MESO_DISP_SLOTS) { p.disp = d_disp; p.disp_n = ago; }
 }
 
 int Engine::pair_compute(int r, int eflag, int vflag)
@@ -1709,8 +1745,9 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     if (r == 0 || r == 2) TRY(halo_forward_seed(sd));
     int beg, end;
     range(r, beg, end);
-    PairArgs p;
+    PairArgs p = {};
     p.bond.nbond = nullptr;
+    pair_shell_args(p, false);       // (stepping through the API: every shell is walked)
     p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
     for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
     int ev = (eflag || vflag) ? 1 : 0;
@@ -1804,8 +1841,9 @@ int Engine::run(int nsteps)
         const bool split = nranks > 1 && overlap && n_split > 0 && n_split < nlocal && !mr_pending;      // (pending: ghosts are fresh)
         if (!ghosts_fresh && !ghosts_by_epilogue) TRY(halo_forward_seed(sd, split));
         ghosts_by_epilogue = false;
-        PairArgs p;
+        PairArgs p = {};
         p.bond.nbond = nullptr;
+        pair_shell_args(p, true);
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
         for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
         p.e_pair = nullptr;
@@ -1848,6 +1886,7 @@ int Engine::run(int nsteps)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
                                   0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
                                   premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
+        if (boundary_in_pair) p.nve.disp_slot = disp_slot();      // the step boundary books its fastest atom (displacement account of the list)
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
         if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }
@@ -1884,7 +1923,7 @@ int Engine::run(int nsteps)
             tbegin("nve");
             launch_nve_boundary(cur, 0.5 * dt, dt, groupbit, nlocal, next_rebuild ? 0 : 1, coord4, veloc4,
                                 0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
-                                premix_tea<64>((u32)seed, (u32)(ntimestep + 1)), stream);
+                                premix_tea<64>((u32)seed, (u32)(ntimestep + 1)), stream, disp_slot());
             tend("nve");
             initial_done = true;
             merged = !next_rebuild;
@@ -2029,7 +2068,17 @@ int Engine::neigh_info(int *ncol, int *max_count, double *avg, int64_t *nb)
     return 0;
 }
 
-int Engine::neigh_download(int *count, int *table, int stride)
+int Engine::neigh_tags(int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride)
+{
+    *tagged = rows_tagged ? 1 : 0; *group = tag_group; *base = shell_base; *k = shell_k; *eps = shell_eps;
+    if (raw && nlocal > 0) {
+        std::vector<int> cnt(nlocal);
+        return neigh_download(cnt.data(), raw, stride, true);
+    }
+    return 0;
+}
+
+int Engine::neigh_download(int *count, int *table, int stride, bool raw)
 {
     HIPCHK(hipStreamSynchronize(stream));
     if (!nlocal) return 0;
@@ -2038,9 +2087,10 @@ int Engine::neigh_download(int *count, int *table, int stride)
     std::vector<int> h(tiles * 64 * (size_t)n_col);
     HIPCHK(hipMemcpy(h.data(), pair_table, h.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < nlocal; i++) {
-        int n = std::min(count[i], stride);
+        int n = std::min(raw ? (count[i] + 7) & ~7 : count[i], stride);      // (raw: the tail slots of the last chunk too)
         for (int p = 0; p < n; p++)
-            table[(size_t)i * stride + p] = h[((((size_t)(i >> 6)) * (n_col >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)];
+            table[(size_t)i * stride + p] = (int)((uint32_t)h[((((size_t)(i >> 6)) * (n_col >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)] &
+                                                  (rows_tagged && !raw ? MESO_ROW_INDEX : 0xFFFFFFFFu));      // (tagged rows: the index bits)
     }
     return 0;
 }

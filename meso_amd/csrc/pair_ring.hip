@@ -27,25 +27,61 @@
 //
 // One wave owns its 64 atoms from start to end: no block barriers after the prologue, no global atomics; integer
 // addition is associative, so the sums do not depend on the order in which hits are drained (bit-reproducible).
-// Arithmetic of this kernel is contracted (a*b+c -> fma), like nvcc's default for the reference's fp32 kernel.
+// Nothing is left to the compiler's contraction: the fused multiply-adds of the fp32 style are written out (see the kernel).
+//
+// Tagged rows (LP = 1, round 4; RowTagArgs in kernels.h): the list builder leaves in every entry its distance shell at build time
+// and its Newton-pairing class, and the step boundaries keep a rigorous bound D on every atom's displacement since the build.  The
+// light phase then has two stages.  Stage 1, lane = atom: one unsigned compare per row entry decides whether it can be inside the
+// cutoff on THIS step (shell <= the shell of r_c + 2 D; mirrored entries never) and the survivors go into a per-wave candidate
+// queue in LDS (ballot + mbcnt) - no gather, no distance for the 55 % of the entries that cannot be hits.  Stage 2, lane =
+// candidate: 64 queued candidates at a time are gathered and tested with every lane busy (the owner's coordinate comes from
+// LDS), hits go to the hit ring as before: the wave no longer walks as many gather-and-test rounds as its longest row has chunks.
+// A skipped entry contributes exactly zero and the fixed-point sums do not depend on order: forces are bit-identical to the full walk.
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "kernels.h"
 #include "meso_device.h"
 
 namespace meso {
 
+#ifndef RG_UNIT
+#define RG_UNIT 1             // 1: the fp32 instantiations and the launcher; 2 (pair_ring_dp.hip): the fp64 instantiations
+#endif
 #ifndef RG_WAVES
 #define RG_WAVES 4
 #endif
 #define RG_GROUP (64 * RG_WAVES)      // atoms of a workgroup = Newton-pairing group
-#ifndef RG_GATHER_AHEAD
-#define RG_GATHER_AHEAD 0     // measured (profiles/r03_notes.md): gathers of chunk c + 1 in flight while chunk c is tested need 128
-#endif                        // VGPRs = 4 waves per SIMD instead of 5: 101 -> 112 us at 64^3
+#ifndef RG_TRING
+#define RG_TRING 128                // tagged rows: hit records per wave (a candidate batch adds at most 64 to fewer than 64 queued)
+#endif
+#ifndef RG_CK
+#define RG_CK 2                     // tagged rows: candidate batches requested together (1, 3, 4 and 8 measured: within 2 % at 64^3)
+#endif
+#ifndef RG_LV_ALL
+#define RG_LV_ALL 0                 // 1: in-group partners' velocity records from LDS in every variant of the kernel (not only one lane per atom, fp32)
+#endif
+#ifndef RG_LDS_COORD
+#define RG_LDS_COORD 1              // tagged rows: an in-group candidate's coordinate comes from the workgroup's LDS copy, not from a gather
+#endif
+#ifndef RG_FIX_WAVES
+#define RG_FIX_WAVES 0
+#endif
+#ifndef RG_SYNC
+#define RG_SYNC 0                   // 1: a group is tested right after it was requested (no group pending across the next row chunk)
+#endif
+#ifndef RG_QSLOTS
+#define RG_QSLOTS 4                 // tagged rows: entry slots of every lane per fill of the candidate queue (8: a whole row chunk - 3 % faster
+#endif                              // at equal occupancy, but its 2 KB queue leaves five workgroups per CU instead of six)
+#define RG_CAND (64 * RG_QSLOTS)    // tagged rows: candidate words per wave
 #ifndef RG_RING
 #define RG_RING 256                 // records per wave; a drain check every 2 slots keeps the fill below 64 + 128
 #endif
 #ifndef RG_OCC
 #define RG_OCC 20                   // waves per CU the fp32 kernel is compiled for
+#endif
+#ifndef RG_OCC_TAGGED
+#define RG_OCC_TAGGED 24            // ... the one-lane form on tagged rows (79 VGPRs, 26 KB of LDS per workgroup: six workgroups per CU; 64^3: 100.9 -> 97.5 us)
 #endif
 #ifndef RG_OCC_PARTS
 #define RG_OCC_PARTS 20             // ... the variants with 2 / 4 lanes per atom (small launches: one round of waves; they prefetch the step boundary's inputs)
@@ -74,18 +110,32 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 // is the whole 32-bit partner index, owner lane and pairing flag travel in a byte ring next to it
 // PLAIN: the noise is the TEA-keyed Gaussian and the conservative force a0 w (dpd/meso, dpd/fast/meso): the wave-uniform
 // switches for dpd/mini, dpd/polyforce and dpd/tableforce (PairArgs::rng / poly / ftab) are compiled out of the hot loop
-template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_, bool PLAIN>
-__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1)) k_pair_dpd_ring(PairArgs a)
+#ifdef RG_STAMP
+__device__ unsigned long long *g_stamp_dev = nullptr;
+#endif
+// LP: form of the light phase - 0: every row entry is gathered and tested by its atom's lane (plain rows); 1: tagged rows, candidate queue
+template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_, bool PLAIN, int LP>
+__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1))
+#if RG_FIX_WAVES
+    __attribute__((amdgpu_waves_per_eu(RG_FIX_WAVES, RG_FIX_WAVES)))      // (the register allocator otherwise aims for a wave more than the launch bounds ask and spills for it)
+#endif
+    k_pair_dpd_ring(PairArgs a)
 {
     // (no contraction left to the compiler: the pair evaluation is inlined at every drain point of the light phase, and copies that
     // fuse different multiply-adds would give one pair two forces that differ in the last bit, depending on which copy - and, for a
     // pair evaluated from both sides, which side - got it.  The fused operations of the fp32 style are written out below.)
+#ifdef RG_STAMP
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ double smem[];
     float *cf32 = (float *)smem;
     double *cf64 = smem;
     constexpr bool NT1 = TY == 0, UCUT = TY <= 1;
     constexpr bool WIDE = NPART_ == 0;
     constexpr int NPART = WIDE ? 1 : NPART_;
+    constexpr bool TAGGED = LP == 1;
+    constexpr int RING = TAGGED ? RG_TRING : RG_RING;
+    static_assert(!(TAGGED && WIDE), "tagged rows hold 25-bit indices");
     // fp32 style: rows of 8 floats (a0, gamma, sigma, s | 1/rc, rc^2, rc, -): one 16-byte LDS read per evaluated pair
     constexpr int CFP = FAST ? 8 : N_COEFF;
     const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * CFP;
@@ -96,24 +146,26 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
         } else cf64[p] = a.coeff64[p];
     }
     const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t per_wave = RG_RING * 16 + (NT1 ? 0 : RG_RING) + (WIDE ? RG_RING : 0);
+    // (the wave's number in an SGPR: the addresses of its LDS areas are scalar then)
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const size_t per_wave = RING * 16 + (NT1 ? 0 : RING) + (WIDE ? RING : 0) + (TAGGED ? RG_CAND * 4 : 0);
     u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
     // the workgroup's atoms, coordinate and velocity records, by group-local index (wave w owns [64 w, 64 w + 64): one lane per atom):
     // own_c / own_v are this wave's part; a partner of another wave of the group is looked up in own_v_all (issue())
     float4 *own_c_all = (float4 *)((char *)smem + off + 3 * 64 * RG_WAVES * 8);      // (accumulator area sized for NPART = 1)
     float4 *own_v_all = own_c_all + 64 * RG_WAVES;
-    float4 *own_c = own_c_all + 64 * w, *own_v = own_v_all + 64 * w;
+    constexpr int APW = 64 / NPART;                          // atoms per wave (NPART lanes share one atom, see below)
+    float4 *own_c = own_c_all + APW * w, *own_v = own_v_all + APW * w;
     char *wb = (char *)(own_v_all + 64 * RG_WAVES) + (size_t)w * per_wave;
     float4 *ring = (float4 *)wb;        // (partner x, y, z, record word): the coordinate is not gathered twice
-    unsigned char *ringt = (unsigned char *)(ring + RG_RING);     // several types: the partner's type next to its record
-    unsigned char *ringm = ringt + (NT1 ? 0 : RG_RING);           // WIDE: owner lane | pairing flag << 6
+    unsigned char *ringt = (unsigned char *)(ring + RING);        // several types: the partner's type next to its record
+    unsigned char *ringm = ringt + (NT1 ? 0 : RING);              // WIDE: owner lane | pairing flag << 6
+    u32 *cand = (u32 *)(ringm + (WIDE ? RING : 0));               // tagged rows: the candidate queue (index | pairing flag | owner lane << 26)
 
     const int nbk = gridDim.x;
     const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
     // NPART lanes share one atom (small launches: more waves for the same atoms): lane = part * APW + slot, the parts of an
     // atom walk its row chunks part, part + NPART, ...; sums meet in the LDS accumulators like those of the other waves
-    constexpr int APW = 64 / NPART;                          // atoms per wave
     constexpr int NB = APW * RG_WAVES;                       // atoms per workgroup = Newton-pairing group of this launch
     const int slot = lane % APW, part = lane / APW;
     const int blockbase = a.beg + blk * NB;                  // SHARE: beg is a multiple of 256 (launcher)
@@ -121,6 +173,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     const bool mine = i < a.end;
     float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
     int n = 0;
+    // tagged rows: the displacement account of the list (max |v|^2 of the step boundaries since the build) is asked for first -
+    // its load travels with the atom's own data below
+    const bool pruned = TAGGED && a.disp && a.disp_n >= 0;
+    float dv0 = 0.f;
+    if (pruned) dv0 = disp_load(a.disp, a.disp_n, 0);
     // the first chunk of the row is requested together with the atom's own data (its address needs the index only; a row past
     // its count holds stale entries that are never looked at): one memory round trip less at the head of every wave
     const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);
@@ -128,6 +185,16 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     if (mine) {
         c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i];
         first0 = rows[(size_t)part * 128]; first1 = rows[(size_t)part * 128 + 1];
+    }
+    // the shells this step has to look at: everything that can be inside the largest cutoff after those displacements (wave-uniform)
+    u32 thr = 0x80000000u;                       // (smax + 1) << 28; smax = 7: every shell
+    if (pruned) {
+        float dsum = disp_reduce(dv0);
+        for (int g = 4; g < a.disp_n; g += 4) dsum += disp_reduce(disp_load(a.disp, a.disp_n, g));      // (lists older than 4 steps)
+        const float reach = a.shell_rc + 2.00002f * a.shell_dt * dsum + a.shell_eps;
+        const float xs = (reach * reach - a.shell_base) * a.shell_k;
+        const int smax = xs <= 0.f ? 0 : min(7, (int)xs + 1);
+        thr = (u32)__builtin_amdgcn_readfirstlane((smax + 1) << MESO_ROW_SHELL_SHIFT);
     }
     // small launches (two or four lanes per atom: every wave's latency chain counts): what the step-boundary epilogue needs is
     // requested now and waits in registers (16 VGPRs: only the variants with registers to spare)
@@ -147,6 +214,9 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
         facc[ob] = 0; facc[NB + ob] = 0; facc[2 * NB + ob] = 0;
     }
     __syncthreads();   // coefficient table (multi-type), accumulators, this wave's own_c/own_v
+#ifdef RG_STAMP
+    const unsigned long long st_prolog = __builtin_amdgcn_s_memtime();
+#endif
 
     // (num_records is 32 bits: launch_pair clamps nall below 2^28 atoms, 16 bytes each)
     const u32 nrec = (u32)min((unsigned long long)(u32)a.nall * 16ull, 0xFFFFFFFFull);
@@ -168,11 +238,28 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     float4 pc2 = make_float4(0.f, 0.f, 0.f, 0.f), pv2 = pc2;
 
     // evaluate the pending batch (lane = hit)
-    auto compute = [&]() {
+#ifdef RG_STAMP
+    // timing build (tools/build_variant.sh ... -DRG_STAMP): shader-clock cycles of one wave per phase, summed over the waves
+    unsigned long long st_heavy = 0, st_issue = 0, st_cand = 0, st_push = 0, st_ncand = 0;
+#define ST_BEGIN() const unsigned long long st_t0 = __builtin_amdgcn_s_memtime()
+#define ST_END(acc) acc += __builtin_amdgcn_s_memtime() - st_t0
+#else
+#define ST_BEGIN()
+#define ST_END(acc)
+#endif
+    auto compute = [&]() __attribute__((always_inline)) {
         if (pn > 0) {
+            ST_BEGIN();
             if (lane < pn) {
                 const u32 owner = WIDE ? (pm & 63u) : pe >> RG_OWNER_SHIFT;
                 const float4 ci = own_c[owner], vi = own_v[owner];
+                if (RG_LDS_VELOC && (RG_LV_ALL || (NPART_ == 1 && FAST)) && !WIDE && a.lds_veloc) {
+                    // in-group partner: its velocity record is the LDS copy of the wave that owns it (see issue())
+                    const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0 && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end);
+                    const u32 pl = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;                // (in-group: < NB)
+                    const float4 vl = own_v_all[inwg ? pl : (u32)(APW * w + slot)];
+                    pv2.x = inwg ? vl.x : pv2.x; pv2.y = inwg ? vl.y : pv2.y; pv2.z = inwg ? vl.z : pv2.z; pv2.w = inwg ? vl.w : pv2.w;      // (component-wise: v_cndmask, not a trip through scratch)
+                }
                 u64 qx, qy, qz;
                 if (FAST) {
                     float c_cutinv, c_ew, c_a0, c_gamma, c_sigma;
@@ -220,7 +307,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                 __hip_atomic_fetch_add(&facc[oo], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[NB + oo], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[2 * NB + oo], qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT))) {
+                if (SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end)) {
                     // the partner is one of this workgroup's atoms: it receives the opposite force now and skips its own
                     // (mirrored) row entry
                     const u32 pj = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;
@@ -230,32 +317,33 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                 }
             }
             pn = 0;
+            ST_END(st_heavy);
         }
     };
     // request the partner words of the next nb queued records
-    auto issue = [&](int nb) {
+    auto issue = [&](int nb) __attribute__((always_inline)) {
+        ST_BEGIN();
         if (lane < nb) {
-            const float4 rec = ring[(qhead + lane) & (RG_RING - 1)];
+            const float4 rec = ring[(qhead + lane) & (RING - 1)];
             pe = __float_as_uint(rec.w);
             pc2 = make_float4(rec.x, rec.y, rec.z, 0.f);
-            if (WIDE) pm = ringm[(qhead + lane) & (RG_RING - 1)];
+            if (WIDE) pm = ringm[(qhead + lane) & (RING - 1)];
             const u32 joff = (WIDE ? pe : (pe & RG_INDEX_MASK)) << 4;
-            if (!NT1) pc2.w = __uint_as_float((u32)ringt[(qhead + lane) & (RG_RING - 1)]);     // (a fourth gather per hit before)
-            if (RG_LDS_VELOC && NPART_ == 1 && FAST && a.lds_veloc) {
+            if (!NT1) pc2.w = __uint_as_float((u32)ringt[(qhead + lane) & (RING - 1)]);     // (a fourth gather per hit before)
+            if (RG_LDS_VELOC && (RG_LV_ALL || (NPART_ == 1 && FAST)) && !WIDE && a.lds_veloc) {
             // a partner of this workgroup's group (the pairs evaluated once for both, 64 % of the hits) has its velocity record in
             // the LDS copy of the wave that owns it: those lanes read it there and give the gather an out-of-range offset (one lane
             // per atom, launches of several rounds of waves: 64^3 fused launch 121.9 -> 119.7 us, +1.2 % steps/s; 48^3 44.7 -> 46.6 us
             // alone and two lanes per atom 19.0 -> 20.4 us, so not there: PairArgs::lds_veloc, set by the launcher from the size;
             // the fp64 style lost 4 % with it at 64^3: fp32 kernels only)
-            const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0;
-            const u32 pl = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;                // (in-group: < NB)
-            const float4 vl = own_v_all[inwg ? pl : (u32)(64 * w + lane)];           // (one lane per atom: group-local index = slot)
-            const float4 vg = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
-            pv2 = inwg ? vl : vg;
+            // (the LDS record is read - and chosen - when the batch is evaluated: a select here would wait for the gather at once)
+            const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0 && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end);
+            pv2 = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
             } else pv2 = buf_load4(rv, joff);
         }
         pn = nb;
         qhead += nb;
+        ST_END(st_issue);
     };
 
     // chunk ch of my row: two 16-byte words (lanes past their row: zeros, never used)
@@ -314,31 +402,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
             }
         }
     };
-#if RG_GATHER_AHEAD
-    // the gathers of chunk c + 1 are in flight while chunk c is tested (and the row words of chunk c + 2 while those are
-    // issued): the kernel is bound by the latency of its dependent gathers more than by instruction issue
-    {
-        int jA[8], jB[8];
-        bool useA[8], useB[8], shbA[8], shbB[8];
-        float4 cA[8], cB[8];
-        int4 wa0, wa1, wb0, wb1;
-        ldrow(0, wa0, wa1);
-        ldrow(1, wb0, wb1);
-        prep(0, wa0, wa1, jA, useA, shbA, cA);
-        ldrow(2, wa0, wa1);
-#pragma unroll 1
-        for (int c = 0; c < nchmax; c += 2) {
-            prep(c + 1, wb0, wb1, jB, useB, shbB, cB);
-            ldrow(c + 3, wb0, wb1);
-            proc(jA, useA, shbA, cA);
-            if (c + 1 >= nchmax) break;
-            prep(c + 2, wa0, wa1, jA, useA, shbA, cA);
-            ldrow(c + 4, wa0, wa1);
-            proc(jB, useB, shbB, cB);
-        }
-    }
-#else
-    {
+    if constexpr (!TAGGED) {
         int j[8];
         bool use[8], shb[8];
         float4 c2[8];
@@ -351,12 +415,143 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
             prep(c, v0, v1, j, use, shb, c2);
             proc(j, use, shb, c2);
         }
+    } else {
+        // ---- tagged rows: stage 1 (lane = atom) feeds the candidate queue, stage 2 (lane = candidate) the hit ring ----
+        // candidate batches whose gathers are in flight: RG_CK batches are requested together and tested one group later.  The
+        // queue is linear: every row chunk (8 entry slots of every lane) starts it at 0 and all of its candidates are requested
+        // before the next chunk is looked at - no ring arithmetic, at the price of one partly filled batch per chunk
+        constexpr int CK = RG_CK;
+        int cpn = 0;                                 // candidates of the pending group (wave-uniform)
+        u32 crec[CK];
+        float4 cc[CK];
+#pragma clang loop unroll(full)
+        for (int b = 0; b < CK; b++) { crec[b] = 0; cc[b] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        // cutoff test of the pending group, hits into the ring (record = partner coordinate + the candidate word)
+        auto ctest = [&]() __attribute__((always_inline)) {
+#pragma clang loop unroll(full)
+            for (int b = 0; b < CK; b++) {
+                if (b * 64 < cpn) {
+                    const float4 ci = own_c[crec[b] >> RG_OWNER_SHIFT];
+                    const bool valid = b * 64 + lane < cpn;
+                    if (RG_LDS_COORD && SHARE) {
+                        // a partner of this workgroup's group has its coordinate record in LDS (its gather was switched off in cstep)
+                        const bool inwg = (crec[b] & RG_SHARED_BIT) != 0 && (crec[b] & RG_INDEX_MASK) < (u32)a.end;
+                        const float4 cl = own_c_all[inwg ? (crec[b] & RG_INDEX_MASK) - (u32)blockbase : (u32)(APW * w + slot)];
+                        cc[b].x = inwg ? cl.x : cc[b].x; cc[b].y = inwg ? cl.y : cc[b].y; cc[b].z = inwg ? cl.z : cc[b].z;
+                        if (!NT1) cc[b].w = inwg ? cl.w : cc[b].w;
+                    }
+                    bool hit;
+                    u64 m;
+                    if (FAST) {
+                        const float dx = ci.x - cc[b].x, dy = ci.y - cc[b].y, dz = ci.z - cc[b].z;
+                        const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        const float cutsq = UCUT ? (float)a.cf1[P_CUTSQ] : cf32[(__float_as_uint(ci.w) * a.ntypes + __float_as_uint(cc[b].w)) * 8 + 5];
+                        // (the lane mask straight from the compares - LLVM predicates 4 = OLT, 3 = OGE, 38 = SGT: no ballot to materialise)
+                        m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) & __builtin_amdgcn_sicmp(cpn - b * 64, lane, 38);
+                        hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & valid;
+                    } else {
+                        const double rsq = rsq_f64(ci, cc[b]);
+                        const double cutsq = UCUT ? a.cf1[P_CUTSQ] : cf64[(__float_as_uint(ci.w) * a.ntypes + __float_as_uint(cc[b].w)) * N_COEFF + P_CUTSQ];
+                        hit = (rsq < cutsq) & (rsq >= MESO_EPSILON_SQ) & valid;
+                        m = __builtin_amdgcn_ballot_w64(hit);
+                    }
+                    if (hit) {
+                        const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RING - 1);
+                        ring[pos] = make_float4(cc[b].x, cc[b].y, cc[b].z, __uint_as_float(crec[b]));
+                        if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(cc[b].w);
+                    }
+                    qtail += __popcll(m);
+                    while (qtail - qhead >= 64) { compute(); issue(64); }
+                }
+            }
+            cpn = 0;
+        };
+        // the n queued candidates from position c0 on (up to CK batches): their coordinate gathers go out, then the group requested
+        // before - whose data has arrived meanwhile - is tested
+        auto cinwg = [&](u32 rec) __attribute__((always_inline)) { return RG_LDS_COORD && SHARE && (rec & RG_SHARED_BIT) != 0 && (rec & RG_INDEX_MASK) < (u32)a.end; };
+        auto cstep = [&](int c0, int n) __attribute__((always_inline)) {
+#if RG_SYNC
+            // (all batches of the chunk requested together and tested at once, in order: the first test waits for the first gather only)
+#pragma clang loop unroll(full)
+            for (int b = 0; b < CK; b++)
+                if (b * 64 < n) crec[b] = cand[c0 + b * 64 + lane];
+#pragma clang loop unroll(full)
+            for (int b = 0; b < CK; b++)
+                if (b * 64 < n) cc[b] = buf_load4(rc, ((b * 64 + lane < n) & !cinwg(crec[b])) ? (crec[b] & RG_INDEX_MASK) << 4 : 0xFFFFFFF0u);
+            cpn = n;
+            ctest();
+#else
+            u32 r2[CK];
+            float4 c2[CK];
+#pragma clang loop unroll(full)
+            for (int b = 0; b < CK; b++) {
+                r2[b] = 0; c2[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b * 64 < n) r2[b] = cand[c0 + b * 64 + lane];      // (lanes behind n: stale words, masked below)
+            }
+#pragma clang loop unroll(full)
+            for (int b = 0; b < CK; b++)
+                if (b * 64 < n) c2[b] = buf_load4(rc, ((b * 64 + lane < n) & !cinwg(r2[b])) ? (r2[b] & RG_INDEX_MASK) << 4 : 0xFFFFFFF0u);
+            ctest();
+#pragma clang loop unroll(full)
+            for (int b = 0; b < CK; b++) { crec[b] = r2[b]; cc[b] = c2[b]; }
+            cpn = n;
+#endif
+        };
+        int4 w0, w1;
+        ldrow(0, w0, w1);
+#pragma unroll 1
+        for (int c = 0; c < nchmax; c++) {
+            const int4 v0 = w0, v1 = w1;
+            ldrow(c + 1, w0, w1);
+            const u64 amask = __builtin_amdgcn_sicmp(nch, c, 38);       // lanes whose row has this chunk
+            const bool active = c < nch;
+            const u32 jw[8] = {(u32)v0.x, (u32)v0.y, (u32)v0.z, (u32)v0.w, (u32)v1.x, (u32)v1.y, (u32)v1.z, (u32)v1.w};
+#pragma unroll
+            for (int q0 = 0; q0 < 8; q0 += RG_QSLOTS) {
+            int ctail = 0;
+#ifdef RG_STAMP
+            const unsigned long long st_p0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int q = q0; q < q0 + RG_QSLOTS; q++) {
+                // one compare: shell and mirror bit (a launch without pairing looks at mirrored entries too; 36 = ULT); tail slots
+                // carry MESO_ROW_PAD.  The candidate word is the hit record's: index, pairing flag, owner lane
+                const u32 jt = SHARE ? jw[q] : jw[q] & ~MESO_ROW_MIRROR;
+                const u64 m = __builtin_amdgcn_uicmp(jt, thr, 36) & amask;
+                const bool keep = (jt < thr) & active;
+                if (keep) {
+                    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                    (cand + ctail)[cnt] = (jw[q] & (SHARE ? (MESO_ROW_INDEX | MESO_ROW_SHARED) : MESO_ROW_INDEX)) | lanehi;
+                }
+                ctail += __popcll(m);
+            }
+#ifdef RG_STAMP
+            const unsigned long long st_p1 = __builtin_amdgcn_s_memtime();
+            st_push += st_p1 - st_p0;
+            st_ncand += ctail;
+#endif
+            for (int c0 = 0; c0 < ctail; c0 += 64 * CK) cstep(c0, min(64 * CK, ctail - c0));
+#ifdef RG_STAMP
+            st_cand += __builtin_amdgcn_s_memtime() - st_p1;
+#endif
+            }
+        }
+        ctest();
     }
+#ifdef RG_STAMP
+    const unsigned long long st_light = __builtin_amdgcn_s_memtime();
 #endif
     compute();
     while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
+#ifdef RG_STAMP
+    const unsigned long long st_drained = __builtin_amdgcn_s_memtime();
+#endif
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
+    float v2move = 0.f;
+    // (what this wave's copy of the step's displacement word holds: asked for now, needed after the step boundary)
+    float disp_seen = 0.f;
+    if (a.fuse_nve && a.nve.disp_slot && lane == 0) disp_seen = disp_peek(a.nve.disp_slot, (u32)blk * RG_WAVES + (u32)w);
     if (mine && part == 0) {
         double fx, fy, fz;
         if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
@@ -377,29 +572,72 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                     fx += bx; fy += by; fz += bz;
                 }
             }
-            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre);
-            else nve_boundary_atom(a.nve, i, fx, fy, fz);
+            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre, &v2move);
+            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, &v2move);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }
+    // the step boundary moved the atoms: its fastest one goes into the displacement account of the neighbour list (every lane calls)
+#ifndef RG_NO_BOOK
+    if (a.fuse_nve && a.nve.disp_slot) book_disp(a.nve.disp_slot, (u32)blk * RG_WAVES + (u32)w, v2move, disp_seen);
+#endif
+#ifdef RG_STAMP
+    if (g_stamp_dev && lane == 0) {
+        const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = g_stamp_dev + ((size_t)blockIdx.x * RG_WAVES + w) * 10;
+        o[0] = st_end - st_begin; o[1] = st_prolog - st_begin; o[2] = st_push; o[3] = st_cand; o[4] = st_heavy; o[5] = st_issue;
+        o[6] = st_drained - st_light; o[7] = st_end - st_drained; o[8] = st_ncand; o[9] = (unsigned long long)qtail;
+    }
+#endif
 }
 
+#if RG_UNIT == 2
+// fp64 style (dpd/meso): the instantiations of this translation unit, picked by the launcher of pair_ring.hip
+void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t sm, hipStream_t s, bool wide, bool tagged, int npart, bool nt1,
+                             bool ew1, bool share)
+{
+#define RG_L2(A, B, C)                                                                                                  \
+    do {                                                                                                                \
+        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 0, true, 0>), grid, block, sm, s, pl);             \
+        else if (!tagged && npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 4, true, 0>), grid, block, sm, s, pl);  \
+        else if (!tagged && npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 2, true, 0>), grid, block, sm, s, pl);  \
+        else if (!tagged) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 1, true, 0>), grid, block, sm, s, pl);     \
+        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 4, true, 1>), grid, block, sm, s, pl);  \
+        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 2, true, 1>), grid, block, sm, s, pl);  \
+        else hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 1, true, 1>), grid, block, sm, s, pl);                  \
+    } while (0)
+#define RG_T(B, C)                                     \
+    do {                                               \
+        if (nt1) RG_L2(0, B, C);                       \
+        else if (pl.uniform_cut) RG_L2(1, B, C);       \
+        else RG_L2(2, B, C);                           \
+    } while (0)
+    if (share) { if (ew1) RG_T(true, true); else RG_T(false, true); }
+    else { if (ew1) RG_T(true, false); else RG_T(false, false); }
+#undef RG_T
+#undef RG_L2
+}
+#else
+void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t sm, hipStream_t s, bool wide, bool tagged, int npart, bool nt1,
+                             bool ew1, bool share);
 // the instantiation the last launch ran, spelled as rocprofv3 prints it: bench.py attaches profile-derived numbers to its line
 // only while this is the kernel they were collected for
-static char g_last_variant[128] = "";
-const char *pair_ring_last_variant() { return g_last_variant; }
+// (written into the caller's buffer: several engines - the in-process ranks of the LOCAL transport - launch from several host threads)
 
-void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
+void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *variant_out)
 {
+    char g_last_variant[128];
     int n = p.end - p.beg;
     if (n <= 0) return;
     PairArgs pl = p;
-    pl.lds_veloc = n >= 700000 ? 1 : 0;      // (see issue(): pays from about two rounds of waves on)
+    pl.lds_veloc = (n >= 700000 || RG_LV_ALL) ? 1 : 0;      // (see issue(): pays from about two rounds of waves on)
     const bool nt1 = p.ntypes == 1;
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * (fast ? 8 * 4 : N_COEFF * 8);
     // more than 2^25 atoms (locals + ghosts): the record word cannot hold owner lane, pairing flag and index any more
-    const bool wide = (long)p.nall > (1L << 25) || p.debug == 9;      // (debug 9: the wide records on a small system - tests)
-    size_t per_wave = 64 * 16 * 2 + RG_RING * 16 + (nt1 ? 0 : RG_RING) + (wide ? RG_RING : 0) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
+    const bool tagged = p.tagged != 0;       // (the engine tags rows only below 2^25 atoms)
+    const bool wide = !tagged && ((long)p.nall > (1L << 25) || p.debug == 9);      // (debug 9: the wide records on a small system - tests)
+    const int ring = tagged ? RG_TRING : RG_RING;
+    size_t per_wave = 64 * 16 * 2 + ring * 16 + (nt1 ? 0 : ring) + (wide ? ring : 0) + (tagged ? RG_CAND * 4 : 0) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
     // small launches: 2 lanes per atom, so that the same atoms fill twice as many waves (a 32^3 box is 2048 waves for 1024
     // SIMDs otherwise, and each wave walks 7 row chunks and ~11 hit batches one after the other)
@@ -410,28 +648,27 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
     if (wide) npart = 1;
     const int awg = 64 / npart * RG_WAVES;
     dim3 grid(((n + awg - 1) / awg + 7) / 8 * 8), block(64 * RG_WAVES);
-    // p.debug 3/4: occupancy ablation - pad the LDS request so that only 3 / 4 workgroups fit a CU (default: 5)
-    if (p.debug == 3) sm = 53 * 1024;
-    if (p.debug == 4) sm = 40 * 1024;
-    if (p.debug == 5) sm = 32 * 1024;
-    if (p.debug == 6) sm = 26 * 1024;
     bool ew1 = true;
     if (nt1) ew1 = p.cf1[P_EXPW] == 1.0;
     else ew1 = p.all_expw_one != 0;
-    // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom
-    const bool share = p.share != 0 && (p.beg & (RG_GROUP - 1)) == 0;
+    // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom; tagged
+    // rows carry the pairing class of their entries for ONE group size
+    const bool share = p.share != 0 && (p.beg & (awg - 1)) == 0 && (p.beg & (RG_GROUP - 1)) == 0 && (!tagged || p.tag_group == awg);
     const bool plain = p.rng == 0 && !p.poly && !p.ftab;
-#define RG_LAUNCH2(F, A, B, C, P)                                                                               \
-    do {                                                                                                        \
-        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0, P>), grid, block, sm, s, pl);               \
-        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P>), grid, block, sm, s, pl);    \
-        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P>), grid, block, sm, s, pl);    \
-        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P>), grid, block, sm, s, pl);                    \
+#define RG_LAUNCH2(F, A, B, C, P)                                                                                     \
+    do {                                                                                                              \
+        if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0, P, 0>), grid, block, sm, s, pl);                  \
+        else if (!tagged && npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P, 0>), grid, block, sm, s, pl);       \
+        else if (!tagged && npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P, 0>), grid, block, sm, s, pl);       \
+        else if (!tagged) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P, 0>), grid, block, sm, s, pl);          \
+        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P, 1>), grid, block, sm, s, pl);       \
+        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P, 1>), grid, block, sm, s, pl);       \
+        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P, 1>), grid, block, sm, s, pl);                       \
     } while (0)
     // (the fp64 style has no variants: always "plain")
 #define RG_LAUNCH(F, A, B, C)                                   \
     do {                                                        \
-        if (plain || !(F)) RG_LAUNCH2(F, A, B, C, true);        \
+        if (plain) RG_LAUNCH2(F, A, B, C, true);                \
         else RG_LAUNCH2(F, A, B, C, false);                     \
     } while (0)
 #define RG_TYPES(F, B, C)                                      \
@@ -448,16 +685,64 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s)
         if (ew1) RG_TYPES(F, true, false);                \
         else RG_TYPES(F, false, false);                   \
     }
-    snprintf(g_last_variant, sizeof g_last_variant, "k_pair_dpd_ring<%s, %d, %s, %s, %d, %s>", fast ? "true" : "false",
+#ifdef RG_STAMP
+    static unsigned long long *h_dev = nullptr;
+    static size_t h_waves = 0;
+    static long n_launch = 0;
+    const size_t nw = (size_t)grid.x * RG_WAVES;
+    if (nw > h_waves) {
+        if (h_dev) (void)hipFree(h_dev);
+        (void)hipMalloc((void **)&h_dev, nw * 10 * sizeof(unsigned long long));
+        h_waves = nw;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_dev), &h_dev, sizeof h_dev);
+    }
+    (void)hipMemsetAsync(h_dev, 0, nw * 10 * sizeof(unsigned long long), s);
+#endif
+    snprintf(g_last_variant, sizeof g_last_variant, "k_pair_dpd_ring<%s, %d, %s, %s, %d, %s, %d>", fast ? "true" : "false",
              nt1 ? 0 : (p.uniform_cut ? 1 : 2), ew1 ? "true" : "false", share ? "true" : "false", wide ? 0 : npart,
-             (plain || !fast) ? "true" : "false");
-    if (fast) { RG_PICK(true) } else { RG_PICK(false) }
+             (plain || !fast) ? "true" : "false", tagged ? 1 : 0);
+    if (variant_out) snprintf(variant_out, 128, "%s", g_last_variant);
+#ifdef RG_FEW
+    // (timing builds, tools/build_variant.sh: only the instantiations of the one-type benchmark decks)
+    if (!(fast && nt1 && ew1 && share && plain)) { fprintf(stderr, "RG_FEW build: variant not compiled\n"); abort(); }
+    RG_LAUNCH2(true, 0, true, true, true);
+#else
+    // (the fp64 instantiations are compiled by their own translation unit, pair_ring_dp.hip: half the build time)
+    if (fast) { RG_PICK(true) } else launch_pair_dpd_ring_dp(pl, grid, block, sm, s, wide, tagged, npart, nt1, ew1, share);
+#endif
 #undef RG_PICK
 #undef RG_TYPES
 #undef RG_LAUNCH
 #undef RG_LAUNCH2
+#ifdef RG_STAMP
+    if (++n_launch % 97 == 50) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h(nw * 10);
+        (void)hipMemcpy(h.data(), h_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[10] = {0};
+        size_t live = 0;
+        for (size_t k = 0; k < nw; k++) {
+            if (!h[k * 10]) continue;
+            live++;
+            for (int q = 0; q < 10; q++) sum[q] += (double)h[k * 10 + q];
+        }
+        fprintf(stderr, "stamp launch %ld (%s, n %d, disp_n %d): waves %zu  cycles/wave total %.0f prologue %.0f push %.0f cand(step+test+nested heavy) %.0f heavy %.0f issue %.0f final-drain %.0f epilogue %.0f | cand/wave %.0f hits/wave %.0f\n",
+                n_launch, g_last_variant, n, p.disp_n, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, sum[4] / live, sum[5] / live, sum[6] / live,
+                sum[7] / live, sum[8] / live, sum[9] / live);
+    }
+#endif
+}
+
+// lanes per atom the launcher picks for a launch over n atoms (the engine tags rows for the matching pairing group)
+int pair_ring_group_for(int n, int npart_opt)
+{
+    int npart = npart_opt > 0 ? npart_opt : (n <= 163840 ? 2 : 1);
+    if (npart != 1 && npart != 2 && npart != 4) npart = 1;
+    return 64 / npart * RG_WAVES;
 }
 
 int pair_ring_group() { return RG_GROUP; }
+
+#endif
 
 } // namespace meso
