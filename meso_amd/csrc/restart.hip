@@ -253,6 +253,7 @@ int Engine::profile_window(int mode, int64_t start, int64_t end)
             prof_resume = (int (*)(uint64_t))dlsym(h, "roctxProfilerResume");
         }
     }
+    if (getenv("MESO_DEBUG_PROFILE")) fprintf(stderr, "profile_window: mode %d, roctxProfilerPause %s, roctxProfilerResume %s\n", mode, prof_pause ? "found" : "MISSING", prof_resume ? "found" : "MISSING");
     // modes with a window inside the run start with collection paused ("all" brackets the whole program instead)
     if (mode >= 2 && prof_pause) prof_pause(0);
     return 0;

@@ -50,6 +50,44 @@ def test_continuation_is_bit_identical(tmp_path, style, at):
     assert np.array_equal(ref[3], got[3]) and np.array_equal(ref[4], got[4])
 
 
+@pytest.mark.parametrize("at", [20, 25])
+def test_restarted_run_matches_the_oracles_uninterrupted_run(tmp_path, at):
+    """SURVEY.md 8f row 4 against the ORACLE, not against the HIP path itself: pair_style dpd/meso with the thermostat on
+    (sigma = 3), written at step `at` (a rebuild step: between two rebuilds the restarted run wraps and re-merges the coordinates, whose
+    fp32 rounding then differs - see the module docstring) by MesoPairDPD::write_restart's counterpart
+    (/root/reference/src/USER-MESO/pair_dpd_meso.cu:363-447: the pair record carries seed and coefficients, so the TEA stream
+    continues), read back by a fresh context and continued to step 32: positions, velocities and forces must equal the CPU mirror's
+    (oracle/meso_sim.py) UNINTERRUPTED 32 steps - the tolerance of test_trajectory_vs_meso_oracle (1e-9 / 5e-8)."""
+    from meso_amd.api import Meso
+    from oracle.meso_sim import MesoRefSim
+    L = 7
+    x, v, lo, hi = make_box(L)
+    s = MesoRefSim(x, v, lo, hi, every=5)
+    s.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+    s.setup()
+    s.run(32)
+    f = tmp_path / "o.rst"
+    with Meso() as m:
+        _fluid(m, x, v, lo, hi, "dpd/meso")
+        m.run(at)
+        m.write_restart(f)
+    with Meso() as m:
+        m.read_restart(f)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=5, check=False)
+        m.setup()
+        assert m.ntimestep == at
+        m.run(32 - at)
+        xg, vg, fg = m.gather()[:3]
+        assert m.ntimestep == 32
+        assert m.temperature() == pytest.approx(s.temperature, rel=1e-9)
+    prd = s.hi - s.lo
+    d = xg - s.x
+    d -= np.round(d / prd) * prd
+    assert np.abs(d).max() < 1e-9 and np.abs(vg - s.v).max() < 5e-8
+    assert np.abs(fg - s.f).max() <= 1e-8 * np.abs(s.f).max()
+
+
 def test_polymers_with_fene_and_angles_continue(tmp_path):
     from meso_amd.api import Meso
     x, v, types, bonds, lo, hi = make_polymer_box(7, frac=0.3)
