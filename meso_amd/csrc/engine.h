@@ -335,6 +335,7 @@ private:
     float shell_base = 0.f, shell_k = 0.f, shell_eps = 0.f;
     float *disp_slot() const { return (d_disp && ago >= 0 && ago < MESO_DISP_SLOTS) ? d_disp + (size_t)ago * MESO_DISP_STEP : nullptr; }
     void pair_shell_args(PairArgs &p, bool walk) const;
+    int split_gather = -1;          // option: the fused rebuild's placing kernel only orders and a streaming pass gathers (-1: boxes of >= 200 k atoms - 40^3 +1 %, 48^3 +1.8 %, 64^3 +1.6 %, 32^3 -0.7 %; 0; 1)
     int fused_rebuild = 1;          // option
     bool fused_active = false;      // this rebuild ran the fused path: ghosts sit in slot order, directions in senddir
     bool fused_dirty = false;       // a fused rebuild failed half-way: counters are cleared before the next one

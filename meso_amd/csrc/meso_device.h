@@ -597,6 +597,7 @@ struct FusedArgs {
                                // FR_DIRECT_TILES tiles (null otherwise: every tile adds up the tile totals in front of it directly)
     int *estart;               // out [2M+1]
     int *perm;                 // out, nullable: new place -> old place
+    int split_gather;          // the placing kernel only orders (writes perm), the payload moves in a streaming pass of its own (k_fr_gather)
     unsigned long long *scratch;   // [n] (a code denser than the LDS stage)
     int lds_cap;               // entries of the LDS stage of one pass
     MergeOut mg;               // merged pairs of the new order (+ the ghosts'), image counters cleared

@@ -182,7 +182,11 @@ __device__ inline unsigned long long fr_overflow_member(const unsigned long long
 #endif
 // LISTS: bonded systems - the general gather (topology lists travel too); an instantiation of its own so that its registers do not
 // count against the common path
-template <bool LISTS>
+// GATHER false (large one-rank boxes): the kernel only ORDERS - it writes the permutation new place -> old place - and the payload
+// moves in a streaming pass of its own (k_fr_gather: lane = atom, nothing but the permutation between it and its loads).  The
+// fused form keeps a tile's ~600 atoms x 100 bytes behind four dependent round trips (tile base, counts, buckets, gather) with
+// eight tiles resident per CU: 77 us for 190 MB at 64^3, where the streaming gather of round 2 moved the same bytes in 38.
+template <bool LISTS, bool GATHER>
 __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_fr_place(FusedArgs a)
 {
     extern __shared__ unsigned long long fr_pairs[];      // (sub-cell key << 32) | old index, per pass
@@ -283,6 +287,12 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_
                     nn[u] = base + s0 + sb + pos;     // the atom's new place
                 }
             }
+            if (!GATHER) {
+#pragma unroll
+                for (int u = 0; u < FR_U; u++)
+                    if (jj[u] >= 0) a.perm[nn[u]] = jj[u];
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < FR_U; u++) {
                 X[u][0] = X[u][1] = X[u][2] = 0.0;
@@ -351,6 +361,67 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_
         }
         __syncthreads();
         cb = ce;
+    }
+}
+
+// 2b: the payload of the order-only form: atom perm[n] of the old order becomes atom n of the new one (lane = n; gpu_permute_copy,
+// atom_vec_meso.h:11-67, with gpu_merge_xvt folded in), border atoms book their periodic images per tile of ghost cells exactly as
+// the fused form does (the cell from the coordinate, as k_fr_count computed it)
+__global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a)
+{
+    const int n = blockDim.x * blockIdx.x + threadIdx.x;
+    const bool valid = n < a.n;
+    double X[3] = {0.0, 0.0, 0.0};
+    if (valid) {
+        const int j = a.perm[n];
+        double V[3], F[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            X[d] = a.src.x[d][j]; V[d] = a.src.v[d][j];
+            if (a.with_f) F[d] = a.src.f[d][j];
+        }
+        const int TG = a.src.tag[j], TY = a.src.type[j], MK = a.src.mask[j], IM = a.src.image[j];
+        const double MS = a.src.mass[j];
+        if (a.mg.zero) a.mg.zero[n] = 0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            a.dst.x[d][n] = X[d]; a.dst.v[d][n] = V[d];
+            if (a.with_f) a.dst.f[d][n] = F[d];
+        }
+        float4 c, v;
+        c.x = (float)(X[0] - a.mg.cx); c.y = (float)(X[1] - a.mg.cy); c.z = (float)(X[2] - a.mg.cz);
+        c.w = __uint_as_float((u32)(TY - 1));
+        v.x = (float)V[0]; v.y = (float)V[1]; v.z = (float)V[2];
+        v.w = __uint_as_float(signature(a.mg.seed, TG, v.x, v.y, v.z));
+        a.mg.coord4[n] = c;
+        a.mg.veloc4[n] = v;
+        a.dst.tag[n] = TG; a.dst.type[n] = TY; a.dst.mask[n] = MK; a.dst.image[n] = IM; a.dst.mass[n] = MS;
+    }
+    if (!a.gttot) return;
+    // (whole waves: the image counting is a wave-level operation; the border section starts at estart[M], written by the ordering kernel)
+    const int nb = a.estart[a.M];
+    const bool bord = valid && n >= nb;
+    if (__ballot(bord) == 0ull) return;
+    u32 emask = 0;
+    int bx = 0, by = 0, bz = 0;
+    if (bord) {
+        bx = clampi((int)((X[0] - a.g.lo[0]) * a.g.bininv[0] + 1), 0, a.g.mbin[0]);
+        by = clampi((int)((X[1] - a.g.lo[1]) * a.g.bininv[1] + 1), 0, a.g.mbin[1]);
+        bz = clampi((int)((X[2] - a.g.lo[2]) * a.g.bininv[2] + 1), 0, a.g.mbin[2]);
+        emask = image_mask(near_flags(X[0], X[1], X[2], a.sl.lo, a.sl.hi), bx, by, bz, a.g.mbin, a.dir_mask);
+    }
+    u32 any = emask;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) any |= (u32)__shfl_xor((int)any, o, 64);
+    any = (u32)__builtin_amdgcn_readfirstlane((int)any);
+    while (any) {
+        const int dir = __builtin_ctz(any);
+        any &= any - 1u;
+        const bool em = (emask >> dir) & 1u;
+        const int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
+        const u32 gc = interleave3((u32)(sx == 0 ? bx : (sx > 0 ? 0 : a.g.mbin[0] - 1)), (u32)(sy == 0 ? by : (sy > 0 ? 0 : a.g.mbin[1] - 1)),
+                                   (u32)(sz == 0 ? bz : (sz > 0 ? 0 : a.g.mbin[2] - 1)));
+        wave_group_add(em ? gc / FR_GTILE : 0u, em, a.gttot);
     }
 }
 
@@ -550,11 +621,18 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
     const size_t dyn2 = (size_t)a.lds_cap * 8, dyn3 = (size_t)a.lds_cap;
     const bool lists = a.src.bpa > 0 || a.src.apa > 0 || a.src.msp > 0;
     if (dyn2 > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)k_fr_place<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-        (void)hipFuncSetAttribute((const void *)k_fr_place<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+        (void)hipFuncSetAttribute((const void *)k_fr_place<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+        (void)hipFuncSetAttribute((const void *)k_fr_place<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+        (void)hipFuncSetAttribute((const void *)k_fr_place<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
     }
-    if (lists) hipLaunchKernelGGL(k_fr_place<true>, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
-    else hipLaunchKernelGGL(k_fr_place<false>, dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
+    // large boxes of one rank: order, then a streaming gather (split_gather: the engine's choice; needs the permutation array and
+    // no holes in the old order)
+    const bool split = a.split_gather && !lists && a.perm && !a.skip;
+    if (lists) hipLaunchKernelGGL((k_fr_place<true, true>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
+    else if (split) {
+        hipLaunchKernelGGL((k_fr_place<false, false>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
+        hipLaunchKernelGGL(k_fr_gather, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+    } else hipLaunchKernelGGL((k_fr_place<false, true>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     if (a.gttot && a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
     if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(a.gorder ? a.ngorder : ntg), dim3(FR_THREADS), dyn3, s, a);
     else if (!a.novf_later) (void)hipMemsetAsync(a.novf, 0, sizeof(int), s);      // (the ghost kernel clears the overflow count otherwise;
