@@ -83,6 +83,9 @@ namespace meso {
 #ifndef RG_OCC_TAGGED
 #define RG_OCC_TAGGED 24            // ... the one-lane form on tagged rows (79 VGPRs, 26 KB of LDS per workgroup: six workgroups per CU; 64^3: 100.9 -> 97.5 us)
 #endif
+#ifndef RG_OCC_DP
+#define RG_OCC_DP 8                 // ... the fp64 style (116 VGPRs: four waves per SIMD)
+#endif
 #ifndef RG_OCC_PARTS
 #define RG_OCC_PARTS 20             // ... the variants with 2 / 4 lanes per atom (small launches: one round of waves; they prefetch the step boundary's inputs)
 #endif
@@ -115,7 +118,7 @@ __device__ unsigned long long *g_stamp_dev = nullptr;
 #endif
 // LP: form of the light phase - 0: every row entry is gathered and tested by its atom's lane (plain rows); 1: tagged rows, candidate queue
 template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_, bool PLAIN, int LP>
-__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES : 1) : (8 / RG_WAVES > 0 ? 8 / RG_WAVES : 1))
+__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES : 1) : (RG_OCC_DP / RG_WAVES > 0 ? RG_OCC_DP / RG_WAVES : 1))
 #if RG_FIX_WAVES
     __attribute__((amdgpu_waves_per_eu(RG_FIX_WAVES, RG_FIX_WAVES)))      // (the register allocator otherwise aims for a wave more than the launch bounds ask and spills for it)
 #endif

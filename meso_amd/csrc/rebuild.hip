@@ -476,9 +476,12 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
         if (tid < 28) a.dir_start[tid] = tid == 27 ? ng : 0;
         if (tid == 0) {
             a.gstart[a.M] = ng;
+            // (another tile of this launch may be raising an overflow code right now: the write-back is an atomic maximum, never a
+            // plain store that could undo it; a code raised behind this snapshot stays in flags[0] - check_overflow at the end of
+            // run() and the next rebuild's report see it: the run fails, it never carries on with a truncated ghost list)
             int f = a.flags[0];
             if (ng > a.ghost_cap) f = 200000;
-            if (f) a.flags[0] = f;
+            if (f) atomicMax(a.flags, f);
             *a.novf = 0;
             a.report[8] = f;
             a.report[9] = a.estart[a.M];            // n_bulk
