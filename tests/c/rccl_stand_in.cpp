@@ -1,0 +1,189 @@
+// TEST INFRASTRUCTURE ONLY - an in-process stand-in for the eight librccl entry points the engine calls (ncclGetUniqueId,
+// ncclCommInitRank, ncclCommCount, ncclCommDestroy, ncclGroupStart, ncclGroupEnd, ncclSend, ncclRecv).
+//
+// RCCL refuses two ranks on one device ("Duplicate GPU detected", tests/test_gpu_multiproc.py), so on the one-GPU test box the
+// engine's RCCL branch - Engine::comm_init("rccl") and the grouped send / receive schedule of Engine::xchg (comm.hip) - never ran.
+// Preloaded into a test process (LD_PRELOAD), this library lets several in-process ranks (one host thread and one engine context
+// each, as the LOCAL transport's tests have them) run that very branch: it keeps RCCL's matching rules - point-to-point messages
+// between two ranks match in the order they were posted, a send and its receive must agree on the byte count, everything inside
+// one ncclGroupStart / ncclGroupEnd is posted together - and moves the bytes with device-to-device copies.  It is not shipped, not
+// linked by the product, and says nothing about RCCL's performance.
+//
+// Build: hipcc -shared -fPIC tests/c/rccl_stand_in.cpp -o tests/c/librccl_stand_in.so  (__graft_entry__.build())
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Msg {
+    const void *buf;
+    size_t bytes;
+    bool taken = false;
+};
+struct Group {
+    int nranks = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::deque<std::shared_ptr<Msg>>> box;      // [src * nranks + dst]: messages posted and not yet received, in order
+};
+struct Comm {
+    Group *g;
+    int rank;
+};
+struct Op {
+    bool send;
+    void *buf;
+    size_t bytes;
+    int peer;
+    Comm *c;
+    hipStream_t stream;
+};
+
+std::mutex g_reg_mu;
+std::map<std::string, Group *> g_registry;
+std::atomic<long> g_next_id{1};
+thread_local int t_depth = 0;
+thread_local std::vector<Op> t_ops;
+
+size_t type_bytes(ncclDataType_t t)
+{
+    switch (t) {
+    case ncclInt8: case ncclUint8: return 1;
+    case ncclFloat16: case ncclBfloat16: return 2;
+    case ncclInt32: case ncclUint32: case ncclFloat32: return 4;
+    default: return 8;
+    }
+}
+
+ncclResult_t run_ops(std::vector<Op> &ops)
+{
+    if (ops.empty()) return ncclSuccess;
+    // what the messages hold must be complete before a peer copies it
+    for (auto &o : ops) if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+    std::vector<std::shared_ptr<Msg>> mine;
+    for (auto &o : ops) {
+        if (!o.send) continue;
+        Group *g = o.c->g;
+        auto m = std::make_shared<Msg>();
+        m->buf = o.buf; m->bytes = o.bytes;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->box[(size_t)o.c->rank * g->nranks + o.peer].push_back(m);
+        }
+        g->cv.notify_all();
+        mine.push_back(m);
+    }
+    ncclResult_t rc = ncclSuccess;
+    for (auto &o : ops) {
+        if (o.send) continue;
+        Group *g = o.c->g;
+        std::shared_ptr<Msg> m;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            auto &q = g->box[(size_t)o.peer * g->nranks + o.c->rank];
+            g->cv.wait(lk, [&] { return !q.empty(); });
+            m = q.front();
+            q.pop_front();
+        }
+        if (m->bytes != o.bytes) {
+            fprintf(stderr, "rccl stand-in: rank %d receives %zu bytes from rank %d, which sent %zu\n", o.c->rank, o.bytes, o.peer, m->bytes);
+            rc = ncclInvalidUsage;
+        } else if (o.bytes && (hipMemcpyAsync(o.buf, m->buf, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess ||
+                               hipStreamSynchronize(o.stream) != hipSuccess))
+            rc = ncclUnhandledCudaError;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            m->taken = true;
+        }
+        g->cv.notify_all();
+    }
+    // a send buffer may be reused once its message was received
+    for (size_t k = 0, s = 0; k < ops.size(); k++) {
+        if (!ops[k].send) continue;
+        Group *g = ops[k].c->g;
+        std::unique_lock<std::mutex> lk(g->mu);
+        auto &m = mine[s++];
+        g->cv.wait(lk, [&] { return m->taken; });
+    }
+    return rc;
+}
+
+}      // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
+{
+    memset(id, 0, sizeof *id);
+    snprintf(id->internal, sizeof id->internal, "stand-in-%ld", g_next_id.fetch_add(1));
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    Group *&g = g_registry[std::string(id.internal, sizeof id.internal)];
+    if (!g) {
+        g = new Group;
+        g->nranks = nranks;
+        g->box.resize((size_t)nranks * nranks);
+    }
+    if (g->nranks != nranks || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    Comm *c = new Comm{g, rank};
+    *comm = reinterpret_cast<ncclComm_t>(c);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+    *count = reinterpret_cast<Comm *>(comm)->g->nranks;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm)
+{
+    delete reinterpret_cast<Comm *>(comm);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupStart()
+{
+    t_depth++;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupEnd()
+{
+    if (--t_depth > 0) return ncclSuccess;
+    t_depth = 0;
+    std::vector<Op> ops;
+    ops.swap(t_ops);
+    return run_ops(ops);
+}
+
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    t_ops.push_back(Op{true, const_cast<void *>(sendbuff), count * type_bytes(datatype), peer, reinterpret_cast<Comm *>(comm), stream});
+    if (t_depth == 0) { std::vector<Op> ops; ops.swap(t_ops); return run_ops(ops); }
+    return ncclSuccess;
+}
+
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    t_ops.push_back(Op{false, recvbuff, count * type_bytes(datatype), peer, reinterpret_cast<Comm *>(comm), stream});
+    if (t_depth == 0) { std::vector<Op> ops; ops.swap(t_ops); return run_ops(ops); }
+    return ncclSuccess;
+}
+
+}      // extern "C"

@@ -1,0 +1,42 @@
+"""The engine's RCCL branch with SEVERAL ranks on the one GPU of the test box.
+
+RCCL itself refuses two ranks on one device (tests/test_gpu_multiproc.py records the refusal), so Engine::comm_init("rccl") and the
+grouped ncclSend / ncclRecv schedule of Engine::xchg (meso_amd/csrc/comm.hip; replaces MesoComm::borders / exchange /
+forward_comm, /root/reference/src/USER-MESO/comm_meso.cu:41-186,256-550) never executed with more than one rank before round 4.
+Here a child process preloads tests/c/librccl_stand_in.so - the eight librccl entry points the engine calls, re-implemented for
+in-process ranks with RCCL's matching rules (per-pair FIFO, equal byte counts, grouped posting) - and runs the 2x2x2 and 2x1x1
+decks over transport "rccl" and again over "local": trajectories must be bit-identical.  What this does NOT cover is RCCL itself
+(its kernels, its IPC set-up): that needs the driver's multi-GPU node."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+LIB = os.path.join(ROOT, "tests", "c", "librccl_stand_in.so")
+
+
+def _build():
+    src = os.path.join(ROOT, "tests", "c", "rccl_stand_in.cpp")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        r = subprocess.run(["hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", src, "-o", LIB], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("nranks,grid,L,style,steps,opts", [
+    (8, (2, 2, 2), 12, "dpd/meso", 23, ()),                        # 4 rebuilds with migration, refresh received straight into the merged arrays
+    (8, (2, 2, 2), 12, "dpd/fast/meso", 23, ()),
+    (2, (2, 1, 1), 10, "dpd/fast/meso", 12, ()),                   # a rank that is its own neighbour in y and z
+    (8, (2, 2, 2), 12, "dpd/meso", 12, ("refresh_direct=0", "refresh_epilogue=0")),     # pack / scatter kernels around the exchange
+    (4, (2, 2, 1), 12, "dpd/meso", 12, ("async_counts=0",)),       # the synchronous two-phase border exchange
+])
+def test_rccl_branch_equals_local_transport(nranks, grid, L, style, steps, opts):
+    _build()
+    env = dict(os.environ, LD_PRELOAD=LIB, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "rccl_stand_in_run.py"), str(nranks)] + [str(g) for g in grid] + [str(L), style, str(steps)] + list(opts)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "OK ranks" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -9,7 +9,7 @@ cd $R
 timeout -k 10 400 python3 bench.py > gpurun_out/${tag}_bench64_fast.json 2> gpurun_out/${tag}_bench64_fast.err
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kt -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kt -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline --other-boxes "" > $R/gpurun_out/${tag}_kt.log 2>&1
 echo "kernel trace done"
 cd $R
 python3 - <<PY
@@ -22,7 +22,7 @@ with open("gpurun_out/${tag}_kernel_stats_64_fast.txt", "w") as o:
 PY
 # the same trace with the step boundary in its own kernel: k_pair_dpd_ring's average is then the force kernel ALONE (the graded figure)
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_ktp -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 50 --opt fuse_pair=0 > $R/gpurun_out/${tag}_ktp.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_ktp -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline --other-boxes "" --steps 300 --warmup 50 --opt fuse_pair=0 > $R/gpurun_out/${tag}_ktp.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob
@@ -33,19 +33,21 @@ with open("gpurun_out/${tag}_kernel_stats_64_pair_only.txt", "w") as o:
         o.write("%-90s calls %6s avg_us %9.2f total_ms %9.2f pct %6s\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"][:6]))
 PY
 echo "pair-only kernel trace done"
-bash tools/pmc_run.sh ${tag}_pmc
+bash tools/pmc_run.sh ${tag}_pmc --other-boxes ""
 ( echo "# rocprofv3 --pmc <counters> -- python3 bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline   (64^3 rho=4, dpd/fast/meso; one pass per counter group; mean per dispatch)"; cat gpurun_out/${tag}_pmc.summary.txt ) > gpurun_out/${tag}_pmc_64_fast.txt
 echo "pmc done"
 # the force kernel launched alone (step boundary in its own kernel): HBM traffic of the graded kernel
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 240 rocprofv3 --pmc $c -d $R/gpurun_out/${tag}_pmcp/$c -o x --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline --opt fuse_pair=0 > $R/gpurun_out/${tag}_pmcp.$c.log 2>&1
+  timeout -k 10 240 rocprofv3 --pmc $c -d $R/gpurun_out/${tag}_pmcp/$c -o x --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline --other-boxes "" --opt fuse_pair=0 > $R/gpurun_out/${tag}_pmcp.$c.log 2>&1
 done
 cd $R
 ( echo "# rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline --opt fuse_pair=0   (force kernel alone; mean per dispatch, KB)"; python3 tools/pmc_summary.py gpurun_out/${tag}_pmcp pair_dpd merge_xvt nve ) > gpurun_out/${tag}_pmc_pair_only.txt
 echo "pair-only pmc done"
 # issue / texture-path counters of the force kernel launched alone (the limiter block of the bench line)
-bash tools/pmc_focus.sh ${tag}_focus --opt fuse_pair=0 > gpurun_out/${tag}_focus.log 2>&1 || echo "focus counters failed"
+bash tools/pmc_focus.sh ${tag}_focus --other-boxes "" --opt fuse_pair=0 > gpurun_out/${tag}_focus.log 2>&1 || echo "focus counters failed"
+# ... and of the fp64 style (dpd/meso: configs[1] and configs[3])
+bash tools/pmc_focus.sh ${tag}_focus_dp --other-boxes "" --style dpd/meso --opt fuse_pair=0 > gpurun_out/${tag}_focus_dp.log 2>&1 || echo "fp64 focus counters failed"
 echo "focus pmc done"
 # the other configurations of BASELINE.json (parity-test cases; timed for the record)
 timeout -k 10 300 python3 bench.py --box 25 --no-cpu-baseline > gpurun_out/${tag}_bench25_fast.json 2>/dev/null
