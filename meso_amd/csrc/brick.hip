@@ -368,7 +368,10 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
     // workgroup's LDS and wave slots are free again only when its slowest wave is done, and a wave with two light bins takes a
     // third one (32^3: 44 -> 39.5 us per build, 64^3: 180 -> 177).  4-brick: bins dealt out by number, as before.  (The counter is
     // set before the barrier that ends the staging.)
-    for (int k = QUEUE ? __builtin_amdgcn_readfirstlane(w) : w + WAVES * part; k < CODES; k += QUEUE ? 0 : WAVES * split) {
+    // (2-brick with split > 1 - boxes whose bricks fill little more than one round of workgroups: `split` workgroups stage the same
+    // neighbourhood and share its eight bins, draw d of part p = bin d * split + p: the launch has `split` times the workgroups of
+    // a fraction of the work, so the staging of one overlaps the scans of the others instead of all staging at once)
+    for (int k = QUEUE ? __builtin_amdgcn_readfirstlane(w) * split + part : w + WAVES * part; k < CODES; k += QUEUE ? 0 : WAVES * split) {
         const int kx = (k & 1) | (((k >> 3) & 1) << 1), ky = ((k >> 1) & 1) | (((k >> 4) & 1) << 1),
                   kz = ((k >> 2) & 1) | (((k >> 5) & 1) << 1);
         const int hb = (kx + 1) + H * ((ky + 1) + H * (kz + 1));
@@ -376,14 +379,14 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
         const int own0 = __builtin_amdgcn_readfirstlane(hoff[hb]), na = __builtin_amdgcn_readfirstlane(hloc[hb]);
         // (the next bin is drawn when this iteration ends, whichever way it ends)
         struct Next {
-            int &k; int lane; int *q; int kcur;
+            int &k; int lane; int *q; int kcur; int split, part;
             __device__ ~Next() {
                 if (!QUEUE) return;
                 int v = 0;
                 if (lane == 0) v = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                k = __builtin_amdgcn_readfirstlane(v);
+                k = __builtin_amdgcn_readfirstlane(v) * split + part;
             }
-        } next_{k, lane, &nextcell, k};
+        } next_{k, lane, &nextcell, k, split, part};
         if (na == 0) continue;
         // the 9 candidate runs of the bin's stencil and their prefix: lanes 0..8 read the two offsets of "their" run in one LDS
         // round trip, v_readlane moves the 18 values to SGPRs.  The table lives only while candidates are loaded - 19 SGPRs
@@ -735,14 +738,17 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         // 2x2x2 bricks: eight times as many workgroups of 4 waves
         BrickArgs g2 = g;
         g2.nactive = g.order2 ? g.norder2 : g.M / 8;
-        const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
+        // (option brick2_split: several workgroups per brick - measured, round 4: every workgroup stages the whole neighbourhood, and
+        // that costs more than the finer grain buys at every size: 25^3 24.8 -> 25.7 us with two, 32^3 39.6 -> 45.2, 48^3 93 -> 108)
+        const int split2 = g.split2 > 0 ? g.split2 : 1;
+        const dim3 tgrid2((g2.nactive * split2 + 7) / 8 * 8);
         const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2 + TB_ROWPAD * 2;
         if (tg.on) {
             if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-            hipLaunchKernelGGL((k_tile_build<2, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, tg);
+            hipLaunchKernelGGL((k_tile_build<2, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, split2, dbg, tg);
         } else {
             if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-            hipLaunchKernelGGL((k_tile_build<2, false>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, tg);
+            hipLaunchKernelGGL((k_tile_build<2, false>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, split2, dbg, tg);
         }
     } else {
     int split = 1;

@@ -146,7 +146,13 @@ private:
     // several ranks, borders without a host round trip (comm.hip): fixed-capacity messages, counts in band
     std::vector<int> mr_cap_s, mr_cap_r;          // ghosts per peer message, from the counts of the previous rebuild (same on both sides)
     bool mr_caps_ready = false, mr_pending = false;
-    double mr_cap_margin = 0.25;                  // option: capacity = count * (1 + margin) + 256
+    // option: capacity = count * (1 + margin) + 256.  A border message is sent at its capacity, so head-room costs wire bytes
+    // (64 B per ghost, once per rebuild); what it must cover: between two rebuilds an atom moves at most D (the neighbour list is
+    // only valid while 2 D <= skin), so the ghosts of a slab of width r_c + skin can grow by at most the atoms of a layer D thick
+    // next to it: D / (r_c + skin) <= 11.5 % at equal density, times the density contrast across the slab's edge.  0.5 covers a
+    // contrast of 4 (phase-separating decks); a message that still outgrows it ends the job with an error on every rank
+    // (the launcher tears the job down on the first rank's status), never with a truncated ghost list.
+    double mr_cap_margin = 0.5;
     int *d_mr = nullptr;                          // device-side offsets and counts of the exchange in flight (128 ints)
     // migration with the counts in the messages (comm.hip)
     std::vector<int> mig_cap_s, mig_cap_r;
@@ -296,6 +302,7 @@ private:
     // one rank: the rebuild in three launches (rebuild.hip) - count, place + gather + ghost emission, ghosts
     int *brick_order2 = nullptr;    // launch order of the 2-bricks (those that own real cells, fullest first)
     int brick2 = 1;                 // option: 2x2x2 bricks in the list builder (0: the 4x4x4 bricks of rounds 1-2)
+    int brick2_split = 0;           // option: workgroups per 2-brick (0: by the number of bricks, see launch_tile_build)
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on

@@ -318,7 +318,8 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "shell_walk") { shell_walk = (int)val; return 0; }
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
-    if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }               // 0: never the 2x2x2 bricks of small boxes
+    if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
+    if (key == "brick2_split") { brick2_split = (int)val; return 0; }      // workgroups per 2-brick of the list builder (0: by size)               // 0: never the 2x2x2 bricks of small boxes
     if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
@@ -1495,6 +1496,7 @@ int Engine::build_cells_and_table()
                 bb.gcnt = (fused_active && fused_gcnt_valid) ? fr_gcnt : (mr_runs ? mr_gcnt : nullptr);
                 if (brick2_off || !brick2) bb.maxh2 = 0;
                 bb.brick2_limit = brick2_limit;
+                bb.split2 = brick2_split;
                 // tagged rows (RowTagArgs): shell at build time + pairing class in every entry, while indices fit 25 bits and the
                 // staged neighbourhood's slots 13; the shells split [base, r_list^2) evenly in r^2, base = the largest cutoff plus
                 // the rounding of the merged fp32 coordinates (|x| up to half the sub-box: 4 ulp + 1e-5)

@@ -201,6 +201,7 @@ struct BrickArgs {
     int maxh;            // halo atoms a brick may hold (pitch of hmap, LDS of the tile builder); chosen from the density
     int maxh2;           // the same for the 2x2x2 brick of small boxes (4x4x4-bin neighbourhood); 0: never use it
     int brick2_limit;    // 2-bricks while the bin grid spans at most this many 4-bricks
+    int split2;          // workgroups per 2-brick (0: by the number of bricks)
     const int *order2;   // [norder2] the 2-bricks that own real cells, by decreasing number of them (null: every brick, in Morton order)
     int norder2;
     int maxown;          // atoms a brick may own (0: unlimited - only the brick-layout kernels have a static bound)
