@@ -64,6 +64,9 @@ namespace meso {
 #ifndef RG_LDS_COORD
 #define RG_LDS_COORD 1              // tagged rows: an in-group candidate's coordinate comes from the workgroup's LDS copy, not from a gather
 #endif
+#ifndef RG_HEAVY2
+#define RG_HEAVY2 0                 // 1: two hit batches in flight in the heavy phase (measured: see profiles/r04_notes.md)
+#endif
 #ifndef RG_FIX_WAVES
 #define RG_FIX_WAVES 0
 #endif
@@ -239,6 +242,15 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     int pn = 0;                   // records of the batch whose gathers are in flight
     u32 pe = 0, pm = 0;
     float4 pc2 = make_float4(0.f, 0.f, 0.f, 0.f), pv2 = pc2;
+#if RG_HEAVY2
+    // (timing experiment: TWO hit batches with their velocity gathers in flight - issue() fills the younger set, shift() ages it)
+    int qn = 0;
+    u32 qe = 0, qm = 0;
+    float4 qc2 = pc2, qv2 = pc2;
+#define RG_IN(x) q##x
+#else
+#define RG_IN(x) p##x
+#endif
 
     // evaluate the pending batch (lane = hit)
 #ifdef RG_STAMP
@@ -328,11 +340,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
         ST_BEGIN();
         if (lane < nb) {
             const float4 rec = ring[(qhead + lane) & (RING - 1)];
-            pe = __float_as_uint(rec.w);
-            pc2 = make_float4(rec.x, rec.y, rec.z, 0.f);
-            if (WIDE) pm = ringm[(qhead + lane) & (RING - 1)];
-            const u32 joff = (WIDE ? pe : (pe & RG_INDEX_MASK)) << 4;
-            if (!NT1) pc2.w = __uint_as_float((u32)ringt[(qhead + lane) & (RING - 1)]);     // (a fourth gather per hit before)
+            RG_IN(e) = __float_as_uint(rec.w);
+            RG_IN(c2) = make_float4(rec.x, rec.y, rec.z, 0.f);
+            if (WIDE) RG_IN(m) = ringm[(qhead + lane) & (RING - 1)];
+            const u32 joff = (WIDE ? RG_IN(e) : (RG_IN(e) & RG_INDEX_MASK)) << 4;
+            if (!NT1) RG_IN(c2).w = __uint_as_float((u32)ringt[(qhead + lane) & (RING - 1)]);     // (a fourth gather per hit before)
             if (RG_LDS_VELOC && (RG_LV_ALL || (NPART_ == 1 && FAST)) && !WIDE && a.lds_veloc) {
             // a partner of this workgroup's group (the pairs evaluated once for both, 64 % of the hits) has its velocity record in
             // the LDS copy of the wave that owns it: those lanes read it there and give the gather an out-of-range offset (one lane
@@ -340,13 +352,18 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
             // alone and two lanes per atom 19.0 -> 20.4 us, so not there: PairArgs::lds_veloc, set by the launcher from the size;
             // the fp64 style lost 4 % with it at 64^3: fp32 kernels only)
             // (the LDS record is read - and chosen - when the batch is evaluated: a select here would wait for the gather at once)
-            const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0 && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end);
-            pv2 = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
-            } else pv2 = buf_load4(rv, joff);
+            const bool inwg = SHARE && (WIDE ? (RG_IN(m) & 64u) : (RG_IN(e) & RG_SHARED_BIT)) != 0 && (!TAGGED || (RG_IN(e) & RG_INDEX_MASK) < (u32)a.end);
+            RG_IN(v2) = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
+            } else RG_IN(v2) = buf_load4(rv, joff);
         }
-        pn = nb;
+        RG_IN(n) = nb;
         qhead += nb;
         ST_END(st_issue);
+    };
+    auto shift = [&]() __attribute__((always_inline)) {
+#if RG_HEAVY2
+        pn = qn; pe = qe; pm = qm; pc2 = qc2; pv2 = qv2; qn = 0;
+#endif
     };
 
     // chunk ch of my row: two 16-byte words (lanes past their row: zeros, never used)
@@ -401,7 +418,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
             }
             qtail += __popcll(m);
             if (RG_RING < 256 || (q & 1)) {
-                while (qtail - qhead >= 64) { compute(); issue(64); }
+                while (qtail - qhead >= 64) { compute(); shift(); issue(64); }
             }
         }
     };
@@ -464,7 +481,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
                         if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(cc[b].w);
                     }
                     qtail += __popcll(m);
-                    while (qtail - qhead >= 64) { compute(); issue(64); }
+                    while (qtail - qhead >= 64) { compute(); shift(); issue(64); }
                 }
             }
             cpn = 0;
@@ -544,8 +561,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
 #ifdef RG_STAMP
     const unsigned long long st_light = __builtin_amdgcn_s_memtime();
 #endif
-    compute();
-    while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
+    compute(); shift(); compute();
+    while (qtail > qhead) { issue(min(64, qtail - qhead)); shift(); compute(); }
 
 #ifdef RG_STAMP
     const unsigned long long st_drained = __builtin_amdgcn_s_memtime();
