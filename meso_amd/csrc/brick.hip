@@ -174,13 +174,7 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 #ifndef TB_EXPANDED
 #define TB_EXPANDED 0        // 1: distances in the expanded form on brick-relative coordinates (see the scan); 0: (o - c)^2 on absolute ones
 #endif
-#ifndef TB_PACK2
-#define TB_PACK2 0
-#endif
-#ifndef TB_LATE_CLAMP
-#define TB_LATE_CLAMP 0
-#endif
-#define TB_ROWPAD (TB_LATE_CLAMP ? 384 : 64)      // entries behind the last staged row (see the scan step)
+#define TB_ROWPAD 64               // entries behind the last staged row (see the scan step)
 #define TB_ROWCAP_MAX 1024         // rows are staged in LDS at their full capacity n_col (2 bytes per entry)
 
 // E: brick edge in bins.  4: the 4x4x4 brick (64 Morton codes, 6x6x6-bin neighbourhood, 10 waves) of rounds 1-2.  2 (default):
@@ -463,38 +457,19 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
             // straight-line code lets the chains of the group's atoms overlap.  FULL: all TB_G own atoms present (16 independent
             // chains for 4 batches).  Special-bond partners are dropped by k_filter_exclusion afterwards.
             auto scan = [&](auto full, const int cs, const float cx, const float cy, const float cz, const float c2) {
-#if TB_PACK2
-                // (timing experiment: the distances of two own atoms per packed instruction - v_pk_add / v_pk_mul / v_pk_fma_f32)
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                f2 dd[TB_G / 2];
-#pragma unroll
-                for (int p = 0; p < TB_G / 2; p++) {
-                    const f2 axp = {ax[2 * p], ax[2 * p + 1]}, ayp = {ay[2 * p], ay[2 * p + 1]}, azp = {az[2 * p], az[2 * p + 1]};
-                    const f2 dx = axp - (f2){cx, cx}, dy = ayp - (f2){cy, cy}, dz = azp - (f2){cz, cz};
-                    dd[p] = dx * dx + dy * dy + dz * dz;
-                }
-#endif
 #pragma unroll
                 for (int t = 0; t < TB_G; t++) {
                     if (decltype(full)::value || t < ng) {
                         float d;
                         if (TB_EXPANDED) d = __builtin_fmaf(ax[t], cx, __builtin_fmaf(ay[t], cy, __builtin_fmaf(az[t], cz, c2)));
-#if TB_PACK2
-                        else d = dd[t >> 1][t & 1];
-#else
                         else { const float dx = ax[t] - cx, dy = ay[t] - cy, dz = az[t] - cz; d = dx * dx + dy * dy + dz * dz; }
-#endif
                         const u64 m = __builtin_amdgcn_fcmpf(d, th[t], 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33);
                         const bool hit = (d <= th[t]) & (cs != own0 + g0 + t);
                         // (row position = entries so far [scalar, SALU work, kept inside the row] + hits in lower lanes [mbcnt x 2,
                         // shift-add].  The lane part is not clamped - one instruction of eleven per step, 4 % of the kernel: a row
                         // that overflows writes up to 63 entries into the next row, or into the TB_ROWPAD entries behind the last.
                         // Every entry written is a valid halo slot, the overflow is reported below and ends the run, as it did.)
-#if TB_LATE_CLAMP
-                        const int have = nrow[t];         // (clamped once per four batches, see below: one SALU instruction less per step)
-#else
                         const int have = min(nrow[t], n_col - 1);
-#endif
                         const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
                         // the entry's distance shell at build time rides in the top three bits of its 16-bit slot (tg.on; slots < 8192):
                         // shell 0 = inside the cutoff, s >= 1: d in [base + (s - 1) / k, base + s / k).  v_cvt_u32_f32 saturates
@@ -519,21 +494,11 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                 for (int b = 0; b < 4; b++)
                     if (b < nbatch && dbg != 3) scan(std::false_type{}, cs4[b], cx4[b], cy4[b], cz4[b], cq4[b]);
             }
-#if TB_LATE_CLAMP
-            // (a row that outgrew its capacity during the four batches above has written valid slots into the rows behind it - at most
-            // 4 x 64 entries, TB_ROWPAD covers the last row - and is reported below; from here on it stays inside its capacity)
-#pragma unroll
-            for (int t = 0; t < TB_G; t++) nrow[t] = min(nrow[t], n_col + 1);
-#endif
             for (int b = 4; b < nbatch; b++) {
                 int cs[4];
                 float cx[4], cy[4], cz[4], cq[4];
                 load_cand(b, 1, cs, cx, cy, cz, cq);
                 scan(std::false_type{}, cs[0], cx[0], cy[0], cz[0], cq[0]);
-#if TB_LATE_CLAMP
-#pragma unroll
-                for (int t = 0; t < TB_G; t++) nrow[t] = min(nrow[t], n_col + 1);
-#endif
             }
             // rows out, 16 lanes per own atom of the group: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become
             // global indices, the tail of the last chunk is padded with the atom itself

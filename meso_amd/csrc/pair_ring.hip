@@ -58,20 +58,11 @@ namespace meso {
 #ifndef RG_CK
 #define RG_CK 2                     // tagged rows: candidate batches requested together (1, 3, 4 and 8 measured: within 2 % at 64^3)
 #endif
-#ifndef RG_LV_ALL
-#define RG_LV_ALL 0                 // 1: in-group partners' velocity records from LDS in every variant of the kernel (not only one lane per atom, fp32)
-#endif
 #ifndef RG_LDS_COORD
 #define RG_LDS_COORD 1              // tagged rows: an in-group candidate's coordinate comes from the workgroup's LDS copy, not from a gather
 #endif
-#ifndef RG_HEAVY2
-#define RG_HEAVY2 0                 // 1: two hit batches in flight in the heavy phase (measured: see profiles/r04_notes.md)
-#endif
 #ifndef RG_FIX_WAVES
 #define RG_FIX_WAVES 0
-#endif
-#ifndef RG_SYNC
-#define RG_SYNC 0                   // 1: a group is tested right after it was requested (no group pending across the next row chunk)
 #endif
 #ifndef RG_QSLOTS
 #define RG_QSLOTS 4                 // tagged rows: entry slots of every lane per fill of the candidate queue (8: a whole row chunk - 3 % faster
@@ -242,15 +233,6 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     int pn = 0;                   // records of the batch whose gathers are in flight
     u32 pe = 0, pm = 0;
     float4 pc2 = make_float4(0.f, 0.f, 0.f, 0.f), pv2 = pc2;
-#if RG_HEAVY2
-    // (timing experiment: TWO hit batches with their velocity gathers in flight - issue() fills the younger set, shift() ages it)
-    int qn = 0;
-    u32 qe = 0, qm = 0;
-    float4 qc2 = pc2, qv2 = pc2;
-#define RG_IN(x) q##x
-#else
-#define RG_IN(x) p##x
-#endif
 
     // evaluate the pending batch (lane = hit)
 #ifdef RG_STAMP
@@ -268,7 +250,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
             if (lane < pn) {
                 const u32 owner = WIDE ? (pm & 63u) : pe >> RG_OWNER_SHIFT;
                 const float4 ci = own_c[owner], vi = own_v[owner];
-                if (RG_LDS_VELOC && (RG_LV_ALL || (NPART_ == 1 && FAST)) && !WIDE && a.lds_veloc) {
+                if (RG_LDS_VELOC && (NPART_ == 1 && FAST) && !WIDE && a.lds_veloc) {
                     // in-group partner: its velocity record is the LDS copy of the wave that owns it (see issue())
                     const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0 && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end);
                     const u32 pl = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;                // (in-group: < NB)
@@ -340,30 +322,25 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
         ST_BEGIN();
         if (lane < nb) {
             const float4 rec = ring[(qhead + lane) & (RING - 1)];
-            RG_IN(e) = __float_as_uint(rec.w);
-            RG_IN(c2) = make_float4(rec.x, rec.y, rec.z, 0.f);
-            if (WIDE) RG_IN(m) = ringm[(qhead + lane) & (RING - 1)];
-            const u32 joff = (WIDE ? RG_IN(e) : (RG_IN(e) & RG_INDEX_MASK)) << 4;
-            if (!NT1) RG_IN(c2).w = __uint_as_float((u32)ringt[(qhead + lane) & (RING - 1)]);     // (a fourth gather per hit before)
-            if (RG_LDS_VELOC && (RG_LV_ALL || (NPART_ == 1 && FAST)) && !WIDE && a.lds_veloc) {
+            pe = __float_as_uint(rec.w);
+            pc2 = make_float4(rec.x, rec.y, rec.z, 0.f);
+            if (WIDE) pm = ringm[(qhead + lane) & (RING - 1)];
+            const u32 joff = (WIDE ? pe : (pe & RG_INDEX_MASK)) << 4;
+            if (!NT1) pc2.w = __uint_as_float((u32)ringt[(qhead + lane) & (RING - 1)]);     // (a fourth gather per hit before)
+            if (RG_LDS_VELOC && (NPART_ == 1 && FAST) && !WIDE && a.lds_veloc) {
             // a partner of this workgroup's group (the pairs evaluated once for both, 64 % of the hits) has its velocity record in
             // the LDS copy of the wave that owns it: those lanes read it there and give the gather an out-of-range offset (one lane
             // per atom, launches of several rounds of waves: 64^3 fused launch 121.9 -> 119.7 us, +1.2 % steps/s; 48^3 44.7 -> 46.6 us
             // alone and two lanes per atom 19.0 -> 20.4 us, so not there: PairArgs::lds_veloc, set by the launcher from the size;
             // the fp64 style lost 4 % with it at 64^3: fp32 kernels only)
             // (the LDS record is read - and chosen - when the batch is evaluated: a select here would wait for the gather at once)
-            const bool inwg = SHARE && (WIDE ? (RG_IN(m) & 64u) : (RG_IN(e) & RG_SHARED_BIT)) != 0 && (!TAGGED || (RG_IN(e) & RG_INDEX_MASK) < (u32)a.end);
-            RG_IN(v2) = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
-            } else RG_IN(v2) = buf_load4(rv, joff);
+            const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0 && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end);
+            pv2 = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
+            } else pv2 = buf_load4(rv, joff);
         }
-        RG_IN(n) = nb;
+        pn = nb;
         qhead += nb;
         ST_END(st_issue);
-    };
-    auto shift = [&]() __attribute__((always_inline)) {
-#if RG_HEAVY2
-        pn = qn; pe = qe; pm = qm; pc2 = qc2; pv2 = qv2; qn = 0;
-#endif
     };
 
     // chunk ch of my row: two 16-byte words (lanes past their row: zeros, never used)
@@ -418,7 +395,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
             }
             qtail += __popcll(m);
             if (RG_RING < 256 || (q & 1)) {
-                while (qtail - qhead >= 64) { compute(); shift(); issue(64); }
+                while (qtail - qhead >= 64) { compute(); issue(64); }
             }
         }
     };
@@ -481,7 +458,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
                         if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(cc[b].w);
                     }
                     qtail += __popcll(m);
-                    while (qtail - qhead >= 64) { compute(); shift(); issue(64); }
+                    while (qtail - qhead >= 64) { compute(); issue(64); }
                 }
             }
             cpn = 0;
@@ -490,17 +467,6 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
         // before - whose data has arrived meanwhile - is tested
         auto cinwg = [&](u32 rec) __attribute__((always_inline)) { return RG_LDS_COORD && SHARE && (rec & RG_SHARED_BIT) != 0 && (rec & RG_INDEX_MASK) < (u32)a.end; };
         auto cstep = [&](int c0, int n) __attribute__((always_inline)) {
-#if RG_SYNC
-            // (all batches of the chunk requested together and tested at once, in order: the first test waits for the first gather only)
-#pragma clang loop unroll(full)
-            for (int b = 0; b < CK; b++)
-                if (b * 64 < n) crec[b] = cand[c0 + b * 64 + lane];
-#pragma clang loop unroll(full)
-            for (int b = 0; b < CK; b++)
-                if (b * 64 < n) cc[b] = buf_load4(rc, ((b * 64 + lane < n) & !cinwg(crec[b])) ? (crec[b] & RG_INDEX_MASK) << 4 : 0xFFFFFFF0u);
-            cpn = n;
-            ctest();
-#else
             u32 r2[CK];
             float4 c2[CK];
 #pragma clang loop unroll(full)
@@ -515,7 +481,6 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
 #pragma clang loop unroll(full)
             for (int b = 0; b < CK; b++) { crec[b] = r2[b]; cc[b] = c2[b]; }
             cpn = n;
-#endif
         };
         int4 w0, w1;
         ldrow(0, w0, w1);
@@ -561,8 +526,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
 #ifdef RG_STAMP
     const unsigned long long st_light = __builtin_amdgcn_s_memtime();
 #endif
-    compute(); shift(); compute();
-    while (qtail > qhead) { issue(min(64, qtail - qhead)); shift(); compute(); }
+    compute();
+    while (qtail > qhead) { issue(min(64, qtail - qhead)); compute(); }
 
 #ifdef RG_STAMP
     const unsigned long long st_drained = __builtin_amdgcn_s_memtime();
@@ -650,7 +615,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     int n = p.end - p.beg;
     if (n <= 0) return;
     PairArgs pl = p;
-    pl.lds_veloc = (n >= 700000 || RG_LV_ALL) ? 1 : 0;      // (see issue(): pays from about two rounds of waves on)
+    pl.lds_veloc = n >= 700000 ? 1 : 0;      // (see issue(): pays from about two rounds of waves on)
     const bool nt1 = p.ntypes == 1;
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * (fast ? 8 * 4 : N_COEFF * 8);
     // more than 2^25 atoms (locals + ghosts): the record word cannot hold owner lane, pairing flag and index any more
