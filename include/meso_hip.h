@@ -61,7 +61,16 @@ int meso_device_sync(meso_ctx *ctx);
  *                    in a header, so the ghost stage needs neither a count exchange nor a host round trip
  *   mig_cap_floor 64  several ranks, async_counts: a migration message has the capacity 2 * (count of the previous rebuild) + floor and
  *                    carries its counts in a header (no separate count exchange); one that does not fit is sent again, exactly
- *   mr_cap_margin 0.25  see async_counts (a message that outgrows its capacity is an error, reported at the end of run())
+ *   mr_cap_margin 0.5  see async_counts (a message that outgrows its capacity is an error, reported at the end of run(); between
+ *                    two rebuilds a slab's ghosts can grow by at most the atoms of a layer as thick as the largest displacement
+ *                    next to it - 11.5 % at equal density with the default skin)
+ *   shell_walk    0  1 = tagged neighbour rows (distance shell at build time + Newton-pairing class in the spare bits of an
+ *                    entry), a device-side displacement bound and a force kernel that looks only at the entries that can be
+ *                    inside the cutoff on the current step; bit-identical forces, measured slower as a whole step (default 0);
+ *                    2 = the same rows, every shell walked (timing A/B)
+ *   split_gather -1  one rank: the rebuild's placing kernel only orders and a streaming pass moves the payload
+ *                    (-1 = boxes of at least 200 000 local atoms, 0 off, 1 on)
+ *   brick2_split  0  list builder: workgroups per 2x2x2 brick (0 = 1; more measured slower)
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
  *                    images (no k_pack_forward launch between rebuilds); -1 = for boxes of at most 524 288 local atoms, 0 off, 1 on
  *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost
