@@ -283,11 +283,14 @@ __host__ __device__ inline float polyval_integral_f32(float x, const float *row)
 // pair_dpd_meso.cu:120-160), one definition for the force kernels; compiled uncontracted (explicit fma only).
 struct PairCoeff64 { double cutinv, expw, a0, gamma, sigma; };
 template <bool EW1>
+// cutsq_exact >= 0: the caller filtered with a widened fp32 test; the exact test of the reference (rsq < cutsq && rsq >= epsilon, on
+// the same fp64 r^2 as rsq_f64) is made here and a pair that fails it gets a zero force
 __device__ inline void pair_dpd_f64(const float4 ci, const float4 cj, const float4 vi, const float4 vj, const PairCoeff64 &c,
-                                    double dt_inv_sqrt, double &fx, double &fy, double &fz)
+                                    double dt_inv_sqrt, double &fx, double &fy, double &fz, double cutsq_exact = -1.0)
 {
     const double dx = (double)ci.x - (double)cj.x, dy = (double)ci.y - (double)cj.y, dz = (double)ci.z - (double)cj.z;
     const double rsq = dx * dx + dy * dy + dz * dz;
+    if (cutsq_exact >= 0.0 && !(rsq < cutsq_exact && rsq >= MESO_EPSILON_SQ)) { fx = fy = fz = 0.0; return; }
     const double rn = gaussian_tea(__float_as_uint(vi.w), __float_as_uint(vj.w));
     const double rinv = rsqrt(rsq);
     const double r = rsq * rinv;
