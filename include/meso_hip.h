@@ -64,13 +64,11 @@ int meso_device_sync(meso_ctx *ctx);
  *   mr_cap_margin 0.5  see async_counts (a message that outgrows its capacity is an error, reported at the end of run(); between
  *                    two rebuilds a slab's ghosts can grow by at most the atoms of a layer as thick as the largest displacement
  *                    next to it - 11.5 % at equal density with the default skin)
- *   shell_walk    0  1 = tagged neighbour rows (distance shell at build time + Newton-pairing class in the spare bits of an
- *                    entry), a device-side displacement bound and a force kernel that looks only at the entries that can be
- *                    inside the cutoff on the current step; bit-identical forces, measured slower as a whole step (default 0);
- *                    2 = the same rows, every shell walked (timing A/B)
+ *   row_part      1  the list builder writes every row in two sections (meso_neigh_parts): what the atom evaluates in front,
+ *                    mirrored in-group entries behind; the ring kernel walks the front section only.  0 = plain rows, pairing
+ *                    decided per entry and step from the two indices (round-4 form; bit-identical forces)
  *   split_gather -1  one rank: the rebuild's placing kernel only orders and a streaming pass moves the payload
  *                    (-1 = boxes of at least 200 000 local atoms, 0 off, 1 on)
- *   brick2_split  0  list builder: workgroups per 2x2x2 brick (0 = 1; more measured slower)
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
  *                    images (no k_pack_forward launch between rebuilds); -1 = for boxes of at most 524 288 local atoms, 0 off, 1 on
  *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost
@@ -185,12 +183,14 @@ int meso_neigh_info(meso_ctx *ctx, int *n_col, int *max_count, double *avg_count
 /* row-major copy of the neighbour table: table[i*stride + p], rows of atoms in device order */
 int meso_neigh_download(meso_ctx *ctx, int *count, int *table, int stride);
 int meso_merged_download(meso_ctx *ctx, float *coord4, float *veloc4, int nall);
-/* tagged rows (round 4; no counterpart in the reference, whose rows keep "core from the front, skin from the back",
- * neigh_build_meso.cu:91-115): *tagged = 1 when the table in use carries, above the 25 index bits of an entry, its distance shell
- * at build time (bits 28..30: 0 = r^2 < base, s >= 1: r^2 in [base + (s-1)/k, base + s/k)), the mirror bit (31: partner in the same
- * aligned group of `group` atoms, lower index) and the pair-once bit (25: same group, higher index).  raw != NULL: the table as
- * stored, bits included, laid out like meso_neigh_download's. */
-int meso_neigh_tags(meso_ctx *ctx, int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride);
+/* partitioned rows (round 5; the reference keeps its rows in two sections as well - "core from the front, skin from the back",
+ * neigh_build_meso.cu:91-115 - split by distance; here by who evaluates a pair): *parted = 1 when the table in use holds, per atom,
+ * a front section (the pairs this atom evaluates: partners outside its aligned group of `group` atoms one-sided, partners inside
+ * it for both atoms) and a back section (in-group partners that evaluate the pair themselves), each padded with the atom itself
+ * to a multiple of 8 entries.  meso_neigh_download returns the neighbours alone, front section first.
+ * nfront, nback (nullable): [nlocal] section lengths; front, back (nullable): the sections as stored, padding included,
+ * front[i * stride + p] / back[i * stride + p]. */
+int meso_neigh_parts(meso_ctx *ctx, int *parted, int *group, int *nfront, int *nback, int *front, int *back, int stride);
 /* per-phase device time (ms, HIP events on the engine's stream) accumulated since the last reset;
  * names: "pair","neigh","nve","merge","halo","reorder","bin","total_steps" */
 int meso_timer_reset(meso_ctx *ctx);

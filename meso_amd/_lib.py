@@ -75,7 +75,7 @@ SIGNATURES = {
     "meso_compute_pressure": (_i, [_vp, C.POINTER(_d)]),
     "meso_neigh_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_d), C.POINTER(_i64)]),
     "meso_neigh_download": (_i, [_vp, _vp, _vp, _i]),
-    "meso_neigh_tags": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), _vp, _i]),
+    "meso_neigh_parts": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), _vp, _vp, _vp, _vp, _i]),
     "meso_merged_download": (_i, [_vp, _vp, _vp, _i]),
     "meso_timer_reset": (_i, [_vp]),
     "meso_timer_get": (_i, [_vp, _cp, C.POINTER(_d), C.POINTER(_i64)]),

@@ -337,16 +337,20 @@ class Meso:
         self._ck(self.lib.meso_neigh_download(self._h, _p(count), _p(table), stride))
         return count, table
 
-    def neigh_tags(self, raw=False, stride=None):
-        """Tag geometry of the table in use (meso_neigh_tags); raw=True: also the table as stored, shell / pairing bits included."""
+    def neigh_parts(self, raw=False, stride=None):
+        """Row sections of the table in use (meso_neigh_parts); raw=True: also the two sections as stored, padding included."""
         t, g = C.c_int(), C.c_int()
-        b, k, e = C.c_double(), C.c_double(), C.c_double()
+        n = self.counts()[0]
+        nf, nb = np.zeros(n, np.int32), np.zeros(n, np.int32)
         stride = self.neigh_info()["n_col"] if stride is None else stride
-        tab = np.zeros((self.counts()[0], stride), np.int32) if raw else None
-        self._ck(self.lib.meso_neigh_tags(self._h, C.byref(t), C.byref(g), C.byref(b), C.byref(k), C.byref(e), _p(tab) if raw else None, stride))
-        out = {"tagged": bool(t.value), "group": g.value, "base": b.value, "k": k.value, "eps": e.value}
+        front = np.full((n, stride), -1, np.int32) if raw else None
+        back = np.full((n, stride), -1, np.int32) if raw else None
+        self._ck(self.lib.meso_neigh_parts(self._h, C.byref(t), C.byref(g), _p(nf), _p(nb), _p(front) if raw else None,
+                                           _p(back) if raw else None, stride))
+        out = {"parted": bool(t.value), "group": g.value, "nfront": nf, "nback": nb}
         if raw:
-            out["table"] = tab.view(np.uint32)
+            out["front"] = front
+            out["back"] = back
         return out
 
     def merged(self):

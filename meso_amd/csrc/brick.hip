@@ -183,15 +183,12 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 // gain as well although 8 atoms are staged per own atom instead of 3.4 (staging is a small part; the finer grain hides the
 // staging latency of one workgroup behind the scans of the seven others): 32^3 77 -> 52 us, 64^3 303 -> 265, 128^3 2257 -> 1784.
 // The 4-brick remains the fallback when a 2-brick neighbourhood nears its LDS stage (which does not grow).
-template <int E, bool TAGS>
+template <int E>
 __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3 : 2) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
                                                               int n_col, int *__restrict__ count, int *__restrict__ table,
-                                                              int *__restrict__ overflow, int split, int dbg, RowTagArgs tg)
+                                                              int *__restrict__ overflow, int split, int dbg, RowPartArgs pt)
 {
 #pragma clang fp contract(fast)
-    // shell walk (see RowTagArgs, kernels.h): the launch's first workgroup opens a new displacement account for the list
-    if (tg.disp && blockIdx.x == 0)
-        for (int k = threadIdx.x; k < MESO_DISP_SLOTS * MESO_DISP_SUB; k += blockDim.x) tg.disp[(size_t)k * MESO_DISP_PITCH] = 0.f;
     constexpr int CODES = E * E * E, H = E + 2, NHB = H * H * H, THREADS = E == 4 ? BRK_THREADS : TB2_THREADS, WAVES = THREADS / 64;
     const int maxh = E == 4 ? g.maxh : g.maxh2;
     // staged neighbourhood, SoA (candidate reads are consecutive slots); sized at launch for g.maxh halo atoms, so denser
@@ -471,16 +468,7 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                         // Every entry written is a valid halo slot, the overflow is reported below and ends the run, as it did.)
                         const int have = min(nrow[t], n_col - 1);
                         const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                        // the entry's distance shell at build time rides in the top three bits of its 16-bit slot (tg.on; slots < 8192):
-                        // shell 0 = inside the cutoff, s >= 1: d in [base + (s - 1) / k, base + s / k).  v_cvt_u32_f32 saturates
-                        // negative arguments to 0 (written as an instruction: the C conversion is undefined there); 3 VALU per step
-                        u32 ent = (u32)cs;
-                        if (TAGS) {
-                            u32 sh;
-                            asm("v_cvt_u32_f32 %0, %1" : "=v"(sh) : "v"(__builtin_fmaf(d, tg.k, tg.off)));
-                            ent |= sh << 13;
-                        }
-                        if (hit) (myrow(t) + have)[cnt] = (unsigned short)ent;
+                        if (hit) (myrow(t) + have)[cnt] = (unsigned short)cs;
                         nrow[t] += __popcll(m);
                     }
                 }
@@ -500,42 +488,60 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                 load_cand(b, 1, cs, cx, cy, cz, cq);
                 scan(std::false_type{}, cs[0], cx[0], cy[0], cz[0], cq[0]);
             }
-            // rows out, 16 lanes per own atom of the group: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become
-            // global indices, the tail of the last chunk is padded with the atom itself
+            // rows out, 16 lanes per own atom of the group, four atoms at once: slots become global indices and every entry goes to
+            // one of the row's two sections (RowPartArgs, kernels.h) - front: what this atom evaluates, back: mirrored entries
+            // (partner in the same pairing group, both local, and the balanced rule gives the pair to the partner).  One ballot
+            // per 16 entries places both: a front entry moves up by the mirrored entries before it, a mirrored one takes that
+            // number as its place in the back row.  Both sections are padded with the atom itself to whole 32-byte chunks.
             {
                 const int t_l = lane >> 4, el = lane & 15;
                 const bool on = t_l < ng;
                 const int n_l = t_l == 0 ? nrow[0] : t_l == 1 ? nrow[1] : t_l == 2 ? nrow[2] : nrow[3];
-                const int i_l = (int)hgi[own0 + g0 + (on ? t_l : 0)];
+                const u32 i_l = hgi[own0 + g0 + (on ? t_l : 0)];
                 const int nn_l = (dbg == 2 || !on) ? 0 : min(n_l, n_col);
-                const int pad_l = (nn_l + 7) & ~7;
                 // (row_word8(i, 0, n_col) with unsigned factors: one 32 x 32 -> 64 multiply-add)
-                int *dst = table + (((size_t)((u32)i_l >> 6) * (u32)(n_col >> 3)) * 64 + ((u32)i_l & 63u)) * 8 + (el & 7) + (size_t)(el >> 3) * 512;
+                // (row_word8(i, 0, n_col) in bytes with unsigned factors: one 32 x 32 -> 64 multiply-add per table)
+                char *dstF = (char *)table + ((size_t)(i_l >> 6) * (u32)(n_col * 256) + ((i_l & 63u) << 5));
+                char *dstB = (char *)pt.back + ((size_t)(i_l >> 6) * (u32)(pt.nb_col * 256) + ((i_l & 63u) << 5));
                 const unsigned short *row_l = myrow0 + t_l * n_col;
-                const int nmax = __builtin_amdgcn_readfirstlane(max(max(nrow[0], nrow[1]), max(nrow[2], nrow[3])));
-                const int padmax = (min(nmax, n_col) + 7) & ~7;
-                for (int e0 = 0; e0 < padmax; e0 += 16) {
+                const int nmax = min(n_col, __builtin_amdgcn_readfirstlane(max(max(nrow[0], nrow[1]), max(nrow[2], nrow[3]))));
+                // my 16-lane group inside my half of the wave's lane mask: the lanes below me, and all of it
+                const u32 below16 = ((1u << el) - 1u) << (16 * (t_l & 1)), grp16 = 0xFFFFu << (16 * (t_l & 1));
+                const int hsh = lane & 32;
+                int nbr = 0;                     // back entries so far (the same in the 16 lanes of an atom)
+                // byte offset of entry p inside a chunked-8 row: (p >> 3) * 2048 + (p & 7) * 4 = 4 p + 252 (p & ~7)
+                auto rowoff = [](int p) -> u32 { return __umul24((u32)p & ~7u, 252u) + ((u32)p << 2); };
+                for (int e0 = 0; e0 < nmax; e0 += 16) {
                     const int e = e0 + el;
-                    if (e < pad_l) {
-                        int val = TAGS ? (int)((u32)i_l | MESO_ROW_PAD) : i_l;
-                        if (e < nn_l) {
-                            const u32 ent = row_l[e];
-                            if (TAGS) {
-                                // shell into bits 28..30; Newton-pairing class of the entry for the force kernel's groups of
-                                // (1 << tg.gshift) atoms: same group and lower index = mirrored (bit 31: never looked at by a pairing
-                                // launch), same group and higher = evaluated once for both (bit 25)
-                                const u32 j = hgi[ent & 0x1FFFu];
-                                const bool same = ((j ^ (u32)i_l) >> tg.gshift) == 0u, lower = j < (u32)i_l;
-                                const u32 fl = same ? (lower ? MESO_ROW_MIRROR : MESO_ROW_SHARED) : 0u;
-                                val = (int)(j | ((ent & 0xE000u) << 15) | fl);
-                            } else val = (int)hgi[ent];
-                        }
-                        dst[(size_t)(e0 >> 3) * 512] = val;
-                    }
+                    // (a lane past its row reads a stale slot - a valid one, every slot ever staged is - and neither counts nor stores)
+                    const u32 j = hgi[row_l[e]];
+                    const u32 y = j - i_l, z = (y << 31) + y;                       // sign of z = (j < i) != ((j - i) & 1)
+                    // lane masks straight from the compares (LLVM predicates: 36 = ULT, 40 = SLT): mirrored entries of the 64 lanes
+                    const u64 m = __builtin_amdgcn_uicmp(j ^ i_l, (u32)pt.group, 36) & __builtin_amdgcn_uicmp(j, (u32)pt.nlocal, 36) &
+                                  __builtin_amdgcn_sicmp((int)z, 0, 40) & __builtin_amdgcn_sicmp(e, nn_l, 40);
+                    const u32 half = (u32)(m >> hsh);
+                    const int cc = nbr + __popc(half & below16);
+                    // (a back row that overflows - reported below, the run ends - keeps writing into its last entry)
+                    const int pf = e - cc, pb = min(cc, pt.nb_col - 1);
+                    int pos;
+                    char *d;
+                    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(pos) : "v"(pf), "v"(pb), "s"(m));
+                    asm("v_cndmask_b32 %0, %2, %4, %6\n\tv_cndmask_b32 %1, %3, %5, %6" : "=&v"(((u32 *)&d)[0]), "=&v"(((u32 *)&d)[1])
+                        : "v"((u32)(size_t)dstF), "v"((u32)((size_t)dstF >> 32)), "v"((u32)(size_t)dstB), "v"((u32)((size_t)dstB >> 32)), "s"(m));
+                    if (e < nn_l) *(__attribute__((address_space(1))) int *)(size_t)(d + rowoff(pos)) = (int)j;      // (a global store, not a flat one)
+                    nbr += __popc(half & grp16);
+                }
+                // the tails of the two sections' last chunks: the atom itself (r = 0: no kernel takes it for a neighbour)
+                const int nf = nn_l - nbr, nb = min(nbr, pt.nb_col);
+                if (on && el < 8) {
+                    const int pf = nf + el, pb = nb + el;
+                    if (pf < ((nf + 7) & ~7)) *(int *)((char *)dstF + rowoff(pf)) = (int)i_l;
+                    if (pb < ((nb + 7) & ~7)) *(int *)((char *)dstB + rowoff(pb)) = (int)i_l;
                 }
                 if (on && el == 0) {
-                    if (n_l > n_col) atomicMax(overflow, n_l);
-                    count[i_l] = nn_l;
+                    if (n_l > n_col || nbr > pt.nb_col) atomicMax(overflow, max(n_l, n_col + 1));
+                    count[i_l] = nf;
+                    if (pt.group) pt.nback[i_l] = nb;
                 }
             }
         }
@@ -655,9 +661,9 @@ void launch_ghost_morton(const AtomSoA &a, const BinGeom &g, int nlocal, int ngh
 // even on a deck without a single exclusion (scalar-register spills of the larger kernel) and a third of its occupancy
 // while the tags of the neighbourhood were staged in LDS.
 __global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nlocal, int n_col, int *__restrict__ count,
-                                                          int *__restrict__ table, u32 imask)
+                                                          int *__restrict__ table, int nb_col, int *__restrict__ nback, int *__restrict__ back)
 {
-    // (imask: the index bits of an entry - tagged rows carry shell and pairing bits above them, which travel with a kept entry)
+    // (nback != null: partitioned rows, RowPartArgs in kernels.h - the front row and the back row are compacted one after the other)
     // FOUR atoms at a time per wave, 16 lanes each: the filter is a chain of dependent memory round trips per atom (special
     // list and count, row entries, their tags), so its speed is the number of atoms in flight (one atom per wave: 250 us on a
     // melt of 1 M chain beads, four: see profiles/r02_notes.md)
@@ -668,6 +674,7 @@ __global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nloca
     const int il = i0 + lane;
     const int nsp_own = il < nlocal ? ex.nspecial[il] : 0;
     const int cnt_own = il < nlocal ? count[il] : 0;       // (loaded for all 64 atoms at once: one round trip less per atom below)
+    const int bck_own = (nback && il < nlocal) ? nback[il] : 0;
     const u64 todo = __builtin_amdgcn_ballot_w64(nsp_own > 0);
     const int ntodo = __popcll(todo);
     if (ntodo == 0) return;
@@ -680,35 +687,46 @@ __global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nloca
         const int al = on ? (int)todo_s[w][r + g] : 0;
         const int i = i0 + al;
         // (shuffles outside any branch: a lane that is switched off hands out nothing)
-        const int nsp_a = __shfl(nsp_own, al, 64), n_a = __shfl(cnt_own, al, 64);
+        const int nsp_a = __shfl(nsp_own, al, 64), n_a = __shfl(cnt_own, al, 64), nb_a = __shfl(bck_own, al, 64);
         const int nsp = on ? nsp_a : 0;
-        const int n = on ? n_a : 0;
         // (requested together with the row entries: the list load does not wait for anything; lists longer than 16: rest from memory)
         int sp_l = (on && l16 < ex.msp) ? ex.special[(size_t)i * ex.msp + l16] : -1;
         if (l16 >= nsp) sp_l = -1;
-        int nspmax = nsp, nmax = n;
+        int nspmax = nsp;
 #pragma unroll
-        for (int o = 32; o >= 16; o >>= 1) { nspmax = max(nspmax, __shfl_xor(nspmax, o, 64)); nmax = max(nmax, __shfl_xor(nmax, o, 64)); }
-        nspmax = __builtin_amdgcn_readfirstlane(nspmax); nmax = __builtin_amdgcn_readfirstlane(nmax);
-        int *row = table + row_word8(i, 0, n_col) * 8;
-        int nout = 0;
-        for (int e0 = 0; e0 < nmax; e0 += 16) {
-            const int e = e0 + l16;
-            const bool in = e < n;
-            const int j = in ? row[(size_t)(e >> 3) * 512 + (e & 7)] : i;
-            const int tg = ex.tagc[(u32)j & imask];
-            bool keep = in;
-            for (int sp = 0; sp < min(nspmax, 16); sp++) keep = keep & (__shfl(sp_l, (lane & 48) + sp, 64) != tg);
-            for (int sp = 16; sp < nsp; sp++) keep = keep & (ex.special[(size_t)i * ex.msp + sp] != tg);
-            const u32 m16 = (u32)(__builtin_amdgcn_ballot_w64(keep) >> (16 * g)) & 0xffffu;
-            const int pos = nout + __popc(m16 & below);
-            if (keep) row[(size_t)(pos >> 3) * 512 + (pos & 7)] = j;
-            nout += __popc(m16);
-        }
-        if (on) {
-            const int e = nout + l16;
-            if (e < ((nout + 7) & ~7)) row[(size_t)(e >> 3) * 512 + (e & 7)] = (int)((u32)i | ~imask);     // (tagged rows: MESO_ROW_PAD)
-            if (l16 == 0) count[i] = nout;
+        for (int o = 32; o >= 16; o >>= 1) nspmax = max(nspmax, __shfl_xor(nspmax, o, 64));
+        nspmax = __builtin_amdgcn_readfirstlane(nspmax);
+        // the n entries of a row, compacted in place (writes never pass the reads of a later batch), tail padded with the atom itself
+        auto section = [&](int *row, int n) -> int {
+            int nmax = n;
+#pragma unroll
+            for (int o = 32; o >= 16; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+            nmax = __builtin_amdgcn_readfirstlane(nmax);
+            int nout = 0;
+            for (int e0 = 0; e0 < nmax; e0 += 16) {
+                const int e = e0 + l16;
+                const bool in = e < n;
+                const int j = in ? row[(size_t)(e >> 3) * 512 + (e & 7)] : i;
+                const int tg = ex.tagc[j];
+                bool keep = in;
+                for (int sp = 0; sp < min(nspmax, 16); sp++) keep = keep & (__shfl(sp_l, (lane & 48) + sp, 64) != tg);
+                for (int sp = 16; sp < nsp; sp++) keep = keep & (ex.special[(size_t)i * ex.msp + sp] != tg);
+                const u32 m16 = (u32)(__builtin_amdgcn_ballot_w64(keep) >> (16 * g)) & 0xffffu;
+                const int pos = nout + __popc(m16 & below);
+                if (keep) row[(size_t)(pos >> 3) * 512 + (pos & 7)] = j;
+                nout += __popc(m16);
+            }
+            if (on) {
+                const int e = nout + l16;
+                if (e < ((nout + 7) & ~7)) row[(size_t)(e >> 3) * 512 + (e & 7)] = i;
+            }
+            return nout;
+        };
+        const int nf = section(table + row_word8(i, 0, n_col) * 8, on ? n_a : 0);
+        if (on && l16 == 0) count[i] = nf;
+        if (nback) {
+            const int nb = section(back + row_word8(i, 0, nb_col) * 8, on ? nb_a : 0);
+            if (on && l16 == 0) nback[i] = nb;
         }
     }
 }
@@ -719,15 +737,13 @@ void launch_brick_plan(const BrickArgs &g, int *overflow, hipStream_t s)
     hipLaunchKernelGGL(k_brick_plan, dim3(brick_grid(g)), dim3(256), 0, s, g, overflow);
 }
 
-// largest LDS stage (halo atoms) whose slots leave room for the three shell bits of a staged row entry
-int tile_build_tag_slots() { return 8192; }
-
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
-                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s, const RowTagArgs *tags)
+                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s, const RowPartArgs *part)
 {
     if (g.nactive <= 0) return;
-    RowTagArgs tg = {};
-    if (tags) tg = *tags;
+    RowPartArgs pt = {0, 0, nullptr, nullptr, 8};
+    if (part) pt = *part;
+    if (!pt.nback || !pt.back) { pt.group = 0; pt.back = table; pt.nback = count; }      // (plain rows: nothing is ever written behind)
     // (the scan's expanded distance form loses < 1e-4 absolute to cancellation: the list cutoff is widened by more than that)
     if (TB_EXPANDED) rc2 += 4.0e-4f;
     // few bricks (small boxes, sub-boxes of many ranks): several workgroups share a brick as long as all of them still fit the
@@ -738,37 +754,24 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         // 2x2x2 bricks: eight times as many workgroups of 4 waves
         BrickArgs g2 = g;
         g2.nactive = g.order2 ? g.norder2 : g.M / 8;
-        // (option brick2_split: several workgroups per brick - measured, round 4: every workgroup stages the whole neighbourhood, and
-        // that costs more than the finer grain buys at every size: 25^3 24.8 -> 25.7 us with two, 32^3 39.6 -> 45.2, 48^3 93 -> 108)
-        const int split2 = g.split2 > 0 ? g.split2 : 1;
-        const dim3 tgrid2((g2.nactive * split2 + 7) / 8 * 8);
+        const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
         const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2 + TB_ROWPAD * 2;
-        if (tg.on) {
-            if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-            hipLaunchKernelGGL((k_tile_build<2, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, split2, dbg, tg);
-        } else {
-            if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-            hipLaunchKernelGGL((k_tile_build<2, false>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, split2, dbg, tg);
-        }
+        if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+        hipLaunchKernelGGL((k_tile_build<2>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, pt);
     } else {
-    int split = 1;
-    while (split < 4 && occupied * split * 2 <= 900) split *= 2;
-    if (dbg >= 100) { split = dbg - 100; dbg = 0; }     // timing experiments: pair_debug 110 + split
-    const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
-    const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2 + TB_ROWPAD * 2;
-    if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
-    if (tg.on) {
-        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        hipLaunchKernelGGL((k_tile_build<4, true>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, tg);
-    } else {
-        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        hipLaunchKernelGGL((k_tile_build<4, false>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, tg);
-    }
+        int split = 1;
+        while (split < 4 && occupied * split * 2 <= 900) split *= 2;
+        if (dbg >= 100) { split = dbg - 100; dbg = 0; }     // timing experiments: pair_debug 110 + split
+        const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
+        const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2 + TB_ROWPAD * 2;
+        if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
+        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((k_tile_build<4>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, pt);
     }
     if (excl && excl->tagc && nlocal > 0) {
         const int nw = (nlocal + 63) / 64;                                  // one wave per 64 consecutive atoms
-        hipLaunchKernelGGL(k_filter_exclusion, dim3((nw + 3) / 4), dim3(256), 0, s, *excl, nlocal, n_col, count, table,
-                           tg.on ? MESO_ROW_INDEX : 0xFFFFFFFFu);
+        hipLaunchKernelGGL(k_filter_exclusion, dim3((nw + 3) / 4), dim3(256), 0, s, *excl, nlocal, n_col, count, table, pt.nb_col,
+                           pt.group ? pt.nback : nullptr, pt.group ? pt.back : nullptr);
     }
 }
 

@@ -247,11 +247,12 @@ int meso_xchg_stats(meso_ctx *ctx, char *buf, int nbuf)
     snprintf(buf, (size_t)nbuf, "%s", ctx->eng->xchg_report().c_str());
     return 0;
 }
-int meso_neigh_tags(meso_ctx *ctx, int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride)
+int meso_neigh_parts(meso_ctx *ctx, int *parted, int *group, int *nfront, int *nback, int *front, int *back, int stride)
 {
     CTX(ctx);
-    if (!tagged || !group || !base || !k || !eps) return set_err(MESO_ERR_ARG, "null argument");
-    RET(E.neigh_tags(tagged, group, base, k, eps, raw, stride));
+    if (!parted || !group) return set_err(MESO_ERR_ARG, "null argument");
+    if ((front || back) && stride <= 0) return set_err(MESO_ERR_ARG, "invalid neighbour buffers");
+    RET(E.neigh_parts(parted, group, nfront, nback, front, back, stride));
 }
 int meso_neigh_download(meso_ctx *ctx, int *count, int *table, int stride)
 {

@@ -100,8 +100,8 @@ public:
 
     // introspection
     int neigh_info(int *n_col, int *max_count, double *avg, int64_t *nbuild);
-    int neigh_download(int *count, int *table, int stride, bool raw = false);
-    int neigh_tags(int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride);
+    int neigh_download(int *count, int *table, int stride);
+    int neigh_parts(int *parted, int *group, int *nfront, int *nback, int *front, int *back, int stride);
     int merged_download(float *c4, float *v4, int nall);
     int timer_reset();
     int timer_get(const std::string &name, double *ms, int64_t *calls);
@@ -302,7 +302,6 @@ private:
     // one rank: the rebuild in three launches (rebuild.hip) - count, place + gather + ghost emission, ghosts
     int *brick_order2 = nullptr;    // launch order of the 2-bricks (those that own real cells, fullest first)
     int brick2 = 1;                 // option: 2x2x2 bricks in the list builder (0: the 4x4x4 bricks of rounds 1-2)
-    int brick2_split = 0;           // option: workgroups per 2-brick (0: by the number of bricks, see launch_tile_build)
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on
@@ -332,16 +331,13 @@ private:
     int *mr_gcnt = nullptr;         // [M+1] ghosts per ghost cell of that form (gstart holds the starts)
     int mr_gcnt_n = 0;
     int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
-    // tagged rows + displacement account (RowTagArgs, kernels.h): the force kernel walks only the row entries that can be inside
-    // the cutoff on the current step
-    int shell_walk = 0;             // option: 1 tagged rows, pruned walk; 2 tagged rows, every shell walked (A/B of the queue form alone); 0 (default:
-                                    // measured faster at every size, profiles/r04_notes.md) plain rows
-    float *d_disp = nullptr;        // [MESO_DISP_SLOTS][MESO_DISP_STEP] max |v|^2 per step since the list was built (MESO_DISP_SUB copies per step)
-    bool rows_tagged = false;       // the table in use carries tags
-    int tag_group = 0;              // ... built for this pairing group of the force kernel
-    float shell_base = 0.f, shell_k = 0.f, shell_eps = 0.f;
-    float *disp_slot() const { return (d_disp && ago >= 0 && ago < MESO_DISP_SLOTS) ? d_disp + (size_t)ago * MESO_DISP_STEP : nullptr; }
-    void pair_shell_args(PairArgs &p, bool walk) const;
+    // partitioned rows (RowPartArgs, kernels.h): the list builder decides the Newton pairing of in-group pairs once per rebuild
+    int row_part = 1;               // option: 1 rows in two sections (front: what the atom evaluates, back: mirrored entries); 0 plain rows
+    int *pair_nback = nullptr;      // [nmax] back entries per atom
+    int *pair_back = nullptr;       // the back table: chunked-8 rows of nb_col entries
+    int nb_col = 0;
+    bool rows_part = false;         // the table in use is partitioned
+    int part_group = 0;             // ... for this pairing group of the force kernel
     int split_gather = -1;          // option: the fused rebuild's placing kernel only orders and a streaming pass gathers (-1: boxes of >= 200 k atoms - 40^3 +1 %, 48^3 +1.8 %, 64^3 +1.6 %, 32^3 -0.7 %; 0; 1)
     int fused_rebuild = 1;          // option
     bool fused_active = false;      // this rebuild ran the fused path: ghosts sit in slot order, directions in senddir

@@ -80,7 +80,7 @@ void Engine::free_all()
     dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc); dfree(tagbits);
     dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
     dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
-    dfree(pair_count); dfree(pair_table); dfree(d_disp);
+    dfree(pair_count); dfree(pair_nback); dfree(pair_table); dfree(pair_back);
     dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(img_cnt); dfree(img); dfree(d_shift27);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
     dfree(fr_bucket); dfree(fr_ovf); dfree(fr_novf); dfree(fr_scratch); dfree(senddir); dfree(fr_gorder); dfree(fr_gcnt);
@@ -315,11 +315,10 @@ int Engine::pair_coeff_table(int i, int j, double gamma, double sigma, int len, 
 int Engine::set_option(const std::string &key, double val)
 {
     if (key == "fused_rebuild") { fused_rebuild = (int)val; return 0; }
-    if (key == "shell_walk") { shell_walk = (int)val; return 0; }
+    if (key == "row_part") { row_part = (int)val; return 0; }
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
-    if (key == "brick2_split") { brick2_split = (int)val; return 0; }      // workgroups per 2-brick of the list builder (0: by size)               // 0: never the 2x2x2 bricks of small boxes
     if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
@@ -428,7 +427,7 @@ int Engine::alloc_atoms(int cap)
     for (int k = 0; k < 6; k++) HIPCHK(regrow(virial[k], 0, c, stream));
     HIPCHK(regrow(e_pair, 0, c, stream));
     HIPCHK(regrow(xhold, 0, 3 * c, stream));
-    HIPCHK(regrow(pair_count, 0, c, stream));
+    HIPCHK(regrow(pair_count, 0, c, stream)); HIPCHK(regrow(pair_nback, 0, c, stream));
     HIPCHK(regrow(bin_key, 0, c, stream)); HIPCHK(regrow(bin_key_alt, 0, c, stream));
     HIPCHK(regrow(bin_val, 0, c, stream)); HIPCHK(regrow(bin_val_alt, 0, c, stream));
     HIPCHK(regrow(rkey, 0, c, stream)); HIPCHK(regrow(rkey_alt, 0, c, stream));
@@ -461,8 +460,9 @@ int Engine::alloc_atoms(int cap)
     }
     if (n_col > 0) {
         table_tiles = ((size_t)cap + 63) / 64;
-        dfree(pair_table);
+        dfree(pair_table); dfree(pair_back);
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
+        HIPCHK(dalloc(pair_back, table_tiles * 64 * (size_t)nb_col));
         dfree(brick_own);
         HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
@@ -878,9 +878,11 @@ int Engine::init_params()
     int ncol = ((int)std::ceil(expected) + 31) / 32 * 32;
     if (ncol != n_col || !pair_table) {
         n_col = ncol;
+        nb_col = std::max(8, (n_col / 2 + 7) & ~7);      // back section of a partitioned row: about half of the in-group partners, at most half a row
         table_tiles = ((size_t)nmax + 63) / 64;
-        dfree(pair_table);
+        dfree(pair_table); dfree(pair_back);
         HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
+        HIPCHK(dalloc(pair_back, table_tiles * 64 * (size_t)nb_col));
         dfree(brick_own);
         HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
@@ -1496,36 +1498,20 @@ int Engine::build_cells_and_table()
                 bb.gcnt = (fused_active && fused_gcnt_valid) ? fr_gcnt : (mr_runs ? mr_gcnt : nullptr);
                 if (brick2_off || !brick2) bb.maxh2 = 0;
                 bb.brick2_limit = brick2_limit;
-                bb.split2 = brick2_split;
-                // tagged rows (RowTagArgs): shell at build time + pairing class in every entry, while indices fit 25 bits and the
-                // staged neighbourhood's slots 13; the shells split [base, r_list^2) evenly in r^2, base = the largest cutoff plus
-                // the rounding of the merged fp32 coordinates (|x| up to half the sub-box: 4 ulp + 1e-5)
-                RowTagArgs tg = {};
-                rows_tagged = false;
-                const long nall_bound = counts_pending ? (long)nmax : (long)nlocal + nghost;
-                if (shell_walk && ring_selected() && nall_bound < (1L << 25) && std::max(bb.maxh, bb.maxh2) <= tile_build_tag_slots()) {
-                    double ext = 0.0;
-                    for (int d = 0; d < 3; d++) ext = std::max(ext, 0.5 * (subhi[d] - sublo[d]) + cutghost);
-                    shell_eps = (float)(4.0 * ext * 1.1920929e-7 + 1.0e-5);
-                    const double rb = cutmax + 2.0 * shell_eps;
-                    shell_base = (float)(rb * rb);
-                    shell_k = (float)(6.9 / ((cutmax + skin) * (cutmax + skin) * 1.0001 - (double)shell_base));
-                    if (!d_disp) { HIPCHK(dalloc(d_disp, (size_t)MESO_DISP_SLOTS * MESO_DISP_STEP)); HIPCHK(hipMemsetAsync(d_disp, 0, (size_t)MESO_DISP_SLOTS * MESO_DISP_STEP * sizeof(float), stream)); }
-                    tag_group = pair_ring_group_for(nlocal, pair_npart);
-                    tg.on = 1; tg.k = shell_k; tg.off = (float)(1.0 - (double)shell_base * (double)shell_k);
-                    tg.gshift = 0;
-                    while ((1 << tg.gshift) < tag_group) tg.gshift++;
-                    tg.disp = d_disp;
-                    rows_tagged = skin > 0.0;
-                    if (!rows_tagged) tg = RowTagArgs{};
-                }
+                // partitioned rows (RowPartArgs): the pairing group is the ring kernel's workgroup for a launch over this rank's atoms
+                // (every force launch of the interval is then made with the same lanes per atom, launch_pair)
+                // (not for the wide records of more than 2^25 atoms on a rank, whose launches walk one row per atom)
+                rows_part = row_part != 0 && pair_share != 0 && ring_selected() && pair_debug != 9 &&
+                            (counts_pending ? (long)nmax : (long)nlocal + nghost) <= (1L << 25);
+                part_group = rows_part ? pair_ring_group_for(nlocal, pair_npart) : 0;
+                RowPartArgs pt = {part_group, nlocal, pair_nback, pair_back, nb_col};
                 launch_tile_build(bb, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,
-                                  pair_debug >= 10 ? pair_debug - 10 : 0, stream, rows_tagged ? &tg : nullptr);
+                                  pair_debug >= 10 ? pair_debug - 10 : 0, stream, &pt);
                 tend("neigh");
                 nbuild++;
                 return 0;
             }
-            rows_tagged = false;
+            rows_part = false; part_group = 0;
             launch_bin_ranges(estart, gstart, bargs.M, nlocal, binrange, stream);
             launch_cell_build(coord4, rkey, reorder_sub_bits(geom), binrange, bargs.M, geom.mbin, rc2, nlocal, n_col, pair_count, pair_table,
                               d_flags, have_bonds ? &ex : nullptr, stream);
@@ -1679,7 +1665,7 @@ int Engine::decide(int *rebuild)
 int Engine::nve_initial()
 {
     tbegin("nve");
-    launch_nve_initial(cur, 0.5 * dt, dt, groupbit, nlocal, stream, disp_slot());
+    launch_nve_initial(cur, 0.5 * dt, dt, groupbit, nlocal, stream);
     tend("nve");
     return 0;
 }
@@ -1717,9 +1703,10 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.nall = (int)std::min<long>(counts_pending ? (long)nmax : (long)nlocal + nghost, (1L << 28) - 1);
     p.rng = pair_rng;
     p.npart = pair_npart;
-    p.tagged = rows_tagged ? 1 : 0;
-    p.tag_group = tag_group;
-    if (rows_tagged) p.npart = 4 * 64 / tag_group;      // every launch of the interval pairs inside the groups the rows were tagged for
+    p.nback = rows_part ? pair_nback : nullptr;
+    p.table_back = pair_back; p.nb_col = nb_col;
+    p.part_group = part_group;
+    if (rows_part) p.npart = 4 * 64 / part_group;      // every launch of the interval pairs inside the groups the rows were partitioned for
     p.poly = pair_poly ? d_poly : nullptr;
     p.ftab = pair_ftab ? d_ftab : nullptr;
     p.ftab_len = ftab_len;
@@ -1733,15 +1720,6 @@ void Engine::launch_pair(PairArgs &p, int ev)
     else launch_pair_dpd_ring(p, pair_style, stream, pair_variant);
 }
 
-// the shell geometry of the table in use; walk: the caller's step is covered by the displacement account (one rank: the ghosts
-// are this rank's own atoms, and every step boundary since the build booked its fastest atom)
-void Engine::pair_shell_args(PairArgs &p, bool walk) const
-{
-    p.disp = nullptr; p.disp_n = -1;
-    p.shell_rc = (float)cutmax; p.shell_dt = (float)dt; p.shell_eps = shell_eps; p.shell_base = shell_base; p.shell_k = shell_k;
-    if (walk && rows_tagged && shell_walk == 1 && nranks == 1 && d_disp && ago >= 0 && ago <= MESO_DISP_SLOTS) { p.disp = d_disp; p.disp_n = ago; }
-}
-
 int Engine::pair_compute(int r, int eflag, int vflag)
 {
     if (!is_setup && !params_ready) return fail(3, "pair_compute before setup");
@@ -1752,7 +1730,6 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     range(r, beg, end);
     PairArgs p = {};
     p.bond.nbond = nullptr;
-    pair_shell_args(p, false);       // (stepping through the API: every shell is walked)
     p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
     for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
     int ev = (eflag || vflag) ? 1 : 0;
@@ -1848,7 +1825,6 @@ int Engine::run(int nsteps)
         ghosts_by_epilogue = false;
         PairArgs p = {};
         p.bond.nbond = nullptr;
-        pair_shell_args(p, true);
         p.coord4 = coord4; p.veloc4 = veloc4; p.count = pair_count; p.table = pair_table; p.n_col = n_col;
         for (int d = 0; d < 3; d++) p.f[d] = cur.f[d];
         p.e_pair = nullptr;
@@ -1891,7 +1867,6 @@ int Engine::run(int nsteps)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
                                   0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
                                   premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
-        if (boundary_in_pair) p.nve.disp_slot = disp_slot();      // the step boundary books its fastest atom (displacement account of the list)
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
         if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }
@@ -1928,7 +1903,7 @@ int Engine::run(int nsteps)
             tbegin("nve");
             launch_nve_boundary(cur, 0.5 * dt, dt, groupbit, nlocal, next_rebuild ? 0 : 1, coord4, veloc4,
                                 0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
-                                premix_tea<64>((u32)seed, (u32)(ntimestep + 1)), stream, disp_slot());
+                                premix_tea<64>((u32)seed, (u32)(ntimestep + 1)), stream);
             tend("nve");
             initial_done = true;
             merged = !next_rebuild;
@@ -2058,14 +2033,19 @@ int Engine::compute_pressure(double *p)
 // ------------------------------------------------------------------------------------------------
 // introspection / tests
 // ------------------------------------------------------------------------------------------------
+// (partitioned rows, RowPartArgs in kernels.h: an atom's neighbours are its front row plus its back row)
 int Engine::neigh_info(int *ncol, int *max_count, double *avg, int64_t *nb)
 {
     HIPCHK(hipStreamSynchronize(stream));
-    std::vector<int> h((size_t)nlocal);
+    std::vector<int> h((size_t)nlocal), hb;
     if (nlocal) HIPCHK(hipMemcpy(h.data(), pair_count, nlocal * sizeof(int), hipMemcpyDeviceToHost));
+    if (rows_part && nlocal) { hb.resize(nlocal); HIPCHK(hipMemcpy(hb.data(), pair_nback, nlocal * sizeof(int), hipMemcpyDeviceToHost)); }
     long tot = 0;
     int mx = 0;
-    for (int i = 0; i < nlocal; i++) { tot += h[i]; mx = std::max(mx, h[i]); }
+    for (int i = 0; i < nlocal; i++) {
+        const int n = h[i] + (rows_part ? hb[i] : 0);
+        tot += n; mx = std::max(mx, n);
+    }
     if (ncol) *ncol = n_col;
     if (max_count) *max_count = mx;
     if (avg) *avg = nlocal ? (double)tot / nlocal : 0.0;
@@ -2073,29 +2053,59 @@ int Engine::neigh_info(int *ncol, int *max_count, double *avg, int64_t *nb)
     return 0;
 }
 
-int Engine::neigh_tags(int *tagged, int *group, double *base, double *k, double *eps, int *raw, int stride)
+static void unchunk_rows(const std::vector<int> &h, int pitch, int nlocal, bool raw, const int *count, int *table, int stride, int col0)
 {
-    *tagged = rows_tagged ? 1 : 0; *group = tag_group; *base = shell_base; *k = shell_k; *eps = shell_eps;
-    if (raw && nlocal > 0) {
-        std::vector<int> cnt(nlocal);
-        return neigh_download(cnt.data(), raw, stride, true);
+    for (int i = 0; i < nlocal; i++) {
+        const int n = raw ? (count[i] + 7) & ~7 : count[i];      // (raw: the tail slots of the last chunk too)
+        for (int p = 0; p < n && col0 + p < stride; p++)
+            table[(size_t)i * stride + col0 + p] = h[((((size_t)(i >> 6)) * (pitch >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)];
+    }
+}
+
+// sections of the table in use as stored (padding of the last chunk included): front[i * stride + p], back[i * stride + p]
+int Engine::neigh_parts(int *parted, int *group, int *nfront, int *nback, int *front, int *back, int stride)
+{
+    HIPCHK(hipStreamSynchronize(stream));
+    *parted = rows_part ? 1 : 0; *group = part_group;
+    if (!nlocal) return 0;
+    std::vector<int> cf(nlocal), cb(nlocal, 0);
+    HIPCHK(hipMemcpy(cf.data(), pair_count, nlocal * sizeof(int), hipMemcpyDeviceToHost));
+    if (rows_part) HIPCHK(hipMemcpy(cb.data(), pair_nback, nlocal * sizeof(int), hipMemcpyDeviceToHost));
+    if (nfront) std::copy(cf.begin(), cf.end(), nfront);
+    if (nback) std::copy(cb.begin(), cb.end(), nback);
+    const size_t tiles = ((size_t)nlocal + 63) / 64;
+    if (front) {
+        std::vector<int> h(tiles * 64 * (size_t)n_col);
+        HIPCHK(hipMemcpy(h.data(), pair_table, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+        unchunk_rows(h, n_col, nlocal, true, cf.data(), front, stride, 0);
+    }
+    if (back && rows_part) {
+        std::vector<int> h(tiles * 64 * (size_t)nb_col);
+        HIPCHK(hipMemcpy(h.data(), pair_back, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+        unchunk_rows(h, nb_col, nlocal, true, cb.data(), back, stride, 0);
     }
     return 0;
 }
 
-int Engine::neigh_download(int *count, int *table, int stride, bool raw)
+// the neighbours of every atom, front section first
+int Engine::neigh_download(int *count, int *table, int stride)
 {
     HIPCHK(hipStreamSynchronize(stream));
     if (!nlocal) return 0;
     HIPCHK(hipMemcpy(count, pair_count, nlocal * sizeof(int), hipMemcpyDeviceToHost));
-    size_t tiles = ((size_t)nlocal + 63) / 64;
+    const size_t tiles = ((size_t)nlocal + 63) / 64;
     std::vector<int> h(tiles * 64 * (size_t)n_col);
     HIPCHK(hipMemcpy(h.data(), pair_table, h.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (int i = 0; i < nlocal; i++) {
-        int n = std::min(raw ? (count[i] + 7) & ~7 : count[i], stride);      // (raw: the tail slots of the last chunk too)
-        for (int p = 0; p < n; p++)
-            table[(size_t)i * stride + p] = (int)((uint32_t)h[((((size_t)(i >> 6)) * (n_col >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)] &
-                                                  (rows_tagged && !raw ? MESO_ROW_INDEX : 0xFFFFFFFFu));      // (tagged rows: the index bits)
+    unchunk_rows(h, n_col, nlocal, false, count, table, stride, 0);
+    if (rows_part) {
+        std::vector<int> cb(nlocal), hb(tiles * 64 * (size_t)nb_col);
+        HIPCHK(hipMemcpy(cb.data(), pair_nback, nlocal * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.data(), pair_back, hb.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nlocal; i++) {
+            for (int p = 0; p < cb[i] && count[i] + p < stride; p++)
+                table[(size_t)i * stride + count[i] + p] = hb[((((size_t)(i >> 6)) * (nb_col >> 3) + (p >> 3)) * 64 + (i & 63)) * 8 + (p & 7)];
+            count[i] += cb[i];
+        }
     }
     return 0;
 }

@@ -33,11 +33,11 @@ struct HaloShift { double prd[3]; };
 //      domain_meso.cu:30-145, memory_meso.h:17, atom_vec_meso.h:90) -------------------------------------
 void launch_merge_xvt(const AtomSoA &a, float4 *coord4, float4 *veloc4, double cx, double cy, double cz,
                       uint32_t seed, int beg, int end, hipStream_t s);
-void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s, float *disp_slot = nullptr);
+void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s);
 void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s);
 // final(step s) + initial(step s+1) [+ merge for step s+1] in one pass
 void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, int merge, float4 *coord4,
-                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s, float *disp_slot = nullptr);
+                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s);
 void launch_sum_mv2(const AtomSoA &a, int groupbit, int n, double *partial, double *result, hipStream_t s);
 void launch_pbc(const AtomSoA &a, const double *boxlo, const double *boxhi, const int *periodic, int n,
                 hipStream_t s);
@@ -122,7 +122,6 @@ struct NveArgs {
     float4 *img_c4, *img_v4;
     const int *img_vofs;
     const double *img_center;
-    float *disp_slot;             // nullable: this step's word of the neighbour list's displacement account (max |v|^2, RowTagArgs)
 };
 NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,
                       float4 *veloc4_next, double cx, double cy, double cz, uint32_t seed_next);
@@ -160,13 +159,10 @@ struct PairArgs {
     int npart;            // ring kernel: lanes per atom (0: chosen from the launch size; 1, 2, 4)
     int lds_veloc;        // ring kernel (set by its launcher): in-group partners' velocity records from the workgroup's LDS copy
     int share;            // ring kernel: Newton pairing inside a workgroup allowed (end == nlocal or a multiple of 256)
-    // tagged rows (RowTagArgs below): the table's entries carry shell and pairing bits; tag_group = the pairing group they were
-    // built for.  disp != null && disp_n >= 0: the ring kernel walks only the shells that can be inside the cutoff after the
-    // displacements booked in disp[0 .. disp_n) (max |v|^2 per step since the build); shell_*: the shell geometry of the build
-    int tagged, tag_group;
-    const float *disp;
-    int disp_n;
-    float shell_rc, shell_dt, shell_eps, shell_base, shell_k;
+    // partitioned rows (RowPartArgs below): count / table hold the FRONT sections; nback[i] mirrored entries of atom i live in
+    // table_back (chunked-8 rows of nb_col entries); part_group = the pairing group the builder partitioned for.  nback null: plain rows
+    const int *nback, *table_back;
+    int nb_col, part_group;
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;
     NveArgs nve;
@@ -227,39 +223,25 @@ void launch_ghost_count(const AtomSoA &a, const BinGeom &g, int nlocal, int ngho
                         const int *nghost_dev, hipStream_t s);
 
 struct ExclArgs;
-// Tagged rows (round 4, "shell walk").  The tile builder knows every kept candidate's distance and both indices, so an entry of a
-// tagged table carries, above its 25 index bits,
-//   bits 28..30  the distance shell at build time: 0 = inside the largest cutoff (+ a rounding guard), s >= 1: r^2 in
-//                [base + (s - 1) / k, base + s / k) - the reference keeps the same knowledge as "core from the row front, skin from
-//                the back" (neigh_build_meso.cu:91-115);
-//   bit 31       mirrored: partner in the same aligned group of (1 << gshift) atoms with the LOWER index - a force launch that pairs
-//                inside such groups never looks at it (one unsigned compare covers shell and mirror bit);
-//   bit 25       the partner is in the same group with the HIGHER index: evaluated once, added to both (the ring record's flag bit).
-// The force kernel walks an entry only if its shell can be inside the cutoff now: r_build < r_c + 2 D, D = sum over the steps since
-// the build of dt * max_i |v_i| (a rigorous bound on every atom's displacement; the step boundaries book max |v|^2 per step into
-// disp[step since the build], the builder clears the account).  Skipped entries contribute exactly zero and the fixed-point force
-// sums do not depend on the order of the others: forces are bit-identical to the full walk.
-#define MESO_ROW_INDEX 0x01FFFFFFu
-#define MESO_ROW_SHARED 0x02000000u
-#define MESO_ROW_MIRROR 0x80000000u
-#define MESO_ROW_PAD 0xFE000000u          // tail slots of a row's last chunk (the atom itself): never a candidate
-#define MESO_ROW_SHELL_SHIFT 28
-#define MESO_DISP_SLOTS 16                // steps since the build the account covers (later steps: full walk)
-// a step's word is kept in MESO_DISP_SUB copies 128 bytes apart (the waves of a launch end together, and same-address atomics
-// serialise in L2: a wave books into the copy of its number); the step's maximum is the maximum over the copies
-#define MESO_DISP_SUB 16
-#define MESO_DISP_PITCH 32                // floats between two copies
-#define MESO_DISP_STEP (MESO_DISP_SUB * MESO_DISP_PITCH)      // floats per step
-struct RowTagArgs {
-    int on;              // 0: plain rows (indices only)
-    float k, off;        // shell = sat_u32(r^2 * k + off), off = 1 - base * k
-    int gshift;          // log2 of the force kernel's pairing group
-    float *disp;         // [MESO_DISP_SLOTS][MESO_DISP_STEP] max |v|^2 of the step boundaries since this build (cleared by the builder); null: no account
+// Partitioned rows (round 5).  The tile builder knows both indices of every kept candidate, so it decides ONCE per rebuild what the
+// force kernel decided per entry and step: a pair whose two atoms lie in the same aligned group of `group` atoms (the ring kernel's
+// workgroup) is evaluated by exactly one of them and added to both (Newton pairing).  The rule is balanced - atom i evaluates the
+// pair (i, j) when (i < j) != ((i ^ j) & 1) - so every atom keeps about half of its in-group partners, whatever its place in the
+// group (the round-4 rule "the lower index evaluates" gave a group's first wave 2.4 times the pairs of its last).  A row comes in
+// two sections, each padded with the atom itself to whole 32-byte chunks:
+//   front (count[i] entries of table):     what this atom evaluates - in-group partners for both atoms, the others one-sided;
+//   back  (nback[i] entries of table_back): mirrored entries - in-group partners that evaluate the pair themselves.
+// A kernel that needs every neighbour walks both; a pairing launch of the ring kernel walks the front section only.  The reference
+// keeps its rows in two sections for a like reason ("core from the row front, skin from the back", neigh_build_meso.cu:91-115).
+struct RowPartArgs {
+    int group;           // pairing group of the force launches this table serves (power of two); 0: plain rows, nothing mirrored
+    int nlocal;          // partners from this index on (ghosts) are never paired
+    int *nback, *back;   // [nlocal] out, and the back table (chunked-8 rows of nb_col entries)
+    int nb_col;
 };
-int tile_build_tag_slots();
 // cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
-                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s, const RowTagArgs *tags = nullptr);
+                       const ExclArgs *excl, int nlocal, int dbg, hipStream_t s, const RowPartArgs *part = nullptr);
 int tile_build_rowcap();
 void launch_estart(const uint32_t *sorted_key, int n, int key_shift, int ncodes, int *estart, hipStream_t s);
 void launch_code_starts_u32(const uint32_t *sorted_key, int n, int ncodes, int *start, hipStream_t s);

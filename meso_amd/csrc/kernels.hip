@@ -52,26 +52,23 @@ __global__ void __launch_bounds__(256) k_nve_initial(double *__restrict__ x, dou
                                                      const double *__restrict__ fx, const double *__restrict__ fy,
                                                      const double *__restrict__ fz, const int *__restrict__ mask,
                                                      const double *__restrict__ mass, double dtf, double dtv,
-                                                     int groupbit, int n, float *__restrict__ disp_slot)
+                                                     int groupbit, int n)
 {
-    float v2max = 0.f;
     for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (mask[i] & groupbit) {
             double dtfm = dtf * rcp_poly(mass[i]);
             double a = vx[i] + dtfm * fx[i], b = vy[i] + dtfm * fy[i], c = vz[i] + dtfm * fz[i];
             vx[i] = a; vy[i] = b; vz[i] = c;
             x[i] += dtv * a; y[i] += dtv * b; z[i] += dtv * c;
-            v2max = fmaxf(v2max, (float)((a * a + b * b + c * c) * 1.000001));
         }
     }
-    if (disp_slot) book_disp(disp_slot, blockIdx.x * 4u + (threadIdx.x >> 6), v2max, 0.f);      // (the neighbour list's displacement account, RowTagArgs in kernels.h)
 }
 
-void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s, float *disp_slot)
+void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_nve_initial, dim3(capgrid(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], a.v[0], a.v[1],
-                       a.v[2], a.f[0], a.f[1], a.f[2], a.mask, a.mass, dtf, dtv, groupbit, n, disp_slot);
+                       a.v[2], a.f[0], a.f[1], a.f[2], a.mask, a.mass, dtf, dtv, groupbit, n);
 }
 
 // gpu_fix_NVE_final_integrate (fix_nve_meso.cu:157-178)
@@ -103,21 +100,15 @@ void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStre
 __global__ void __launch_bounds__(256) k_nve_boundary(NveArgs a, const double *__restrict__ fx, const double *__restrict__ fy,
                                                       const double *__restrict__ fz, int n)
 {
-    float v2max = 0.f;
-    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float v2 = 0.f;
-        nve_boundary_atom(a, i, fx[i], fy[i], fz[i], nullptr, &v2);
-        v2max = fmaxf(v2max, v2);
-    }
-    if (a.disp_slot) book_disp(a.disp_slot, blockIdx.x * 4u + (threadIdx.x >> 6), v2max, 0.f);
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        nve_boundary_atom(a, i, fx[i], fy[i], fz[i]);
 }
 
 void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, int merge, float4 *coord4,
-                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s, float *disp_slot)
+                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s)
 {
     if (n <= 0) return;
     NveArgs nv = make_nve_args(a, dtf, dtv, groupbit, merge, coord4, veloc4, cx, cy, cz, seed_next);
-    nv.disp_slot = disp_slot;
     hipLaunchKernelGGL(k_nve_boundary, dim3(capgrid(n, 256)), dim3(256), 0, s, nv, a.f[0], a.f[1], a.f[2], n);
 }
 
@@ -132,7 +123,6 @@ NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, in
     nv.cx = cx; nv.cy = cy; nv.cz = cz; nv.seed_next = seed_next;
     nv.img_cnt = nullptr; nv.img = nullptr; nv.img_shift = nullptr;
     nv.img_c4 = coord4_next; nv.img_v4 = veloc4_next; nv.img_vofs = nullptr; nv.img_center = nullptr;
-    nv.disp_slot = nullptr;
     return nv;
 }
 
@@ -927,17 +917,18 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
     const int n = a.count[i];
     const int *col = a.table + ((size_t)(i >> 6) * a.n_col) * 64 + (i & 63);
     // row entry p: transposed 64-atom tiles, or chunked-8 words (cell-ordered builder)
-    // (tagged rows - RowTagArgs, kernels.h - carry shell and pairing bits above the index: this kernel looks at every entry)
-    const u32 imask = a.tagged ? MESO_ROW_INDEX : 0xFFFFFFFFu;
+    // (partitioned rows - RowPartArgs, kernels.h: entries n .. n + nb - 1 of this walk are the back section, a row of table_back)
+    const int nb = a.nback ? a.nback[i] : 0;
     auto entry = [&](int p) -> int {
-        return (int)((u32)(a.chunked ? a.table[row_word8(i, p >> 3, a.n_col) * 8 + (p & 7)] : col[(size_t)p * 64]) & imask);
+        if (p >= n) { p -= n; return a.table_back[row_word8(i, p >> 3, a.nb_col) * 8 + (p & 7)]; }
+        return a.chunked ? a.table[row_word8(i, p >> 3, a.n_col) * 8 + (p & 7)] : col[(size_t)p * 64];
     };
 
     if (FAST) {
         float fx = 0.f, fy = 0.f, fz = 0.f, energy = 0.f;
         float vr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float dtis = (float)a.dt_inv_sqrt;
-        for (int p = 0; p < n; p++) {
+        for (int p = 0; p < n + nb; p++) {
             int j = entry(p);
             float4 c2 = a.coord4[j];
             float dx = c1.x - c2.x, dy = c1.y - c2.y, dz = c1.z - c2.z;
@@ -980,7 +971,7 @@ __global__ void __launch_bounds__(256) k_pair_dpd(PairArgs a)
     } else {
         double fx = 0., fy = 0., fz = 0., energy = 0.;
         double vr[6] = {0., 0., 0., 0., 0., 0.};
-        for (int p = 0; p < n; p++) {
+        for (int p = 0; p < n + nb; p++) {
             int j = entry(p);
             float4 c2 = a.coord4[j];
             double dx = (double)c1.x - (double)c2.x;

@@ -330,49 +330,7 @@ __device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p)
     p.vx = a.v[0][i]; p.vy = a.v[1][i]; p.vz = a.v[2][i];
     p.mass = a.mass[i]; p.mask = a.mask[i]; p.tag = a.tag[i]; p.type = a.type[i];
 }
-// |v|^2 of the wave's fastest atom into the displacement account of the neighbour list (RowTagArgs, kernels.h): every lane of the
-// wave calls (lanes without a moving atom pass 0); non-negative floats order like their bit patterns, so the maximum is an integer
-// atomic - one per wave, into the copy of the step's word that belongs to the wave's number (sub); `seen` is what that copy held
-// when the caller looked earlier on (disp_peek: a plain load issued where its latency is covered; a stale value can only be lower
-// and costs an atomic that changes nothing).  The wave maximum is a DPP reduction: no LDS round trips at the tail of a wave.
-__device__ inline float wave_max_dpp(float v)
-{
-    // row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast 15 and 31: lane 63 holds the maximum (all values >= 0)
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false)));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ inline float *disp_copy(float *slot, unsigned sub) { return slot + (size_t)(sub & (MESO_DISP_SUB - 1)) * MESO_DISP_PITCH; }
-__device__ inline float disp_peek(float *slot, unsigned sub) { return *(volatile float *)disp_copy(slot, sub); }
-__device__ inline void book_disp(float *slot, unsigned sub, float v2, float seen)
-{
-    v2 = wave_max_dpp(v2);
-    if (__lane_id() == 0 && v2 > seen) atomicMax((unsigned int *)disp_copy(slot, sub), __float_as_uint(v2));
-}
-// the displacement bound of a list that is n steps old: dt * sum over the steps of the largest booked |v| (wave-uniform).  One load
-// covers four steps: a row of 16 lanes reads the 16 copies of one step's word (disp_load: to be issued with the caller's other
-// loads, not behind them) and reduces them with DPP shifts inside the row (disp_reduce)
-__device__ inline float disp_load(const float *disp, int n, int g)
-{
-    const int lane = __lane_id(), q = g + (lane >> 4);
-    return q < n ? disp[(size_t)q * MESO_DISP_STEP + (size_t)(lane & (MESO_DISP_SUB - 1)) * MESO_DISP_PITCH] : 0.f;
-}
-__device__ inline float disp_reduce(float v)
-{
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false)));
-    const int sq = __float_as_int(__builtin_sqrtf(v));
-    return (__int_as_float(__builtin_amdgcn_readlane(sq, 15)) + __int_as_float(__builtin_amdgcn_readlane(sq, 31))) +
-           (__int_as_float(__builtin_amdgcn_readlane(sq, 47)) + __int_as_float(__builtin_amdgcn_readlane(sq, 63)));
-}
-// (v2out: |v|^2 of the velocity the atom moves with, rounded up - 0 for an atom outside the group)
-__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre = nullptr, float *v2out = nullptr)
+__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre = nullptr)
 {
     double x = pre ? pre->x : a.x[0][i], y = pre ? pre->y : a.x[1][i], z = pre ? pre->z : a.x[2][i];
     double vx = pre ? pre->vx : a.v[0][i], vy = pre ? pre->vy : a.v[1][i], vz = pre ? pre->vz : a.v[2][i];
@@ -383,7 +341,6 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
         x += a.dtv * vx; y += a.dtv * vy; z += a.dtv * vz;
         a.v[0][i] = vx; a.v[1][i] = vy; a.v[2][i] = vz;
         a.x[0][i] = x; a.x[1][i] = y; a.x[2][i] = z;
-        if (v2out) *v2out = (float)((vx * vx + vy * vy + vz * vz) * 1.000001);
     }
     if (a.merge) {
         float4 c;

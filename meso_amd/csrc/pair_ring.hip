@@ -29,14 +29,13 @@
 // addition is associative, so the sums do not depend on the order in which hits are drained (bit-reproducible).
 // Nothing is left to the compiler's contraction: the fused multiply-adds of the fp32 style are written out (see the kernel).
 //
-// Tagged rows (LP = 1, round 4; RowTagArgs in kernels.h): the list builder leaves in every entry its distance shell at build time
-// and its Newton-pairing class, and the step boundaries keep a rigorous bound D on every atom's displacement since the build.  The
-// light phase then has two stages.  Stage 1, lane = atom: one unsigned compare per row entry decides whether it can be inside the
-// cutoff on THIS step (shell <= the shell of r_c + 2 D; mirrored entries never) and the survivors go into a per-wave candidate
-// queue in LDS (ballot + mbcnt) - no gather, no distance for the 55 % of the entries that cannot be hits.  Stage 2, lane =
-// candidate: 64 queued candidates at a time are gathered and tested with every lane busy (the owner's coordinate comes from
-// LDS), hits go to the hit ring as before: the wave no longer walks as many gather-and-test rounds as its longest row has chunks.
-// A skipped entry contributes exactly zero and the fixed-point sums do not depend on order: forces are bit-identical to the full walk.
+// Partitioned rows (LP = 1, round 5; RowPartArgs in kernels.h): the list builder has decided once per rebuild which of an atom's
+// in-group pairs it evaluates (a balanced rule: about half of them, whatever the atom's place in the group) and has moved the
+// mirrored entries behind the row's front section.  The light phase then walks nact[i] entries instead of count[i] (26 instead of
+// 36 on average: five row chunks per wave instead of seven), every in-group entry it meets is one it evaluates for both atoms, and
+// the four waves of a group carry the same share of the pairs (with "the lower index evaluates" the first wave of a group had 2.4
+// times the hits of the last, and the group's accumulators are read only when the slowest wave is through).  Forces are
+// bit-identical: the same pairs, each evaluated once from one side or once from each, summed as integers.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -52,33 +51,17 @@ namespace meso {
 #define RG_WAVES 4
 #endif
 #define RG_GROUP (64 * RG_WAVES)      // atoms of a workgroup = Newton-pairing group
-#ifndef RG_TRING
-#define RG_TRING 128                // tagged rows: hit records per wave (a candidate batch adds at most 64 to fewer than 64 queued)
-#endif
-#ifndef RG_CK
-#define RG_CK 2                     // tagged rows: candidate batches requested together (1, 3, 4 and 8 measured: within 2 % at 64^3)
-#endif
-#ifndef RG_LDS_COORD
-#define RG_LDS_COORD 1              // tagged rows: an in-group candidate's coordinate comes from the workgroup's LDS copy, not from a gather
-#endif
 #ifndef RG_DP_PREFILTER
 #define RG_DP_PREFILTER 1           // fp64 style: fp32 cutoff filter in the row walk, exact fp64 test where the pair is evaluated
 #endif
 #ifndef RG_FIX_WAVES
 #define RG_FIX_WAVES 0
 #endif
-#ifndef RG_QSLOTS
-#define RG_QSLOTS 4                 // tagged rows: entry slots of every lane per fill of the candidate queue (8: a whole row chunk - 3 % faster
-#endif                              // at equal occupancy, but its 2 KB queue leaves five workgroups per CU instead of six)
-#define RG_CAND (64 * RG_QSLOTS)    // tagged rows: candidate words per wave
 #ifndef RG_RING
 #define RG_RING 256                 // records per wave; a drain check every 2 slots keeps the fill below 64 + 128
 #endif
 #ifndef RG_OCC
 #define RG_OCC 20                   // waves per CU the fp32 kernel is compiled for
-#endif
-#ifndef RG_OCC_TAGGED
-#define RG_OCC_TAGGED 24            // ... the one-lane form on tagged rows (79 VGPRs, 26 KB of LDS per workgroup: six workgroups per CU; 64^3: 100.9 -> 97.5 us)
 #endif
 #ifndef RG_OCC_DP
 #define RG_OCC_DP 8                 // ... the fp64 style (116 VGPRs: four waves per SIMD)
@@ -113,9 +96,11 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, u32 byte_off)
 #ifdef RG_STAMP
 __device__ unsigned long long *g_stamp_dev = nullptr;
 #endif
-// LP: form of the light phase - 0: every row entry is gathered and tested by its atom's lane (plain rows); 1: tagged rows, candidate queue
+// LP: 0 plain rows - the row is walked over its whole extent and the pairing class of an entry comes from the two indices ("the lower
+// index evaluates"); 1 partitioned rows (RowPartArgs, kernels.h; SHARE only): the walk covers the front section; 2 partitioned rows
+// under a launch that cannot pair by the builder's rule (a range that splits a group): the walk of LP 0 over front and back section
 template <bool FAST, int TY, bool EW1, bool SHARE, int NPART_, bool PLAIN, int LP>
-__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? (LP == 1 ? RG_OCC_TAGGED : RG_OCC) : RG_OCC_PARTS) / RG_WAVES : 1) : (RG_OCC_DP / RG_WAVES > 0 ? RG_OCC_DP / RG_WAVES : 1))
+__global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES > 0 ? (NPART_ == 1 ? RG_OCC : RG_OCC_PARTS) / RG_WAVES : 1) : (RG_OCC_DP / RG_WAVES > 0 ? RG_OCC_DP / RG_WAVES : 1))
 #if RG_FIX_WAVES
     __attribute__((amdgpu_waves_per_eu(RG_FIX_WAVES, RG_FIX_WAVES)))      // (the register allocator otherwise aims for a wave more than the launch bounds ask and spills for it)
 #endif
@@ -133,12 +118,12 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     constexpr bool NT1 = TY == 0, UCUT = TY <= 1;
     constexpr bool WIDE = NPART_ == 0;
     constexpr int NPART = WIDE ? 1 : NPART_;
-    constexpr bool TAGGED = LP == 1;
+    constexpr bool PARTED = LP == 1;
+    static_assert(!PARTED || SHARE, "partitioned rows serve pairing launches");
     // fp64 style, one lane per atom (launches of several rounds of waves): fp32 cutoff filter in the row walk, exact fp64 test where
     // the pair is evaluated (64^3: 138.5 -> 133.3 us, identical forces; the two-lane form of small boxes lost 1 % with it)
     constexpr bool DPF = RG_DP_PREFILTER && !FAST && NPART_ == 1;
-    constexpr int RING = TAGGED ? RG_TRING : RG_RING;
-    static_assert(!(TAGGED && WIDE), "tagged rows hold 25-bit indices");
+    constexpr int RING = RG_RING;
     // fp32 style: rows of 8 floats (a0, gamma, sigma, s | 1/rc, rc^2, rc, -): one 16-byte LDS read per evaluated pair
     constexpr int CFP = FAST ? 8 : N_COEFF;
     const int ncf = NT1 ? 0 : a.ntypes * a.ntypes * CFP;
@@ -151,7 +136,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     const size_t off = ((size_t)ncf * (FAST ? 4 : 8) + 15) & ~(size_t)15;
     // (the wave's number in an SGPR: the addresses of its LDS areas are scalar then)
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const size_t per_wave = RING * 16 + (NT1 ? 0 : RING) + (WIDE ? RING : 0) + (TAGGED ? RG_CAND * 4 : 0);
+    const size_t per_wave = RING * 16 + (NT1 ? 0 : RING) + (WIDE ? RING : 0);
     u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
     // the workgroup's atoms, coordinate and velocity records, by group-local index (wave w owns [64 w, 64 w + 64): one lane per atom):
     // own_c / own_v are this wave's part; a partner of another wave of the group is looked up in own_v_all (issue())
@@ -163,7 +148,6 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     float4 *ring = (float4 *)wb;        // (partner x, y, z, record word): the coordinate is not gathered twice
     unsigned char *ringt = (unsigned char *)(ring + RING);        // several types: the partner's type next to its record
     unsigned char *ringm = ringt + (NT1 ? 0 : RING);              // WIDE: owner lane | pairing flag << 6
-    u32 *cand = (u32 *)(ringm + (WIDE ? RING : 0));               // tagged rows: the candidate queue (index | pairing flag | owner lane << 26)
 
     const int nbk = gridDim.x;
     const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
@@ -176,28 +160,13 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     const bool mine = i < a.end;
     float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
     int n = 0;
-    // tagged rows: the displacement account of the list (max |v|^2 of the step boundaries since the build) is asked for first -
-    // its load travels with the atom's own data below
-    const bool pruned = TAGGED && a.disp && a.disp_n >= 0;
-    float dv0 = 0.f;
-    if (pruned) dv0 = disp_load(a.disp, a.disp_n, 0);
     // the first chunk of the row is requested together with the atom's own data (its address needs the index only; a row past
     // its count holds stale entries that are never looked at): one memory round trip less at the head of every wave
-    const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);
+    const int4 *rows = (const int4 *)a.table + 2 * row_word8(mine ? i : a.beg, 0, a.n_col);      // (the front section, or the whole plain row)
     int4 first0 = make_int4(0, 0, 0, 0), first1 = first0;
     if (mine) {
         c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i];
         first0 = rows[(size_t)part * 128]; first1 = rows[(size_t)part * 128 + 1];
-    }
-    // the shells this step has to look at: everything that can be inside the largest cutoff after those displacements (wave-uniform)
-    u32 thr = 0x80000000u;                       // (smax + 1) << 28; smax = 7: every shell
-    if (pruned) {
-        float dsum = disp_reduce(dv0);
-        for (int g = 4; g < a.disp_n; g += 4) dsum += disp_reduce(disp_load(a.disp, a.disp_n, g));      // (lists older than 4 steps)
-        const float reach = a.shell_rc + 2.00002f * a.shell_dt * dsum + a.shell_eps;
-        const float xs = (reach * reach - a.shell_base) * a.shell_k;
-        const int smax = xs <= 0.f ? 0 : min(7, (int)xs + 1);
-        thr = (u32)__builtin_amdgcn_readfirstlane((smax + 1) << MESO_ROW_SHELL_SHIFT);
     }
     // small launches (two or four lanes per atom: every wave's latency chain counts): what the step-boundary epilogue needs is
     // requested now and waits in registers (16 VGPRs: only the variants with registers to spare)
@@ -228,12 +197,16 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     const u32 t1 = __float_as_uint(c1.w);
     const float dtis = (float)a.dt_inv_sqrt;
     const u32 lanehi = (u32)slot << RG_OWNER_SHIFT;
-    const int nch_row = (n + 7) >> 3;
-    const int nch = (nch_row - part + NPART - 1) / NPART;      // chunks part, part + NPART, ... of the row
-    int nchmax = nch;
+    int nch, nchmax;
+    // chunks part, part + NPART, ... of a row of n entries; the wave walks as many as its longest row has
+    auto set_row = [&](int n_) {
+        nch = (((n_ + 7) >> 3) - part + NPART - 1) / NPART;
+        nchmax = nch;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nchmax = max(nchmax, __shfl_xor(nchmax, o, 64));
-    nchmax = __builtin_amdgcn_readfirstlane(nchmax);
+        for (int o = 32; o > 0; o >>= 1) nchmax = max(nchmax, __shfl_xor(nchmax, o, 64));
+        nchmax = __builtin_amdgcn_readfirstlane(nchmax);
+    };
+    set_row(n);
 
     int qhead = 0, qtail = 0;     // wave-uniform
     int pn = 0;                   // records of the batch whose gathers are in flight
@@ -258,7 +231,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
                 const float4 ci = own_c[owner], vi = own_v[owner];
                 if (RG_LDS_VELOC && (NPART_ == 1 && FAST) && !WIDE && a.lds_veloc) {
                     // in-group partner: its velocity record is the LDS copy of the wave that owns it (see issue())
-                    const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0 && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end);
+                    const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0;
                     const u32 pl = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;                // (in-group: < NB)
                     const float4 vl = own_v_all[inwg ? pl : (u32)(APW * w + slot)];
                     pv2.x = inwg ? vl.x : pv2.x; pv2.y = inwg ? vl.y : pv2.y; pv2.z = inwg ? vl.z : pv2.z; pv2.w = inwg ? vl.w : pv2.w;      // (component-wise: v_cndmask, not a trip through scratch)
@@ -312,7 +285,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
                 __hip_atomic_fetch_add(&facc[oo], qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[NB + oo], qy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&facc[2 * NB + oo], qz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end)) {
+                if (SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT))) {
                     // the partner is one of this workgroup's atoms: it receives the opposite force now and skips its own
                     // (mirrored) row entry
                     const u32 pj = (WIDE ? pe : (pe & RG_INDEX_MASK)) - (u32)blockbase;
@@ -342,7 +315,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
             // alone and two lanes per atom 19.0 -> 20.4 us, so not there: PairArgs::lds_veloc, set by the launcher from the size;
             // the fp64 style lost 4 % with it at 64^3: fp32 kernels only)
             // (the LDS record is read - and chosen - when the batch is evaluated: a select here would wait for the gather at once)
-            const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0 && (!TAGGED || (pe & RG_INDEX_MASK) < (u32)a.end);
+            const bool inwg = SHARE && (WIDE ? (pm & 64u) : (pe & RG_SHARED_BIT)) != 0;
             pv2 = buf_load4(rv, inwg ? 0xFFFFFFF0u : joff);
             } else pv2 = buf_load4(rv, joff);
         }
@@ -369,9 +342,14 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
                 // same aligned group: lower partner index = mirrored entry, not looked at; higher (and one of this launch's atoms) =
                 // evaluated once for both.  Two compares per entry; everything else is scalar logic on their lane masks
                 // (lower-or-equal: the tail slots of a row hold the atom itself - not looked at either)
-                const bool same = ((u32)j[q] ^ (u32)i) < (u32)NB, lower = (u32)j[q] <= (u32)i;
-                use[q] = active & !(same & lower);
-                shb[q] = same & !lower;
+                if (PARTED) {
+                    // (front section: every in-group entry is mine to evaluate for both; the section's tail slots hold the atom itself)
+                    shb[q] = ((u32)j[q] ^ (u32)i) < (u32)NB;
+                } else {
+                    const bool same = ((u32)j[q] ^ (u32)i) < (u32)NB, lower = (u32)j[q] <= (u32)i;
+                    use[q] = active & !(same & lower);
+                    shb[q] = same & !lower;
+                }
             }
         }
 #pragma unroll
@@ -415,7 +393,17 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
             }
         }
     };
-    if constexpr (!TAGGED) {
+    // a launch that does not pair by the builder's rule on a partitioned table (ranges that split a group, the records of very
+    // large systems) needs every neighbour: it walks the back section as a second row
+    constexpr int npass = LP == 2 ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; pass++) {
+        if (pass == 1) {
+            rows = (const int4 *)a.table_back + 2 * row_word8(mine ? i : a.beg, 0, a.nb_col);
+            set_row(mine ? a.nback[i] : 0);
+            first0 = make_int4(0, 0, 0, 0); first1 = first0;
+            if (nch > 0) { first0 = rows[(size_t)part * 128]; first1 = rows[(size_t)part * 128 + 1]; }
+        }
         int j[8];
         bool use[8], shb[8];
         float4 c2[8];
@@ -428,122 +416,6 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
             prep(c, v0, v1, j, use, shb, c2);
             proc(j, use, shb, c2);
         }
-    } else {
-        // ---- tagged rows: stage 1 (lane = atom) feeds the candidate queue, stage 2 (lane = candidate) the hit ring ----
-        // candidate batches whose gathers are in flight: RG_CK batches are requested together and tested one group later.  The
-        // queue is linear: every row chunk (8 entry slots of every lane) starts it at 0 and all of its candidates are requested
-        // before the next chunk is looked at - no ring arithmetic, at the price of one partly filled batch per chunk
-        constexpr int CK = RG_CK;
-        int cpn = 0;                                 // candidates of the pending group (wave-uniform)
-        u32 crec[CK];
-        float4 cc[CK];
-#pragma clang loop unroll(full)
-        for (int b = 0; b < CK; b++) { crec[b] = 0; cc[b] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        // cutoff test of the pending group, hits into the ring (record = partner coordinate + the candidate word)
-        auto ctest = [&]() __attribute__((always_inline)) {
-#pragma clang loop unroll(full)
-            for (int b = 0; b < CK; b++) {
-                if (b * 64 < cpn) {
-                    const float4 ci = own_c[crec[b] >> RG_OWNER_SHIFT];
-                    const bool valid = b * 64 + lane < cpn;
-                    if (RG_LDS_COORD && SHARE) {
-                        // a partner of this workgroup's group has its coordinate record in LDS (its gather was switched off in cstep)
-                        const bool inwg = (crec[b] & RG_SHARED_BIT) != 0 && (crec[b] & RG_INDEX_MASK) < (u32)a.end;
-                        const float4 cl = own_c_all[inwg ? (crec[b] & RG_INDEX_MASK) - (u32)blockbase : (u32)(APW * w + slot)];
-                        cc[b].x = inwg ? cl.x : cc[b].x; cc[b].y = inwg ? cl.y : cc[b].y; cc[b].z = inwg ? cl.z : cc[b].z;
-                        if (!NT1) cc[b].w = inwg ? cl.w : cc[b].w;
-                    }
-                    bool hit;
-                    u64 m;
-                    if (FAST) {
-                        const float dx = ci.x - cc[b].x, dy = ci.y - cc[b].y, dz = ci.z - cc[b].z;
-                        const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        const float cutsq = UCUT ? (float)a.cf1[P_CUTSQ] : cf32[(__float_as_uint(ci.w) * a.ntypes + __float_as_uint(cc[b].w)) * 8 + 5];
-                        // (the lane mask straight from the compares - LLVM predicates 4 = OLT, 3 = OGE, 38 = SGT: no ballot to materialise)
-                        m = __builtin_amdgcn_fcmpf(rsq, cutsq, 4) & __builtin_amdgcn_fcmpf(rsq, (float)MESO_EPSILON_SQ, 3) & __builtin_amdgcn_sicmp(cpn - b * 64, lane, 38);
-                        hit = (rsq < cutsq) & (rsq >= (float)MESO_EPSILON_SQ) & valid;
-                    } else if (DPF) {
-                        const float dx = ci.x - cc[b].x, dy = ci.y - cc[b].y, dz = ci.z - cc[b].z;
-                        const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        const float cutsq = 1.00001f * (float)(UCUT ? a.cf1[P_CUTSQ] : cf64[(__float_as_uint(ci.w) * a.ntypes + __float_as_uint(cc[b].w)) * N_COEFF + P_CUTSQ]);
-                        hit = (rsq < cutsq) & (rsq >= 0.5f * (float)MESO_EPSILON_SQ) & valid;
-                        m = __builtin_amdgcn_ballot_w64(hit);
-                    } else {
-                        const double rsq = rsq_f64(ci, cc[b]);
-                        const double cutsq = UCUT ? a.cf1[P_CUTSQ] : cf64[(__float_as_uint(ci.w) * a.ntypes + __float_as_uint(cc[b].w)) * N_COEFF + P_CUTSQ];
-                        hit = (rsq < cutsq) & (rsq >= MESO_EPSILON_SQ) & valid;
-                        m = __builtin_amdgcn_ballot_w64(hit);
-                    }
-                    if (hit) {
-                        const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RING - 1);
-                        ring[pos] = make_float4(cc[b].x, cc[b].y, cc[b].z, __uint_as_float(crec[b]));
-                        if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(cc[b].w);
-                    }
-                    qtail += __popcll(m);
-                    while (qtail - qhead >= 64) { compute(); issue(64); }
-                }
-            }
-            cpn = 0;
-        };
-        // the n queued candidates from position c0 on (up to CK batches): their coordinate gathers go out, then the group requested
-        // before - whose data has arrived meanwhile - is tested
-        auto cinwg = [&](u32 rec) __attribute__((always_inline)) { return RG_LDS_COORD && SHARE && (rec & RG_SHARED_BIT) != 0 && (rec & RG_INDEX_MASK) < (u32)a.end; };
-        auto cstep = [&](int c0, int n) __attribute__((always_inline)) {
-            u32 r2[CK];
-            float4 c2[CK];
-#pragma clang loop unroll(full)
-            for (int b = 0; b < CK; b++) {
-                r2[b] = 0; c2[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b * 64 < n) r2[b] = cand[c0 + b * 64 + lane];      // (lanes behind n: stale words, masked below)
-            }
-#pragma clang loop unroll(full)
-            for (int b = 0; b < CK; b++)
-                if (b * 64 < n) c2[b] = buf_load4(rc, ((b * 64 + lane < n) & !cinwg(r2[b])) ? (r2[b] & RG_INDEX_MASK) << 4 : 0xFFFFFFF0u);
-            ctest();
-#pragma clang loop unroll(full)
-            for (int b = 0; b < CK; b++) { crec[b] = r2[b]; cc[b] = c2[b]; }
-            cpn = n;
-        };
-        int4 w0, w1;
-        ldrow(0, w0, w1);
-#pragma unroll 1
-        for (int c = 0; c < nchmax; c++) {
-            const int4 v0 = w0, v1 = w1;
-            ldrow(c + 1, w0, w1);
-            const u64 amask = __builtin_amdgcn_sicmp(nch, c, 38);       // lanes whose row has this chunk
-            const bool active = c < nch;
-            const u32 jw[8] = {(u32)v0.x, (u32)v0.y, (u32)v0.z, (u32)v0.w, (u32)v1.x, (u32)v1.y, (u32)v1.z, (u32)v1.w};
-#pragma unroll
-            for (int q0 = 0; q0 < 8; q0 += RG_QSLOTS) {
-            int ctail = 0;
-#ifdef RG_STAMP
-            const unsigned long long st_p0 = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-            for (int q = q0; q < q0 + RG_QSLOTS; q++) {
-                // one compare: shell and mirror bit (a launch without pairing looks at mirrored entries too; 36 = ULT); tail slots
-                // carry MESO_ROW_PAD.  The candidate word is the hit record's: index, pairing flag, owner lane
-                const u32 jt = SHARE ? jw[q] : jw[q] & ~MESO_ROW_MIRROR;
-                const u64 m = __builtin_amdgcn_uicmp(jt, thr, 36) & amask;
-                const bool keep = (jt < thr) & active;
-                if (keep) {
-                    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                    (cand + ctail)[cnt] = (jw[q] & (SHARE ? (MESO_ROW_INDEX | MESO_ROW_SHARED) : MESO_ROW_INDEX)) | lanehi;
-                }
-                ctail += __popcll(m);
-            }
-#ifdef RG_STAMP
-            const unsigned long long st_p1 = __builtin_amdgcn_s_memtime();
-            st_push += st_p1 - st_p0;
-            st_ncand += ctail;
-#endif
-            for (int c0 = 0; c0 < ctail; c0 += 64 * CK) cstep(c0, min(64 * CK, ctail - c0));
-#ifdef RG_STAMP
-            st_cand += __builtin_amdgcn_s_memtime() - st_p1;
-#endif
-            }
-        }
-        ctest();
     }
 #ifdef RG_STAMP
     const unsigned long long st_light = __builtin_amdgcn_s_memtime();
@@ -555,10 +427,6 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
     const unsigned long long st_drained = __builtin_amdgcn_s_memtime();
 #endif
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
-    float v2move = 0.f;
-    // (what this wave's copy of the step's displacement word holds: asked for now, needed after the step boundary)
-    float disp_seen = 0.f;
-    if (a.fuse_nve && a.nve.disp_slot && lane == 0) disp_seen = disp_peek(a.nve.disp_slot, (u32)blk * RG_WAVES + (u32)w);
     if (mine && part == 0) {
         double fx, fy, fz;
         if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
@@ -579,15 +447,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
                     fx += bx; fy += by; fz += bz;
                 }
             }
-            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre, &v2move);
-            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, &v2move);
+            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre);
+            else nve_boundary_atom(a.nve, i, fx, fy, fz);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }
-    // the step boundary moved the atoms: its fastest one goes into the displacement account of the neighbour list (every lane calls)
-#ifndef RG_NO_BOOK
-    if (a.fuse_nve && a.nve.disp_slot) book_disp(a.nve.disp_slot, (u32)blk * RG_WAVES + (u32)w, v2move, disp_seen);
-#endif
 #ifdef RG_STAMP
     if (g_stamp_dev && lane == 0) {
         const unsigned long long st_end = __builtin_amdgcn_s_memtime();
@@ -600,18 +464,19 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? (LP == 1
 
 #if RG_UNIT == 2
 // fp64 style (dpd/meso): the instantiations of this translation unit, picked by the launcher of pair_ring.hip
-void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t sm, hipStream_t s, bool wide, bool tagged, int npart, bool nt1,
+void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t sm, hipStream_t s, bool wide, int parted, int npart, bool nt1,
                              bool ew1, bool share)
 {
 #define RG_L2(A, B, C)                                                                                                  \
     do {                                                                                                                \
         if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 0, true, 0>), grid, block, sm, s, pl);             \
-        else if (!tagged && npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 4, true, 0>), grid, block, sm, s, pl);  \
-        else if (!tagged && npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 2, true, 0>), grid, block, sm, s, pl);  \
-        else if (!tagged) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 1, true, 0>), grid, block, sm, s, pl);     \
-        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 4, true, 1>), grid, block, sm, s, pl);  \
-        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 2, true, 1>), grid, block, sm, s, pl);  \
-        else hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 1, true, 1>), grid, block, sm, s, pl);                  \
+        else if (parted == 2) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 1, true, 2>), grid, block, sm, s, pl);  \
+        else if (!parted && npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 4, true, 0>), grid, block, sm, s, pl);  \
+        else if (!parted && npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 2, true, 0>), grid, block, sm, s, pl);  \
+        else if (!parted) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 1, true, 0>), grid, block, sm, s, pl);     \
+        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 4, true, (C) ? 1 : 0>), grid, block, sm, s, pl);  \
+        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 2, true, (C) ? 1 : 0>), grid, block, sm, s, pl);  \
+        else hipLaunchKernelGGL((k_pair_dpd_ring<false, A, B, C, 1, true, (C) ? 1 : 0>), grid, block, sm, s, pl);                  \
     } while (0)
 #define RG_T(B, C)                                     \
     do {                                               \
@@ -625,7 +490,7 @@ void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t s
 #undef RG_L2
 }
 #else
-void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t sm, hipStream_t s, bool wide, bool tagged, int npart, bool nt1,
+void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t sm, hipStream_t s, bool wide, int parted, int npart, bool nt1,
                              bool ew1, bool share);
 // the instantiation the last launch ran, spelled as rocprofv3 prints it: bench.py attaches profile-derived numbers to its line
 // only while this is the kernel they were collected for
@@ -641,10 +506,9 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     const bool nt1 = p.ntypes == 1;
     size_t ncf = nt1 ? 0 : (size_t)p.ntypes * p.ntypes * (fast ? 8 * 4 : N_COEFF * 8);
     // more than 2^25 atoms (locals + ghosts): the record word cannot hold owner lane, pairing flag and index any more
-    const bool tagged = p.tagged != 0;       // (the engine tags rows only below 2^25 atoms)
-    const bool wide = !tagged && ((long)p.nall > (1L << 25) || p.debug == 9);      // (debug 9: the wide records on a small system - tests)
-    const int ring = tagged ? RG_TRING : RG_RING;
-    size_t per_wave = 64 * 16 * 2 + ring * 16 + (nt1 ? 0 : ring) + (wide ? ring : 0) + (tagged ? RG_CAND * 4 : 0) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
+    const bool wide = (long)p.nall > (1L << 25) || p.debug == 9;      // (debug 9: the wide records on a small system - tests)
+    const int ring = RG_RING;
+    size_t per_wave = 64 * 16 * 2 + ring * 16 + (nt1 ? 0 : ring) + (wide ? ring : 0) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
     // small launches: 2 lanes per atom, so that the same atoms fill twice as many waves (a 32^3 box is 2048 waves for 1024
     // SIMDs otherwise, and each wave walks 7 row chunks and ~11 hit batches one after the other)
@@ -653,24 +517,33 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     int npart = p.npart > 0 ? p.npart : (n <= 163840 ? 2 : 1);
     if (npart != 1 && npart != 2 && npart != 4) npart = 1;
     if (wide) npart = 1;
+    // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom
+    bool share = p.share != 0 && (p.beg & (64 / npart * RG_WAVES - 1)) == 0 && (p.beg & (RG_GROUP - 1)) == 0;
+    // partitioned rows serve the pairing launches of the group size they were built for (1: the walk covers the front section);
+    // any other launch over such a table needs every neighbour (2: front and back section, one lane per atom, paired by the index
+    // rule when it may pair at all).  (The engine does not partition for the wide records.)
+    int parted = 0;
+    if (wide && p.nback) { fprintf(stderr, "launch_pair_dpd_ring: partitioned rows with the wide record format\n"); abort(); }
+    if (p.nback != nullptr) {
+        parted = (share && !wide && p.part_group == 64 / npart * RG_WAVES) ? 1 : 2;
+        if (parted == 2) { npart = 1; share = share && (p.beg & (RG_GROUP - 1)) == 0; }
+    }
     const int awg = 64 / npart * RG_WAVES;
     dim3 grid(((n + awg - 1) / awg + 7) / 8 * 8), block(64 * RG_WAVES);
     bool ew1 = true;
     if (nt1) ew1 = p.cf1[P_EXPW] == 1.0;
     else ew1 = p.all_expw_one != 0;
-    // Newton pairing needs every 256-group this launch touches to lie inside [beg, end) - or end at the last local atom; tagged
-    // rows carry the pairing class of their entries for ONE group size
-    const bool share = p.share != 0 && (p.beg & (awg - 1)) == 0 && (p.beg & (RG_GROUP - 1)) == 0 && (!tagged || p.tag_group == awg);
     const bool plain = p.rng == 0 && !p.poly && !p.ftab;
 #define RG_LAUNCH2(F, A, B, C, P)                                                                                     \
     do {                                                                                                              \
         if (wide) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 0, P, 0>), grid, block, sm, s, pl);                  \
-        else if (!tagged && npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P, 0>), grid, block, sm, s, pl);       \
-        else if (!tagged && npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P, 0>), grid, block, sm, s, pl);       \
-        else if (!tagged) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P, 0>), grid, block, sm, s, pl);          \
-        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P, 1>), grid, block, sm, s, pl);       \
-        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P, 1>), grid, block, sm, s, pl);       \
-        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P, 1>), grid, block, sm, s, pl);                       \
+        else if (parted == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P, 2>), grid, block, sm, s, pl);       \
+        else if (!parted && npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P, 0>), grid, block, sm, s, pl);       \
+        else if (!parted && npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P, 0>), grid, block, sm, s, pl);       \
+        else if (!parted) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P, 0>), grid, block, sm, s, pl);          \
+        else if (npart == 4) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 4, P, (C) ? 1 : 0>), grid, block, sm, s, pl);       \
+        else if (npart == 2) hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 2, P, (C) ? 1 : 0>), grid, block, sm, s, pl);       \
+        else hipLaunchKernelGGL((k_pair_dpd_ring<F, A, B, C, 1, P, (C) ? 1 : 0>), grid, block, sm, s, pl);                       \
     } while (0)
     // (the fp64 style has no variants: always "plain")
 #define RG_LAUNCH(F, A, B, C)                                   \
@@ -707,7 +580,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
 #endif
     snprintf(g_last_variant, sizeof g_last_variant, "k_pair_dpd_ring<%s, %d, %s, %s, %d, %s, %d>", fast ? "true" : "false",
              nt1 ? 0 : (p.uniform_cut ? 1 : 2), ew1 ? "true" : "false", share ? "true" : "false", wide ? 0 : npart,
-             (plain || !fast) ? "true" : "false", tagged ? 1 : 0);
+             (plain || !fast) ? "true" : "false", parted);
     if (variant_out) snprintf(variant_out, 128, "%s", g_last_variant);
 #ifdef RG_FEW
     // (timing builds, tools/build_variant.sh: only the instantiations of the one-type benchmark decks)
@@ -715,7 +588,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     RG_LAUNCH2(true, 0, true, true, true);
 #else
     // (the fp64 instantiations are compiled by their own translation unit, pair_ring_dp.hip: half the build time)
-    if (fast) { RG_PICK(true) } else launch_pair_dpd_ring_dp(pl, grid, block, sm, s, wide, tagged, npart, nt1, ew1, share);
+    if (fast) { RG_PICK(true) } else launch_pair_dpd_ring_dp(pl, grid, block, sm, s, wide, parted, npart, nt1, ew1, share);
 #endif
 #undef RG_PICK
 #undef RG_TYPES
@@ -733,8 +606,8 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
             live++;
             for (int q = 0; q < 10; q++) sum[q] += (double)h[k * 10 + q];
         }
-        fprintf(stderr, "stamp launch %ld (%s, n %d, disp_n %d): waves %zu  cycles/wave total %.0f prologue %.0f push %.0f cand(step+test+nested heavy) %.0f heavy %.0f issue %.0f final-drain %.0f epilogue %.0f | cand/wave %.0f hits/wave %.0f\n",
-                n_launch, g_last_variant, n, p.disp_n, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, sum[4] / live, sum[5] / live, sum[6] / live,
+        fprintf(stderr, "stamp launch %ld (%s, n %d): waves %zu  cycles/wave total %.0f prologue %.0f push %.0f cand(step+test+nested heavy) %.0f heavy %.0f issue %.0f final-drain %.0f epilogue %.0f | cand/wave %.0f hits/wave %.0f\n",
+                n_launch, g_last_variant, n, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, sum[4] / live, sum[5] / live, sum[6] / live,
                 sum[7] / live, sum[8] / live, sum[9] / live);
     }
 #endif

@@ -640,6 +640,8 @@ def test_lanes_per_atom_give_identical_forces(Meso, style):
         for (i, j), a0 in {(1, 1): 15.0, (2, 2): 15.0, (1, 2): 40.0}.items():
             m.pair_coeff(i, j, a0, 4.5, 3.0, 1.0, 1.0)
         m.timestep(0.005); m.setup()
+        # (setup's forces come from the lane-per-atom kernel that also tallies energy and virial; the ring kernel's are asked for)
+        m.force_clear(); m.compute(0, 0)
         res.append(m.gather()[2])
         m.close()
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2]) and np.array_equal(res[0], res[3])
@@ -774,6 +776,9 @@ def test_dense_region_grows_the_brick_stage_instead_of_failing(Meso):
         m.timestep(0.001)
         m.setup()                                   # raised "Brick halo overflow" before
         info = m.neigh_info()
+        # (the ring kernel's forces - integer sums - instead of setup's, which come from the lane-per-atom kernel: its per-thread
+        # fp32 sums follow the entry order, and the tile builder writes its rows in two sections, RowPartArgs in kernels.h)
+        m.force_clear(); m.compute(0, 0)
         f0 = m.gather()[2]
         m.run(10)
         out[name] = (info, f0, m.gather())
@@ -805,6 +810,7 @@ def test_brick_stage_grows_during_a_run_before_it_overflows(Meso):
         m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
         m.timestep(0.005)
         m.setup()
+        m.force_clear(); m.compute(0, 0)            # (the ring kernel's integer force sums: independent of the row order)
         m.run(60)
         out[name] = (m.gather(), m.neigh_info())
         m.close()
