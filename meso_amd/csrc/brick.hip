@@ -453,13 +453,27 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
             // 33 = NE), slot of every hit in the atom's LDS row.  No "any hit?" branch: a batch almost always holds one, and
             // straight-line code lets the chains of the group's atoms overlap.  FULL: all TB_G own atoms present (16 independent
             // chains for 4 batches).  Special-bond partners are dropped by k_filter_exclusion afterwards.
+            // (two own atoms per packed instruction: the differences, squares and sums of atoms t and t + 1 are the two halves of
+            // v_pk_add / v_pk_mul / v_pk_fma_f32 - 6 instructions for two distances - with the candidate's coordinate broadcast)
+            typedef float f2 __attribute__((ext_vector_type(2)));
             auto scan = [&](auto full, const int cs, const float cx, const float cy, const float cz, const float c2) {
 #pragma unroll
-                for (int t = 0; t < TB_G; t++) {
-                    if (decltype(full)::value || t < ng) {
-                        float d;
-                        if (TB_EXPANDED) d = __builtin_fmaf(ax[t], cx, __builtin_fmaf(ay[t], cy, __builtin_fmaf(az[t], cz, c2)));
-                        else { const float dx = ax[t] - cx, dy = ay[t] - cy, dz = az[t] - cz; d = dx * dx + dy * dy + dz * dz; }
+                for (int t0 = 0; t0 < TB_G; t0 += 2) {
+                    if (!(decltype(full)::value || t0 < ng)) continue;
+                    f2 d2;
+                    if (TB_EXPANDED) {
+                        d2[0] = __builtin_fmaf(ax[t0], cx, __builtin_fmaf(ay[t0], cy, __builtin_fmaf(az[t0], cz, c2)));
+                        d2[1] = __builtin_fmaf(ax[t0 + 1], cx, __builtin_fmaf(ay[t0 + 1], cy, __builtin_fmaf(az[t0 + 1], cz, c2)));
+                    } else {
+                        const f2 dx = (f2){ax[t0], ax[t0 + 1]} - (f2){cx, cx}, dy = (f2){ay[t0], ay[t0 + 1]} - (f2){cy, cy},
+                                 dz = (f2){az[t0], az[t0 + 1]} - (f2){cz, cz};
+                        d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int t = t0 + u;
+                        if (!(decltype(full)::value || t < ng)) continue;
+                        const float d = d2[u];
                         const u64 m = __builtin_amdgcn_fcmpf(d, th[t], 5) & __builtin_amdgcn_uicmp((u32)cs, (u32)(own0 + g0 + t), 33);
                         const bool hit = (d <= th[t]) & (cs != own0 + g0 + t);
                         // (row position = entries so far [scalar, SALU work, kept inside the row] + hits in lower lanes [mbcnt x 2,
@@ -499,44 +513,50 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                 const int n_l = t_l == 0 ? nrow[0] : t_l == 1 ? nrow[1] : t_l == 2 ? nrow[2] : nrow[3];
                 const u32 i_l = hgi[own0 + g0 + (on ? t_l : 0)];
                 const int nn_l = (dbg == 2 || !on) ? 0 : min(n_l, n_col);
-                // (row_word8(i, 0, n_col) with unsigned factors: one 32 x 32 -> 64 multiply-add)
                 // (row_word8(i, 0, n_col) in bytes with unsigned factors: one 32 x 32 -> 64 multiply-add per table)
                 char *dstF = (char *)table + ((size_t)(i_l >> 6) * (u32)(n_col * 256) + ((i_l & 63u) << 5));
                 char *dstB = (char *)pt.back + ((size_t)(i_l >> 6) * (u32)(pt.nb_col * 256) + ((i_l & 63u) << 5));
-                const unsigned short *row_l = myrow0 + t_l * n_col;
+                const unsigned short *row_l = myrow0 + t_l * n_col + el;
                 const int nmax = min(n_col, __builtin_amdgcn_readfirstlane(max(max(nrow[0], nrow[1]), max(nrow[2], nrow[3]))));
+                // pairing happens inside aligned groups that lie wholly below nlocal (the force kernel applies the same test to its
+                // workgroup): an atom of the last, incomplete group has no mirrored entries
+                const u32 grp_l = (i_l | (u32)(pt.group - 1)) < (u32)pt.nlocal ? (u32)pt.group : 0u;
                 // my 16-lane group inside my half of the wave's lane mask: the lanes below me, and all of it
                 const u32 below16 = ((1u << el) - 1u) << (16 * (t_l & 1)), grp16 = 0xFFFFu << (16 * (t_l & 1));
                 const int hsh = lane & 32;
                 int nbr = 0;                     // back entries so far (the same in the 16 lanes of an atom)
+                int pfe = el;                    // my entry's place if nothing before it were mirrored
+                const int rem = nn_l - el;       // my entry of iteration e0 exists while e0 < rem
                 // byte offset of entry p inside a chunked-8 row: (p >> 3) * 2048 + (p & 7) * 4 = 4 p + 252 (p & ~7)
                 auto rowoff = [](int p) -> u32 { return __umul24((u32)p & ~7u, 252u) + ((u32)p << 2); };
                 for (int e0 = 0; e0 < nmax; e0 += 16) {
-                    const int e = e0 + el;
                     // (a lane past its row reads a stale slot - a valid one, every slot ever staged is - and neither counts nor stores)
-                    const u32 j = hgi[row_l[e]];
+                    const u32 j = hgi[row_l[e0]];
                     const u32 y = j - i_l, z = (y << 31) + y;                       // sign of z = (j < i) != ((j - i) & 1)
-                    // lane masks straight from the compares (LLVM predicates: 36 = ULT, 40 = SLT): mirrored entries of the 64 lanes
-                    const u64 m = __builtin_amdgcn_uicmp(j ^ i_l, (u32)pt.group, 36) & __builtin_amdgcn_uicmp(j, (u32)pt.nlocal, 36) &
-                                  __builtin_amdgcn_sicmp((int)z, 0, 40) & __builtin_amdgcn_sicmp(e, nn_l, 40);
+                    // lane masks straight from the compares (LLVM predicates: 36 = ULT, 38 = SGT, 40 = SLT): mirrored entries of the 64 lanes
+                    const u64 vm = __builtin_amdgcn_sicmp(rem, e0, 38);
+                    const u64 m = __builtin_amdgcn_uicmp(j ^ i_l, grp_l, 36) & __builtin_amdgcn_sicmp((int)z, 0, 40) & vm;
                     const u32 half = (u32)(m >> hsh);
                     const int cc = nbr + __popc(half & below16);
                     // (a back row that overflows - reported below, the run ends - keeps writing into its last entry)
-                    const int pf = e - cc, pb = min(cc, pt.nb_col - 1);
+                    const int pf = pfe - cc, pb = min(cc, pt.nb_col - 1);
                     int pos;
                     char *d;
                     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(pos) : "v"(pf), "v"(pb), "s"(m));
                     asm("v_cndmask_b32 %0, %2, %4, %6\n\tv_cndmask_b32 %1, %3, %5, %6" : "=&v"(((u32 *)&d)[0]), "=&v"(((u32 *)&d)[1])
                         : "v"((u32)(size_t)dstF), "v"((u32)((size_t)dstF >> 32)), "v"((u32)(size_t)dstB), "v"((u32)((size_t)dstB >> 32)), "s"(m));
-                    if (e < nn_l) *(__attribute__((address_space(1))) int *)(size_t)(d + rowoff(pos)) = (int)j;      // (a global store, not a flat one)
+                    if (rem > e0) *(__attribute__((address_space(1))) int *)(size_t)(d + rowoff(pos)) = (int)j;      // (a global store, not a flat one)
                     nbr += __popc(half & grp16);
+                    pfe += 16;
                 }
-                // the tails of the two sections' last chunks: the atom itself (r = 0: no kernel takes it for a neighbour)
+                // the tails of the two sections' last chunks: the atom itself (r = 0: no kernel takes it for a neighbour) - lanes 0..7 of
+                // an atom's 16 write behind the front section, lanes 8..15 behind the back section
                 const int nf = nn_l - nbr, nb = min(nbr, pt.nb_col);
-                if (on && el < 8) {
-                    const int pf = nf + el, pb = nb + el;
-                    if (pf < ((nf + 7) & ~7)) *(int *)((char *)dstF + rowoff(pf)) = (int)i_l;
-                    if (pb < ((nb + 7) & ~7)) *(int *)((char *)dstB + rowoff(pb)) = (int)i_l;
+                {
+                    const bool bk = el >= 8;
+                    const int ns = bk ? nb : nf, ps = ns + (el & 7);
+                    char *dp = bk ? dstB : dstF;
+                    if (on && ps < ((ns + 7) & ~7)) *(__attribute__((address_space(1))) int *)(size_t)(dp + rowoff(ps)) = (int)i_l;
                 }
                 if (on && el == 0) {
                     if (n_l > n_col || nbr > pt.nb_col) atomicMax(overflow, max(n_l, n_col + 1));

@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     const u32 t1 = __float_as_uint(c1.w);
     const float dtis = (float)a.dt_inv_sqrt;
     const u32 lanehi = (u32)slot << RG_OWNER_SHIFT;
+    const bool blk_full = blockbase + NB <= a.end;
     int nch, nchmax;
     // chunks part, part + NPART, ... of a row of n entries; the wave walks as many as its longest row has
     auto set_row = [&](int n_) {
@@ -382,7 +383,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
             const u64 m = __builtin_amdgcn_ballot_w64(hit);
             if (hit) {
                 const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)qtail)) & (RG_RING - 1);
-                const bool sh = SHARE && shb[q] && (u32)j[q] < (u32)a.end;
+                // (partitioned rows: pairs are shared inside groups that lie wholly below the end - the builder's own test, scalar here)
+                const bool sh = SHARE && shb[q] && (PARTED ? blk_full : (u32)j[q] < (u32)a.end);
                 ring[pos] = make_float4(c2[q].x, c2[q].y, c2[q].z, __uint_as_float(WIDE ? (u32)j[q] : ((u32)j[q] | (sh ? lanehi | RG_SHARED_BIT : lanehi))));   // record word last
                 if (WIDE) ringm[pos] = (unsigned char)((u32)slot | (sh ? 64u : 0u));
                 if (!NT1) ringt[pos] = (unsigned char)__float_as_uint(c2[q].w);

@@ -584,7 +584,8 @@ run             600
     assert [int(r[0]) for r in rows] == [0, 100, 200, 300, 400, 500, 600]
     pe = np.array([float(r[4]) for r in rows]); pr = np.array([float(r[5]) for r in rows])
     assert pe[0] == pytest.approx(5.63, abs=0.08) and np.all(np.abs(pe[3:] - 4.35) < 0.08)     # 5.628 -> 4.347
-    assert np.all((pr[3:] > 26.0) & (pr[3:] < 28.0))
+    # (instantaneous pressure of 4000 atoms: mean 26.9, standard deviation about 0.45 - four samples within 3 sigma)
+    assert np.all((pr[3:] > 25.5) & (pr[3:] < 28.3)) and abs(pr[3:].mean() - 26.9) < 0.7
 
 
 @pytest.mark.parametrize("style,tol", [("dpd/fast/meso", 3e-5), ("dpd/meso", 1e-9)])

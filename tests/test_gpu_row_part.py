@@ -73,14 +73,15 @@ def test_row_sections(Meso, L, npart):
         assert (fr[i, nf[i]:(nf[i] + 7) & ~7] == i).all() and (bk[i, nb[i]:(nb[i] + 7) & ~7] == i).all()
         assert not (front == i).any() and not (back == i).any()
         assert np.array_equal(np.concatenate([front, back]), table[i, :count[i]])
-        # mine(i, j): in-group pair that atom i evaluates for both
+        # mine(i, j): in-group pair that atom i evaluates for both (pairing inside aligned groups that lie wholly below nlocal)
+        full = (i | (group - 1)) < nlocal
         for j in front:
-            if (j ^ i) < group and j < nlocal:
+            if (j ^ i) < group and full:
                 assert (i < j) != bool((i ^ j) & 1), (i, j)
                 front_pairs.add((min(i, j), max(i, j)))
                 nfront_in += 1
         for j in back:
-            assert (j ^ i) < group and j < nlocal and (j < i) != bool((i ^ j) & 1), (i, j)
+            assert (j ^ i) < group and full and (j < i) != bool((i ^ j) & 1), (i, j)
             nback += 1
     # every in-group pair is in exactly one front section
     assert nfront_in == nback == len(front_pairs) and nback > 0
