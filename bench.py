@@ -129,9 +129,14 @@ def cpu_baseline(L, x, v, lo, hi, every, steps):
     return out
 
 
-def other_box(Meso, make_box, L, a):
-    """One of the other boxes of the reference's protocol (README.md:27-35, example/simple/stat.sh:3), same deck and options: W warm-up
-    steps, K steps timed between device synchronisations.  Not the headline: a record the driver can see."""
+def other_box(Meso, make_box, L, a, style=None, every=None, steps=None, roofline=False):
+    """Another workload of the reference's protocol (README.md:27-35 runs sp.run and dp.run for case 25 / 48 / 64,
+    example/simple/stat.sh:3), same deck and options: W warm-up steps, K steps timed between device synchronisations.  Not the
+    headline: a record the driver can see.  roofline: also the force kernel alone (step boundary in its own kernel, HIP events on
+    the engine's stream) against B_pair of SURVEY.md 8(d)."""
+    style = style or a.style
+    every = every or a.every
+    steps = steps or a.steps
     x, v, lo, hi = make_box(L)
     m = Meso(0)
     for kv in a.opt:
@@ -139,19 +144,36 @@ def other_box(Meso, make_box, L, a):
         m.set_option(k, float(val))
     m.read_atoms(x, v, lo, hi)
     m.neighbor(0.3)
-    m.neigh_modify(delay=0, every=a.every, check=False)
-    m.pair_style(a.style, 1.0, 419084618)
+    m.neigh_modify(delay=0, every=every, check=False)
+    m.pair_style(style, 1.0, 419084618)
     m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
     m.timestep(0.005)
     m.setup()
     m.run(max(a.warmup, 300))           # (past the thermostat's start-up overshoot)
     m.sync()
     t0 = time.perf_counter()
-    m.run(a.steps)
+    m.run(steps)
     m.sync()
     dt = time.perf_counter() - t0
-    out = {"box": L, "natoms": len(x), "value": a.steps / dt, "unit": "timesteps/s", "steps": a.steps, "ms_per_step": 1e3 * dt / a.steps,
-           "M_particle_steps_per_s": a.steps / dt * len(x) / 1e6, "temperature_end": m.temperature(), "kernel_variant": m.pair_kernel_name()}
+    out = {"box": L, "natoms": len(x), "style": style, "every": every, "value": steps / dt, "unit": "timesteps/s", "steps": steps,
+           "ms_per_step": 1e3 * dt / steps, "M_particle_steps_per_s": steps / dt * len(x) / 1e6, "temperature_end": m.temperature(),
+           "kernel_variant": m.pair_kernel_name(), "dtype": "f32" if style != "dpd/meso" else "f64"}
+    if roofline:
+        nbar = m.neigh_info()["avg_count"]
+        m.set_option("fuse_pair", 0)
+        m.set_option("profile", 1)
+        m.timer_reset()
+        m.run(max(every, 40) // every * every)
+        ms, calls = m.timer("pair")
+        ph = {k: m.timer(k) for k in ("neigh", "reorder", "bin")}
+        m.set_option("profile", 0)
+        if calls:
+            b = len(x) * (16 + 16 + 4 + 4.0 * nbar + 24)
+            t = ms / calls * 1e-3
+            out["roofline"] = {"bound": "hbm", "achieved": b / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / t / 1e9 / HBM_PEAK_GBS,
+                               "traffic": None, "kernel": "k_pair_dpd_ring (force only, SURVEY.md 8d B_pair)", "kernel_variant": m.pair_kernel_name(),
+                               "bytes_per_launch": b, "us_per_launch": t * 1e6, "avg_neighbors": nbar}
+            out["rebuild_us"] = {k: (1e3 * v[0] / v[1] if v[1] else None) for k, v in ph.items()}
     m.close()
     return out
 
@@ -361,6 +383,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    ws_bytes = (195 if fp32 else 207) + 88 + 192 + 175.0 / max(a.every, 1)
     line = {
         "metric": "DPD timesteps/s, %d^3 rho=4 box" % L,
         "value": steps_per_s,
@@ -385,11 +408,12 @@ def main():
                      "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "kernel_variant": variant, "bytes_per_launch": b_pair_only,
                      "us_per_launch": t_alone * 1e6, "fused": fused_rec, "limiter_from_profile": limiter},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
-        # the whole step against the whole-step floor of SURVEY.md 8(d) (context, not the graded figure): pair 195 + merge 88 + NVE
-        # 108 + 84 + list build 175 / 5 = 510 B per particle-step at fp32 with a rebuild every 5 steps
-        "whole_step": {"bytes_per_particle": 510, "bytes_per_step": 510.0 * n, "achieved": 510.0 * n * steps_per_s / 1e9, "unit": "GB/s",
-                       "frac": 510.0 * n * steps_per_s / 1e9 / HBM_PEAK_GBS,
-                       "note": "SURVEY.md 8(d) floor for fp32, rebuild every 5; whole job over %d GPU(s)" % a.gpus},
+        # the whole step against the whole-step floor of SURVEY.md 8(d) (context, not the graded figure): pair 195 (fp32 sums; 207 with
+        # fp64 ones) + merge 88 + NVE 108 + 84 + list build 175 per rebuild; non-bonded decks only
+        "whole_step": None if bonds is not None else {
+            "bytes_per_particle": ws_bytes, "bytes_per_step": ws_bytes * n, "achieved": ws_bytes * n * steps_per_s / 1e9, "unit": "GB/s",
+            "frac": ws_bytes * n * steps_per_s / 1e9 / HBM_PEAK_GBS,
+            "note": "SURVEY.md 8(d) floor: pair %d + merge 88 + NVE 192 + list build 175 / %d; whole job over %d GPU(s)" % (195 if fp32 else 207, a.every, a.gpus)},
         # any engine option passed on the command line reaches the timed region: the line says so
         "ablation": bool(a.opt),
     }
@@ -405,15 +429,26 @@ def main():
                                             "back": 1e3 * v["ms_back"] / a.profile_steps, "bytes_per_call": v["bytes"] / max(v["calls"], 1)}
                                         for k, v in xstats.items()}
     # north_star: throughput on the 25^3 / 48^3 / 64^3 boxes - the other two as short passes behind the timed region (N = 1, the
-    # default workload only), so that they reach the driver's record
-    if rank == 0 and a.gpus == 1 and L == 64 and bonds is None and a.other_boxes:
+    # default workload only), so that they reach the driver's record; and the reference's dp.run protocol (README.md:27-35,
+    # example/simple/dp.run) beside sp.run: configs[1] (25^3 dpd/meso, rebuild every step), the one-GPU leg of configs[3] (64^3
+    # dpd/meso) and the per-rank size of 64^3 on 8 GPUs (32^3 dpd/fast/meso), each with its own force-kernel roofline block.
+    # (Not under --opt: an ablation run measures its one workload.)
+    if rank == 0 and a.gpus == 1 and L == 64 and bonds is None and a.other_boxes and not a.opt and a.style == "dpd/fast/meso" and a.every == 5:
         m.close()
         line["other_boxes"] = []
         for ob_l in [int(t) for t in a.other_boxes.split(",") if t]:
             try:
-                line["other_boxes"].append(other_box(Meso, make_box, ob_l, a))
+                line["other_boxes"].append(other_box(Meso, make_box, ob_l, a, steps=max(a.steps, 1000)))
             except Exception as e:      # noqa: BLE001 - must never break the headline
                 line["other_boxes"].append({"box": ob_l, "error": repr(e)[:200]})
+        line["other_configs"] = []
+        for name, ob_l, style, every, steps in (("configs[1]: 25^3 fp64, rebuild every step", 25, "dpd/meso", 1, 1000),
+                                                ("configs[3], one-GPU leg: 64^3 fp64", 64, "dpd/meso", 5, 500),
+                                                ("per-rank size of 64^3 on 8 GPUs: 32^3 fp32", 32, "dpd/fast/meso", 5, 1000)):
+            try:
+                line["other_configs"].append(dict(other_box(Meso, make_box, ob_l, a, style=style, every=every, steps=steps, roofline=True), name=name))
+            except Exception as e:      # noqa: BLE001
+                line["other_configs"].append({"name": name, "error": repr(e)[:200]})
     # CPU baseline: timed on rank 0 at N = 1 only; the N > 1 lines of the same box re-use that sample (scratch file)
     cache = os.path.join(ROOT, "gpurun_out", "cpu_baseline_%d_%d.json" % (L, a.every))
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and bonds is None:
