@@ -530,6 +530,14 @@ __device__ inline u64 to_fixed(float x)
     return ((u64)((u32)(b >> 32) - 0x41380000u) << 32) | (u32)b;
 }
 __device__ inline double from_fixed(u64 a) { return (double)(long long)a * (1.0 / 4294967296.0); }
+// fp32 style of the ring kernel: 32-bit fixed point with 16 fractional bits - one multiply and v_cvt_i32_f32 (round toward zero:
+// symmetric in the sign, so a pair evaluated from both sides still sums to zero) instead of the four-instruction 64-bit
+// conversion, and ds_add_u32 instead of ds_add_u64.  Resolution 1.5e-5 (the fp32 arithmetic of one pair force of size 100 is
+// good to 1e-5), range +-32768 for the SUM of an atom's pair forces: partial sums may wrap, the total must fit (a component
+// beyond that belongs to a run that has diverged; the single term saturates in the conversion).
+#define MESO_FIXED16_SCALE 65536.0f
+__device__ inline u32 to_fixed16(float x) { return (u32)(int)(x * MESO_FIXED16_SCALE); }
+__device__ inline double from_fixed16(u32 a) { return (double)(int)a * (1.0 / 65536.0); }
 
 struct Shift27 { double s[27][3]; };   // shift added to x for each direction (0 when not crossing a PBC)
 struct Center27 { double c[27][3]; };  // merged-coordinate origin of the receiver of each direction

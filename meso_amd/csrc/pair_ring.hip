@@ -38,6 +38,7 @@
 // bit-identical: the same pairs, each evaluated once from one side or once from each, summed as integers.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "kernels.h"
 #include "meso_device.h"
@@ -56,6 +57,9 @@ namespace meso {
 #endif
 #ifndef RG_FIX_WAVES
 #define RG_FIX_WAVES 0
+#endif
+#ifndef RG_FIX32
+#define RG_FIX32 1                  // fp32 style: force sums as 32-bit fixed point (to_fixed16, meso_device.h); 0: the 64-bit sums of rounds 1-4
 #endif
 #ifndef RG_RING
 #define RG_RING 256                 // records per wave; a drain check every 2 slots keeps the fill below 64 + 128
@@ -137,10 +141,13 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     // (the wave's number in an SGPR: the addresses of its LDS areas are scalar then)
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const size_t per_wave = RING * 16 + (NT1 ? 0 : RING) + (WIDE ? RING : 0);
-    u64 *facc = (u64 *)((char *)smem + off);           // [3][256] force sums of the workgroup's atoms, 2^-32 fixed point
+    // [3][256] force sums of the workgroup's atoms in fixed point: 64 bits (36 fractional) in the fp64 style, 32 bits (16) in the fp32 one
+    constexpr bool F32 = FAST && RG_FIX32;
+    typedef typename std::conditional<F32, u32, u64>::type acc_t;
+    acc_t *facc = (acc_t *)((char *)smem + off);
     // the workgroup's atoms, coordinate and velocity records, by group-local index (wave w owns [64 w, 64 w + 64): one lane per atom):
     // own_c / own_v are this wave's part; a partner of another wave of the group is looked up in own_v_all (issue())
-    float4 *own_c_all = (float4 *)((char *)smem + off + 3 * 64 * RG_WAVES * 8);      // (accumulator area sized for NPART = 1)
+    float4 *own_c_all = (float4 *)((char *)smem + off + 3 * 64 * RG_WAVES * sizeof(acc_t));      // (accumulator area sized for NPART = 1)
     float4 *own_v_all = own_c_all + 64 * RG_WAVES;
     constexpr int APW = 64 / NPART;                          // atoms per wave (NPART lanes share one atom, see below)
     float4 *own_c = own_c_all + APW * w, *own_v = own_v_all + APW * w;
@@ -237,7 +244,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                     const float4 vl = own_v_all[inwg ? pl : (u32)(APW * w + slot)];
                     pv2.x = inwg ? vl.x : pv2.x; pv2.y = inwg ? vl.y : pv2.y; pv2.z = inwg ? vl.z : pv2.z; pv2.w = inwg ? vl.w : pv2.w;      // (component-wise: v_cndmask, not a trip through scratch)
                 }
-                u64 qx, qy, qz;
+                acc_t qx, qy, qz;
                 if (FAST) {
                     float c_cutinv, c_ew, c_a0, c_gamma, c_sigma;
                     if (NT1) {
@@ -267,7 +274,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                         fcons = table_force_f32(r * c_cutinv, a.ftab + (NT1 ? 0 : (__float_as_uint(ci.w) * a.ntypes + __float_as_uint(pc2.w)) * a.ftab_len), a.ftab_len);
                     float fpair = __builtin_fmaf(c_sigma * wr * rn, dtis, fcons - (c_gamma * wr * wr * dot * rinv));
                     fpair *= rinv;
-                    qx = to_fixed(dx * fpair); qy = to_fixed(dy * fpair); qz = to_fixed(dz * fpair);
+                    if constexpr (F32) { qx = to_fixed16(dx * fpair); qy = to_fixed16(dy * fpair); qz = to_fixed16(dz * fpair); }
+                    else { qx = to_fixed(dx * fpair); qy = to_fixed(dy * fpair); qz = to_fixed(dz * fpair); }
                 } else {
                     PairCoeff64 pc;
                     if (NT1) {
@@ -431,7 +439,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
     if (mine && part == 0) {
         double fx, fy, fz;
-        if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
+        if constexpr (F32) { fx = from_fixed16(facc[ob]); fy = from_fixed16(facc[NB + ob]); fz = from_fixed16(facc[2 * NB + ob]); }
+        else if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
         else { fx = from_fixed36(facc[ob]); fy = from_fixed36(facc[NB + ob]); fz = from_fixed36(facc[2 * NB + ob]); }
         if (a.fuse_nve) {
             // final(s) + initial(s+1) (+ merge for s+1 into the other merged buffer: this step's is still being read)
@@ -510,7 +519,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     // more than 2^25 atoms (locals + ghosts): the record word cannot hold owner lane, pairing flag and index any more
     const bool wide = (long)p.nall > (1L << 25) || p.debug == 9;      // (debug 9: the wide records on a small system - tests)
     const int ring = RG_RING;
-    size_t per_wave = 64 * 16 * 2 + ring * 16 + (nt1 ? 0 : ring) + (wide ? ring : 0) + 64 * 3 * 8;   // incl. this wave's share of the workgroup accumulators
+    size_t per_wave = 64 * 16 * 2 + ring * 16 + (nt1 ? 0 : ring) + (wide ? ring : 0) + 64 * 3 * ((fast && RG_FIX32) ? 4 : 8);   // incl. this wave's share of the workgroup accumulators
     size_t sm = ((ncf + 15) & ~(size_t)15) + per_wave * RG_WAVES;
     // small launches: 2 lanes per atom, so that the same atoms fill twice as many waves (a 32^3 box is 2048 waves for 1024
     // SIMDs otherwise, and each wave walks 7 row chunks and ~11 hit batches one after the other)
