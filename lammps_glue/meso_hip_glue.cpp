@@ -21,6 +21,20 @@ using namespace LAMMPS_NS;
 
 #define MESO(call) MesoHipContext::check(lmp, (call), FLERR)
 
+/* type ranges of the *_coeff commands: "n", "*", "n*", "*m", "n*m" over 1..nmax - the grammar of Force::bounds (src/force.cpp), parsed
+   here so that the glue needs nothing of class Force beyond its data members */
+static void type_bounds(LAMMPS *lmp, const char *str, int nmax, int &nlo, int &nhi)
+{
+  const char *star = strchr(str, '*');
+  const int n = (int) strlen(str);
+  if (!star) nlo = nhi = atoi(str);
+  else if (n == 1) { nlo = 1; nhi = nmax; }
+  else if (star == str) { nlo = 1; nhi = atoi(str + 1); }
+  else if (star == str + n - 1) { nlo = atoi(str); nhi = nmax; }
+  else { nlo = atoi(str); nhi = atoi(star + 1); }
+  if (nlo < 1 || nhi > nmax || nlo > nhi) lmp->error->all(FLERR, "Numeric index is out of bounds");
+}
+
 static meso_ctx *g_ctx = NULL;
 
 meso_ctx *MesoHipContext::get(LAMMPS *lmp)
@@ -193,8 +207,8 @@ void MesoHipPairDPDPolyForce::coeff(int narg, char **arg)
   int n = atom->ntypes;
   if (!allocated) allocate_gs();
   int ilo, ihi, jlo, jhi;
-  force->bounds(arg[0], n, ilo, ihi);
-  force->bounds(arg[1], n, jlo, jhi);
+  type_bounds(lmp, arg[0], n, ilo, ihi);
+  type_bounds(lmp, arg[1], n, jlo, jhi);
   int order = atoi(arg[4]);
   double *c = new double[order + 1];
   for (int k = 0; k <= order; k++) c[k] = atof(arg[5 + k]);
@@ -270,8 +284,8 @@ void MesoHipPairDPDTableForce::coeff(int narg, char **arg)
     for (int k = 0; k < table_length; k++) t[k] = atof(arg[4 + k]);
   }
   int ilo, ihi, jlo, jhi;
-  force->bounds(arg[0], n, ilo, ihi);
-  force->bounds(arg[1], n, jlo, jhi);
+  type_bounds(lmp, arg[0], n, ilo, ihi);
+  type_bounds(lmp, arg[1], n, jlo, jhi);
   int count = 0;
   for (int i = ilo; i <= ihi; i++)
     for (int j = MAX(jlo, i); j <= jhi; j++) {
@@ -315,8 +329,8 @@ void MesoHipPairDPD::coeff(int narg, char **arg)
   int n = atom->ntypes;
   if (!allocated) allocate();
   int ilo, ihi, jlo, jhi;
-  force->bounds(arg[0], n, ilo, ihi);
-  force->bounds(arg[1], n, jlo, jhi);
+  type_bounds(lmp, arg[0], n, ilo, ihi);
+  type_bounds(lmp, arg[1], n, jlo, jhi);
   double cut_one = narg == 7 ? atof(arg[6]) : cut_global;
   int count = 0;
   for (int i = ilo; i <= ihi; i++)
@@ -421,7 +435,7 @@ void MesoHipBondHarmonic::coeff(int narg, char **arg)
   if (narg != 3) error->all(FLERR, "Incorrect args for bond coefficients");
   if (!allocated) allocate();
   int ilo, ihi;
-  force->bounds(arg[0], atom->nbondtypes, ilo, ihi);
+  type_bounds(lmp, arg[0], atom->nbondtypes, ilo, ihi);
   for (int i = ilo; i <= ihi; i++) {
     k[i] = atof(arg[1]); r0[i] = atof(arg[2]);
     MESO(meso_bond_coeff(MesoHipContext::get(lmp), i, k[i], r0[i]));
@@ -472,7 +486,7 @@ void MesoHipBondFENE::coeff(int narg, char **arg)
   if (narg != 5) error->all(FLERR, "Incorrect args for bond coefficients");
   if (!allocated) allocate();
   int ilo, ihi;
-  force->bounds(arg[0], atom->nbondtypes, ilo, ihi);
+  type_bounds(lmp, arg[0], atom->nbondtypes, ilo, ihi);
   for (int i = ilo; i <= ihi; i++) {
     k[i] = atof(arg[1]); r0[i] = atof(arg[2]); epsilon[i] = atof(arg[3]); sigma[i] = atof(arg[4]);
     MESO(meso_bond_coeff_fene(MesoHipContext::get(lmp), i, k[i], r0[i], epsilon[i], sigma[i]));
@@ -531,7 +545,7 @@ void MesoHipAngleHarmonic::coeff(int narg, char **arg)
   if (narg != 3) error->all(FLERR, "Incorrect args for angle coefficients");
   if (!allocated) allocate();
   int ilo, ihi;
-  force->bounds(arg[0], atom->nangletypes, ilo, ihi);
+  type_bounds(lmp, arg[0], atom->nangletypes, ilo, ihi);
   for (int i = ilo; i <= ihi; i++) {
     k[i] = atof(arg[1]);
     theta0[i] = atof(arg[2]) / 180.0 * MESO_GLUE_PI;     /* stored in radians like AngleHarmonic::coeff :157-181 */

@@ -239,7 +239,7 @@ class MesoHipIntegrate : public Integrate {
   void setup_minimal(int);
   void run(int);                       /* meso_run in chunks that end on output->next, then download */
   void cleanup();
- private:
+ protected:
   void upload();
   void download();
 };
