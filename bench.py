@@ -260,6 +260,11 @@ def main():
             dist.init_process_group("gloo")
             m.set_host_exchange(make_exchange(dist, rank))
             m.comm_init(world, rank, grid, "host")
+    elif os.environ.get("MESO_FORCE_RCCL") and a.transport == "rccl":
+        # one rank, but the engine's RCCL communicator is created all the same (ncclCommInitRank with one rank): the fields a
+        # multi-GPU line carries can be checked on the one-GPU box
+        from meso_amd.api import nccl_unique_id
+        m.comm_init(1, 0, (1, 1, 1), "rccl", nccl_unique_id())
     if bonds is None:
         m.read_atoms(x, v, lo, hi)
     else:
@@ -300,7 +305,9 @@ def main():
     for name in ("pair", "neigh", "nve", "merge", "halo", "reorder", "bin", "total_steps"):
         ms, calls = m.timer(name)
         phases[name] = {"ms_per_call": ms / calls if calls else None, "calls": calls, "ms": ms}
-    xstats = m.xchg_stats() if world > 1 and a.transport == "host" else None
+    # exchanges: host-side account (host transport) or HIP events around every RCCL group on the exchange stream (option profile)
+    rccl_on = a.transport == "rccl" and (world > 1 or os.environ.get("MESO_FORCE_RCCL"))
+    xstats = m.xchg_stats() if (world > 1 and a.transport == "host") or rccl_on else None
     m.set_option("profile", 0)
     # per launch on one rank; with several ranks the force kernel runs twice per step (bulk, then border range after the
     # ghost refresh): the two launches together cover the rank's atoms once, so they are timed together
@@ -419,9 +426,25 @@ def main():
     }
     if a.opt:
         line["options"] = list(a.opt)
-    if world > 1:
+    if world > 1 or rccl_on:
         line["n_ranks_seen"] = m.comm_count()      # ncclCommCount of the engine's communicator
-    if xstats:
+        # atoms and ghosts per rank (min / max over the ranks): a lopsided decomposition or a rank without ghosts shows here
+        cn = list(m.counts()[:2])
+        if dist is not None:
+            tc = torch.tensor(cn, dtype=torch.int64, device="cuda" if a.transport == "rccl" else "cpu")
+            tl = [torch.zeros_like(tc) for _ in range(world)]
+            dist.all_gather(tl, tc)
+            allc = [[int(t[0]), int(t[1])] for t in tl]
+        else:
+            allc = [cn]
+        line["per_rank"] = {"nlocal_min": min(c[0] for c in allc), "nlocal_max": max(c[0] for c in allc),
+                            "nghost_min": min(c[1] for c in allc), "nghost_max": max(c[1] for c in allc)}
+    if xstats is not None and rccl_on:
+        # device time of the RCCL groups per step and kind of exchange (between two events on the exchange stream: the grouped
+        # sends / receives including the wait for the slowest peer) - rank 0's view
+        line["exchange_us_per_step"] = {k: {"calls": v["calls"], "rccl_group": 1e3 * v["ms_wire"] / a.profile_steps,
+                                            "bytes_per_call": v["bytes"] / max(v["calls"], 1)} for k, v in xstats.items()}
+    elif xstats:
         # rank 0's host-side account of the exchanges during the profiled pass (host transport: a rehearsal of the multi-process
         # flow, several ranks on one GPU): per kind of exchange the time until the device had the messages ready, the time on the
         # wire including the wait for the slowest peer, and the copy back - separates exchange waits from kernels

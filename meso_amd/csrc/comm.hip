@@ -15,7 +15,10 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <rccl/rccl.h>
 
 namespace meso {
@@ -155,9 +158,39 @@ int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *uid, si
         ncclUniqueId id;
         memcpy(&id, uid, sizeof id);
         HIPCHK(hipSetDevice(device));
-        ncclComm_t c;
-        if (ncclCommInitRank(&c, nr, id, rk) != ncclSuccess) return fail(5, "ncclCommInitRank failed");
-        nccl = (ncclComm *)c;
+        // ncclCommInitRank blocks until every rank has joined: a rank that never arrives (a crashed peer, a wrong unique id) would
+        // hang the job silently.  The call runs on a helper thread and is given MESO_RCCL_TIMEOUT seconds (default 180); past that
+        // the rank reports itself and its place in the grid and the caller ends the process with a non-zero status (the helper
+        // thread cannot be cancelled: a retry is a fresh process)
+        struct Join { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t rc = ncclSuccess; ncclComm_t c = nullptr; };
+        auto join = std::make_shared<Join>();
+        const int dev = device;
+        std::thread([join, nr, id, rk, dev]() {
+            (void)hipSetDevice(dev);
+            ncclComm_t c = nullptr;
+            const ncclResult_t rc = ncclCommInitRank(&c, nr, id, rk);
+            std::lock_guard<std::mutex> lk(join->mu);
+            join->rc = rc; join->c = c; join->done = true;
+            join->cv.notify_all();
+        }).detach();
+        {
+            const char *te = getenv("MESO_RCCL_TIMEOUT");
+            const double limit = te ? atof(te) : 180.0;
+            std::unique_lock<std::mutex> lk(join->mu);
+            if (!join->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return join->done; })) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "rank %d of %d (grid cell %d %d %d, device %d): ncclCommInitRank did not return within %.0f s - a peer "
+                         "has not joined the communicator", rk, nr, myloc[0], myloc[1], myloc[2], device, limit);
+                return fail(5, msg);
+            }
+            if (join->rc != ncclSuccess) {
+                char msg[200];
+                snprintf(msg, sizeof msg, "rank %d of %d: ncclCommInitRank failed (%s)", rk, nr, ncclGetErrorString(join->rc));
+                return fail(5, msg);
+            }
+        }
+        nccl = (ncclComm *)join->c;
+        rccl_first_done = false;
     } else if (transport == 3) {
         long gid = 0;
         if (uid && uid_bytes >= sizeof(long)) memcpy(&gid, uid, sizeof(long));
@@ -223,6 +256,15 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
             } else if (sbytes[k] || rbytes[k]) any = true;
         }
         if (any) {
+            // (option profile: the group between two events on the exchange stream - what a kernel trace shows as the RCCL kernel)
+            XchgEvent xe;
+            const bool timed = profiling;
+            if (timed) {
+                if (hipEventCreate(&xe.a) != hipSuccess || hipEventCreate(&xe.b) != hipSuccess) return fail(2, "hipEventCreate failed");
+                xe.what = xchg_what; xe.bytes = 0;
+                for (int k = 0; k < np; k++) if (peer[k] != rank) xe.bytes += (double)sbytes[k];
+                HIPCHK(hipEventRecord(xe.a, stream));
+            }
             if (ncclGroupStart() != ncclSuccess) return fail(5, "ncclGroupStart failed");
             for (int k = 0; k < np; k++) {
                 if (peer[k] == rank) continue;
@@ -234,6 +276,26 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
                     if (ncclRecv(rp[q].p, rp[q].n, ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclRecv failed");
             }
             if (ncclGroupEnd() != ncclSuccess) return fail(5, "ncclGroupEnd failed");
+            if (timed) { HIPCHK(hipEventRecord(xe.b, stream)); xchg_events.push_back(xe); }
+            if (!rccl_first_done) {
+                // the first group of a communicator sets up the connections to every peer: it is waited for here, for at most
+                // MESO_RCCL_TIMEOUT seconds, so that a peer that never posts its side is reported by name instead of hanging the job
+                const char *te = getenv("MESO_RCCL_TIMEOUT");
+                const double limit = te ? atof(te) : 180.0;
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(limit);
+                hipError_t q;
+                while ((q = hipStreamQuery(stream)) == hipErrorNotReady && std::chrono::steady_clock::now() < t_end) std::this_thread::yield();
+                if (q == hipErrorNotReady) {
+                    std::string peers;
+                    for (int k = 0; k < np; k++) if (peer[k] != rank && (sbytes[k] || rbytes[k])) peers += (peers.empty() ? "" : " ") + std::to_string(peer[k]);
+                    char msg[320];
+                    snprintf(msg, sizeof msg, "rank %d of %d (grid cell %d %d %d): the first RCCL exchange (%s) with peers [%s] did not complete "
+                             "within %.0f s", rank, nranks, myloc[0], myloc[1], myloc[2], xchg_what, peers.c_str(), limit);
+                    return fail(5, msg);
+                }
+                if (q != hipSuccess) return fail(2, "HIP error in the first RCCL exchange");
+                rccl_first_done = true;
+            }
         }
         return 0;
     }
@@ -313,8 +375,24 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
 }
 
 // "what calls ms_device ms_wire ms_back bytes" per kind of exchange, one per line (meso_xchg_stats)
-std::string Engine::xchg_report() const
+void Engine::xchg_events_flush()
 {
+    for (auto &xe : xchg_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(xe.b) == hipSuccess && hipEventElapsedTime(&ms, xe.a, xe.b) == hipSuccess) {
+            XchgStat &st = xchg_stats[xe.what];
+            st.calls++;
+            st.ms_wire += ms;          // on the device: the grouped sends and receives, including the wait for the slowest peer
+            st.bytes += xe.bytes;
+        }
+        (void)hipEventDestroy(xe.a); (void)hipEventDestroy(xe.b);
+    }
+    xchg_events.clear();
+}
+
+std::string Engine::xchg_report()
+{
+    xchg_events_flush();
     std::string out;
     char buf[256];
     for (const auto &kv : xchg_stats) {

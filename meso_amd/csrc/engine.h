@@ -114,7 +114,13 @@ public:
     // host-side account of the exchanges of the host / in-process transports while option profile is on (comm.hip xchg)
     struct XchgStat { long calls = 0; double ms_device = 0, ms_wire = 0, ms_back = 0, bytes = 0; };
     std::map<std::string, XchgStat> xchg_stats;
-    std::string xchg_report() const;
+    std::string xchg_report();
+    // RCCL exchanges are stream-ordered: with option profile their groups are bracketed by HIP events on the exchange stream and
+    // booked (device time between the events) when the report is asked for
+    struct XchgEvent { hipEvent_t a, b; std::string what; double bytes; };
+    std::vector<XchgEvent> xchg_events;
+    void xchg_events_flush();
+    bool rccl_first_done = false;   // the first RCCL group of this communicator has completed (bounded wait, comm.hip xchg)
     int membw_probe(size_t nbytes, int reps, double *gbs);
 
     std::string err;

@@ -163,6 +163,7 @@ void Engine::tflush()
 
 int Engine::timer_reset()
 {
+    xchg_events_flush();
     xchg_stats.clear();
     tflush();
     for (auto &kv : timers) { kv.second.ms = 0.0; kv.second.calls = 0; }

@@ -38,7 +38,7 @@ def run(nranks, grid, L, style, steps, transport, opts):
             m.timestep(0.005)
             m.setup()
             m.run(steps)
-            out[r] = (m.gather(by_tag=False), m.counts(), m.comm_count())
+            out[r] = (m.gather(by_tag=False), m.counts(), m.comm_count(), m.xchg_stats())
             m.close()
         except Exception as e:   # noqa: BLE001
             errs.append((r, repr(e)))
@@ -54,15 +54,21 @@ def run(nranks, grid, L, style, steps, transport, opts):
         os._exit(2)
     cols = [np.concatenate([o[0][k] for o in out]) for k in range(4)]
     order = np.argsort(cols[3], kind="stable")
-    return [c[order] for c in cols], [o[1] for o in out], [o[2] for o in out]
+    return [c[order] for c in cols], [o[1] for o in out], [o[2] for o in out], [o[3] for o in out]
 
 
 def main():
     nranks, gx, gy, gz, L = (int(t) for t in sys.argv[1:6])
     style, steps = sys.argv[6], int(sys.argv[7])
     opts = [(kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[8:]]
-    a, ca, na = run(nranks, (gx, gy, gz), L, style, steps, "rccl", opts)
-    b, cb, _ = run(nranks, (gx, gy, gz), L, style, steps, "local", opts)
+    a, ca, na, xa = run(nranks, (gx, gy, gz), L, style, steps, "rccl", opts)
+    b, cb, _, _ = run(nranks, (gx, gy, gz), L, style, steps, "local", opts)
+    if dict(opts).get("profile"):
+        # option profile: every RCCL group sits between two HIP events on the exchange stream and is booked per kind of exchange
+        # (meso_xchg_stats; the host / in-process transports keep a host-side account instead)
+        for r, st in enumerate(xa):
+            assert st and all(v["calls"] > 0 and v["ms_wire"] > 0.0 and v["bytes"] > 0 for v in st.values()), (r, st)
+        print("exchange kinds timed on rank 0:", {k: (v["calls"], round(v["ms_wire"], 3)) for k, v in xa[0].items()})
     assert all(n == nranks for n in na), na                      # ncclCommCount of every rank's communicator
     assert ca == cb, (ca, cb)
     n = 4 * L ** 3

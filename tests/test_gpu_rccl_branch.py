@@ -6,7 +6,9 @@ forward_comm, /root/reference/src/USER-MESO/comm_meso.cu:41-186,256-550) never e
 Here a child process preloads tests/c/librccl_stand_in.so - the eight librccl entry points the engine calls, re-implemented for
 in-process ranks with RCCL's matching rules (per-pair FIFO, equal byte counts, grouped posting) - and runs the 2x2x2 and 2x1x1
 decks over transport "rccl" and again over "local": trajectories must be bit-identical.  What this does NOT cover is RCCL itself
-(its kernels, its IPC set-up): that needs the driver's multi-GPU node."""
+(its kernels, its IPC set-up): that needs the driver's multi-GPU node.  Nor does it cover stream-ordering or buffer-reuse hazards of an
+asynchronous transport: the stand-in synchronises the stream before it posts and after every copy (tests/c/rccl_stand_in.cpp), so what
+the comparison validates is the sizes, offsets, order and matching of the engine's messages."""
 import os
 import subprocess
 import sys
@@ -33,6 +35,7 @@ def _build():
     (2, (2, 1, 1), 10, "dpd/fast/meso", 12, ()),                   # a rank that is its own neighbour in y and z
     (8, (2, 2, 2), 12, "dpd/meso", 12, ("refresh_direct=0", "refresh_epilogue=0")),     # pack / scatter kernels around the exchange
     (4, (2, 2, 1), 12, "dpd/meso", 12, ("async_counts=0",)),       # the synchronous two-phase border exchange
+    (8, (2, 2, 2), 12, "dpd/fast/meso", 12, ("profile=1",)),       # every RCCL group between two HIP events: exchange times per kind
 ])
 def test_rccl_branch_equals_local_transport(nranks, grid, L, style, steps, opts):
     _build()
@@ -40,3 +43,5 @@ def test_rccl_branch_equals_local_transport(nranks, grid, L, style, steps, opts)
     cmd = [sys.executable, os.path.join(ROOT, "tests", "rccl_stand_in_run.py"), str(nranks)] + [str(g) for g in grid] + [str(L), style, str(steps)] + list(opts)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "OK ranks" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    if "profile=1" in opts:
+        assert "exchange kinds timed on rank 0" in r.stdout, r.stdout[-2000:]
