@@ -44,9 +44,11 @@ int meso_device_sync(meso_ctx *ctx);
  *   fuse_step     1  final(s) + initial(s+1) + merge(s+1) in one pass between the steps of one run
  *   fuse_pair     1  ... inside the ring kernel's epilogue (forces are then not stored on those steps)
  *   pair_share    1  ring kernel: pairs inside one aligned 256-atom group are evaluated once (Newton pairing)
- *   tile_plan     0  the tile builder computes each brick's plan (halo runs, slot map) itself | 1 separate k_brick_plan launch
- *   reorder_sort  0  locals reordered by counting per [border][Morton(bin)] code | 1 by rocPRIM's sort (former path, same order)
- *   ghost_sort    0  ghosts binned by counting per Morton code | 1 by sorting them (former path, same storage order)
+ *   tile_plan     0  the tile builder computes each brick's plan (halo runs, slot map) itself | 1 separate k_brick_plan launch (what rows
+ *                    shorter than 64 entries use by themselves: test_short_cutoff_rows_of_32_survive_several_fused_rebuilds)
+ *   reorder_sort  0  locals reordered by counting per [border][Morton(bin)] code | 1 by rocPRIM's radix sort (north_star's wording; same
+ *                    order: test_reorder_by_counting_equals_reorder_by_sorting)
+ *   ghost_sort    0  ghosts binned by counting per Morton code | 1 by sorting them (same storage order, same test)
  *   pair_npart    0  ring kernel: lanes per atom; 0 = by launch size (2 up to 163 840 atoms, else 1) | 1 | 2 | 4
  *   fuse_clear    1  force kernel writes f instead of clear + accumulate
  *   fuse_bonds    1  systems with bonds and no angles: the bonds of an atom are evaluated in the force kernel's step-boundary
@@ -72,7 +74,10 @@ int meso_device_sync(meso_ctx *ctx);
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
  *                    images (no k_pack_forward launch between rebuilds); -1 = for boxes of at most 524 288 local atoms, 0 off, 1 on
  *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost
- *                    binning on the side stream, joined by events (same neighbour sets and forces; measured slower)
+ *                    binning on the side stream, joined by events (north_star's "reorder on a side stream overlapped with halo pack":
+ *                    same neighbour sets and forces, measured 4-7 % slower at every size; test_rebuild_variants_give_the_same_trajectory)
+ *   check_launches 0  debugging: every stage of a rebuild (migration, reorder, borders, list builder) is synchronised and asked for
+ *                    HIP errors, so that a fault names the stage instead of surfacing at the end of meso_run
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */
 int meso_set_option(meso_ctx *ctx, const char *key, double value);
 

@@ -317,6 +317,7 @@ int Engine::set_option(const std::string &key, double val)
 {
     if (key == "fused_rebuild") { fused_rebuild = (int)val; return 0; }
     if (key == "row_part") { row_part = (int)val; return 0; }
+    if (key == "check_launches") { check_launches = (int)val; return 0; }
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
@@ -1589,6 +1590,21 @@ int Engine::check_overflow()
     return 0;
 }
 
+// option check_launches (debugging): every stage of a rebuild is waited for and asked for launch / execution errors, so that a fault
+// is reported with the stage that raised it instead of at the end of run()
+int Engine::launch_check(const char *stage)
+{
+    if (!check_launches) return 0;
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "HIP error after the rebuild stage '%s' (timestep %ld): %s", stage, (long)ntimestep, hipGetErrorString(e));
+        return fail(2, msg);
+    }
+    return 0;
+}
+
 int Engine::reneighbor()
 {
     TRY(resolve_counts());       // the previous rebuild's counts (long since arrived) size this one
@@ -1622,6 +1638,7 @@ int Engine::reneighbor()
     wrap_in_reorder = nranks == 1 && !reorder_sort && nlocal > 0;
     if (!wrap_in_reorder && !mig_slim_now()) launch_pbc(cur, boxlo, boxhi, periodic, nlocal, stream);      // (the slim migration front wraps)
     TRY(migrate());
+    TRY(launch_check("migrate"));
     ghosts_binned = false;
     fused_active = false;
     mr_runs = false;
@@ -1629,16 +1646,21 @@ int Engine::reneighbor()
     fwd_packed = false;
     if (fused_ok()) {
         TRY(rebuild_fused());
+        TRY(launch_check("fused rebuild (count, place, gather, ghosts)"));
     } else if (async_ok() && overlap_rebuild && nlocal > 0) {
         TRY(rebuild_overlapped());
+        TRY(launch_check("overlapped rebuild"));
     } else {
         TRY(reorder_locals());
+        TRY(launch_check("reorder"));
         TRY(halo_borders());
+        TRY(launch_check("borders"));
     }
     // the gathers of the force kernel address the merged arrays through 32-bit byte offsets (16 bytes per atom)
     if ((long)nlocal + nghost >= (1L << 28))
         return fail(4, "Too many atoms on one rank: local + ghost atoms exceed 268435456 (32-bit byte offsets of the gathers); use more ranks");
     TRY(build_cells_and_table());
+    TRY(launch_check("ghost binning, merged arrays, list builder"));
     if (dist_check) launch_copy_hold(cur, xhold, nlocal, nmax, stream);
     ago = 0;
     return 0;
