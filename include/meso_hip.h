@@ -76,6 +76,9 @@ int meso_device_sync(meso_ctx *ctx);
  *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost
  *                    binning on the side stream, joined by events (north_star's "reorder on a side stream overlapped with halo pack":
  *                    same neighbour sets and forces, measured 4-7 % slower at every size; test_rebuild_variants_give_the_same_trajectory)
+ *   xcd_balance   1  force launches of more than one round of workgroups: bulk and border workgroups are dealt out over the eight XCDs
+ *                    separately (in Morton order an XCD's border share lies next to its bulk share); 0 = one contiguous range of atoms
+ *                    per XCD, which leaves every border atom - a fifth more pairs, the periodic images - to the last XCD
  *   check_launches 0  debugging: every stage of a rebuild (migration, reorder, borders, list builder) is synchronised and asked for
  *                    HIP errors, so that a fault names the stage instead of surfacing at the end of meso_run
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */

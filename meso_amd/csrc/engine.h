@@ -338,6 +338,7 @@ private:
     int mr_gcnt_n = 0;
     int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
     // partitioned rows (RowPartArgs, kernels.h): the list builder decides the Newton pairing of in-group pairs once per rebuild
+    int xcd_balance = 1;            // option: the force launch deals bulk and border workgroups out over the XCDs separately (PairArgs::bulk_hint)
     int check_launches = 0;         // option (debugging): synchronise and ask for HIP errors after every stage of a rebuild
     int launch_check(const char *stage);
     int row_part = 1;               // option: 1 rows in two sections (front: what the atom evaluates, back: mirrored entries); 0 plain rows

@@ -318,6 +318,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "fused_rebuild") { fused_rebuild = (int)val; return 0; }
     if (key == "row_part") { row_part = (int)val; return 0; }
     if (key == "check_launches") { check_launches = (int)val; return 0; }
+    if (key == "xcd_balance") { xcd_balance = (int)val; return 0; }
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
@@ -1726,6 +1727,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.nall = (int)std::min<long>(counts_pending ? (long)nmax : (long)nlocal + nghost, (1L << 28) - 1);
     p.rng = pair_rng;
     p.npart = pair_npart;
+    p.bulk_hint = xcd_balance ? std::max(n_bulk_prev, 0) : 0;      // (the previous rebuild's bulk count: a scheduling hint)
     p.nback = rows_part ? pair_nback : nullptr;
     p.table_back = pair_back; p.nb_col = nb_col;
     p.part_group = part_group;

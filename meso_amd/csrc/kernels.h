@@ -159,6 +159,10 @@ struct PairArgs {
     int npart;            // ring kernel: lanes per atom (0: chosen from the launch size; 1, 2, 4)
     int lds_veloc;        // ring kernel (set by its launcher): in-group partners' velocity records from the workgroup's LDS copy
     int share;            // ring kernel: Newton pairing inside a workgroup allowed (end == nlocal or a multiple of 256)
+    // ring kernel, scheduling hint only: atoms from bulk_hint on are border atoms (more one-sided pairs, periodic images to write).  The
+    // launcher deals the bulk workgroups AND the border workgroups out over the eight XCDs (xcd_sb, xcd_sr: shares per XCD; xcd_kb: the
+    // first border workgroup): with one contiguous range per XCD the last XCD would hold every border atom.  0 / -1: one range per XCD
+    int bulk_hint, xcd_kb, xcd_sb, xcd_sr;
     // partitioned rows (RowPartArgs below): count / table hold the FRONT sections; nback[i] mirrored entries of atom i live in
     // table_back (chunked-8 rows of nb_col entries); part_group = the pairing group the builder partitioned for.  nback null: plain rows
     const int *nback, *table_back;

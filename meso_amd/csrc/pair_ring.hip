@@ -38,6 +38,7 @@
 // bit-identical: the same pairs, each evaluated once from one side or once from each, summed as integers.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 #include "kernels.h"
@@ -156,8 +157,16 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     unsigned char *ringt = (unsigned char *)(ring + RING);        // several types: the partner's type next to its record
     unsigned char *ringm = ringt + (NT1 ? 0 : RING);              // WIDE: owner lane | pairing flag << 6
 
+    // XCD-aware order (workgroups b and b + 8 share an L2): every XCD walks a contiguous range of the atoms - with a border section
+    // (xcd_sb > 0) a contiguous range of the bulk workgroups and then one of the border workgroups: in Morton order the eighths of
+    // both sections are the octants of the box, so an XCD's border atoms lie next to its bulk atoms, and the border atoms' extra work
+    // (a fifth more pairs to evaluate, their periodic images) is shared by the eight XCDs instead of ending the launch on the last
     const int nbk = gridDim.x;
-    const int blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
+    int blk;
+    if (a.xcd_sb > 0) {
+        const int x = (int)(blockIdx.x & 7), r = (int)(blockIdx.x >> 3);
+        blk = r < a.xcd_sb ? (x * a.xcd_sb + r < a.xcd_kb ? x * a.xcd_sb + r : 0x3FFFFF) : a.xcd_kb + x * a.xcd_sr + (r - a.xcd_sb);
+    } else blk = (nbk & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3));
     // NPART lanes share one atom (small launches: more waves for the same atoms): lane = part * APW + slot, the parts of an
     // atom walk its row chunks part, part + NPART, ...; sums meet in the LDS accumulators like those of the other waves
     constexpr int NB = APW * RG_WAVES;                       // atoms per workgroup = Newton-pairing group of this launch
@@ -541,6 +550,19 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     }
     const int awg = 64 / npart * RG_WAVES;
     dim3 grid(((n + awg - 1) / awg + 7) / 8 * 8), block(64 * RG_WAVES);
+    pl.xcd_kb = pl.xcd_sb = pl.xcd_sr = 0;
+    {
+        // bulk and border workgroups dealt out over the XCDs separately (see the kernel); a hint that is off by a few atoms only moves
+        // a workgroup from one share to the other
+        const int nwg = (n + awg - 1) / awg;
+        const int kb = p.bulk_hint > p.beg ? std::min(nwg, (p.bulk_hint - p.beg) / awg) : 0;
+        // (launches of more than one round of workgroups only: the two shares round up separately, and a launch that just fits the
+        // card in one round - 32^3 - must not grow a second one)
+        if (kb >= 64 && nwg - kb >= 8 && nwg > 5 * 256) {
+            pl.xcd_kb = kb; pl.xcd_sb = (kb + 7) / 8; pl.xcd_sr = (nwg - kb + 7) / 8;
+            grid = dim3(8 * (pl.xcd_sb + pl.xcd_sr));
+        }
+    }
     bool ew1 = true;
     if (nt1) ew1 = p.cf1[P_EXPW] == 1.0;
     else ew1 = p.all_expw_one != 0;
