@@ -72,7 +72,7 @@ int meso_device_sync(meso_ctx *ctx);
  *   split_gather -1  one rank: the rebuild's placing kernel only orders and a streaming pass moves the payload
  *                    (-1 = boxes of at least 200 000 local atoms, 0 off, 1 on)
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
- *                    images (no k_pack_forward launch between rebuilds); -1 = for boxes of at most 524 288 local atoms, 0 off, 1 on
+ *                    images (no k_pack_forward launch between rebuilds); -1 = on (without xcd_balance: up to 524 288 local atoms), 0 off, 1 on
  *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost
  *                    binning on the side stream, joined by events (north_star's "reorder on a side stream overlapped with halo pack":
  *                    same neighbour sets and forces, measured 4-7 % slower at every size; test_rebuild_variants_give_the_same_trajectory)

@@ -297,14 +297,15 @@ private:
     // main stream, border lists + ghost creation + ghost binning on the side stream (north_star: reorder on a side stream
     // overlapped with halo pack/unpack; the reference overlaps its sort-phase transfers, mvv_meso.cu:296-316)
     // one rank, small boxes: the step-boundary epilogue also refreshes the ghosts (no k_pack_forward launch between rebuilds)
-    int ghost_epilogue = -1;        // option: -1 by size (<= 524288 local atoms: +5 % at 25^3, +3 % at 32^3, +1 % at 48^3, -2 % at 64^3), 0 off, 1 on
+    int ghost_epilogue = -1;        // option: -1 on (up to 524288 local atoms without xcd_balance: with every border atom on the last XCD the image
+                                    // writes lengthened the 64^3 launch by 10 us; dealt out over the XCDs they cost 2 us and save the refresh kernel), 0 off, 1 on
     int *img_cnt = nullptr, *img = nullptr;
     double *d_shift27 = nullptr;
     bool images_ready = false;      // this rebuild recorded the images
     bool build_images_now = false;
     // (an atom has at most 7 periodic images - the table holds 8 - only while every periodic edge exceeds twice the ghost cutoff)
     bool img_ok = false;
-    bool images_on() const { return nranks == 1 && img_ok && (ghost_epilogue == 1 || (ghost_epilogue < 0 && nlocal <= 524288)); }
+    bool images_on() const { return nranks == 1 && img_ok && (ghost_epilogue == 1 || (ghost_epilogue < 0 && (nlocal <= 524288 || xcd_balance))); }
     // one rank: the rebuild in three launches (rebuild.hip) - count, place + gather + ghost emission, ghosts
     int *brick_order2 = nullptr;    // launch order of the 2-bricks (those that own real cells, fullest first)
     int brick2 = 1;                 // option: 2x2x2 bricks in the list builder (0: the 4x4x4 bricks of rounds 1-2)
