@@ -66,9 +66,10 @@ int meso_device_sync(meso_ctx *ctx);
  *   mr_cap_margin 0.5  see async_counts (a message that outgrows its capacity is an error, reported at the end of run(); between
  *                    two rebuilds a slab's ghosts can grow by at most the atoms of a layer as thick as the largest displacement
  *                    next to it - 11.5 % at equal density with the default skin)
- *   row_part      1  the list builder writes every row in two sections (meso_neigh_parts): what the atom evaluates in front,
+ *   row_part     -1  1 = the list builder writes every row in two sections (meso_neigh_parts): what the atom evaluates in front,
  *                    mirrored in-group entries behind; the ring kernel walks the front section only.  0 = plain rows, pairing
- *                    decided per entry and step from the two indices (round-4 form; bit-identical forces)
+ *                    decided per entry and step from the two indices (round-4 form; bit-identical forces).  -1 = two sections when
+ *                    they pay: rebuild interval of at least 4 steps (fp32 styles) / 2 steps (dpd/meso), or neigh_modify check yes
  *   split_gather -1  one rank: the rebuild's placing kernel only orders and a streaming pass moves the payload
  *                    (-1 = boxes of at least 200 000 local atoms, 0 off, 1 on)
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic

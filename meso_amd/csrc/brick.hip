@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 // gain as well although 8 atoms are staged per own atom instead of 3.4 (staging is a small part; the finer grain hides the
 // staging latency of one workgroup behind the scans of the seven others): 32^3 77 -> 52 us, 64^3 303 -> 265, 128^3 2257 -> 1784.
 // The 4-brick remains the fallback when a 2-brick neighbourhood nears its LDS stage (which does not grow).
-template <int E>
+// PART: rows in two sections (RowPartArgs, kernels.h); false: plain rows - every entry keeps its place, which spares the row-out the
+// classification and the per-entry address arithmetic (64^3: 177 against 201 us per build; what decks that rebuild on every step use)
+template <int E, bool PART>
 __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3 : 2) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
                                                               int n_col, int *__restrict__ count, int *__restrict__ table,
                                                               int *__restrict__ overflow, int split, int dbg, RowPartArgs pt)
@@ -502,6 +504,33 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
                 load_cand(b, 1, cs, cx, cy, cz, cq);
                 scan(std::false_type{}, cs[0], cx[0], cy[0], cz[0], cq[0]);
             }
+            if constexpr (!PART) {
+                // plain rows out, 16 lanes per own atom of the group: 8 lanes fill one 32-byte chunk of the chunked-8 table, slots become
+                // global indices, the tail of the last chunk is padded with the atom itself
+                const int t_l = lane >> 4, el = lane & 15;
+                const bool on = t_l < ng;
+                const int n_l = t_l == 0 ? nrow[0] : t_l == 1 ? nrow[1] : t_l == 2 ? nrow[2] : nrow[3];
+                const int i_l = (int)hgi[own0 + g0 + (on ? t_l : 0)];
+                const int nn_l = (dbg == 2 || !on) ? 0 : min(n_l, n_col);
+                const int pad_l = (nn_l + 7) & ~7;
+                // (row_word8(i, 0, n_col) with unsigned factors: one 32 x 32 -> 64 multiply-add)
+                int *dst = table + (((size_t)((u32)i_l >> 6) * (u32)(n_col >> 3)) * 64 + ((u32)i_l & 63u)) * 8 + (el & 7) + (size_t)(el >> 3) * 512;
+                const unsigned short *row_l = myrow0 + t_l * n_col;
+                const int nmax = __builtin_amdgcn_readfirstlane(max(max(nrow[0], nrow[1]), max(nrow[2], nrow[3])));
+                const int padmax = (min(nmax, n_col) + 7) & ~7;
+                for (int e0 = 0; e0 < padmax; e0 += 16) {
+                    const int e = e0 + el;
+                    if (e < pad_l) {
+                        int val = i_l;
+                        if (e < nn_l) val = (int)hgi[row_l[e]];
+                        dst[(size_t)(e0 >> 3) * 512] = val;
+                    }
+                }
+                if (on && el == 0) {
+                    if (n_l > n_col) atomicMax(overflow, n_l);
+                    count[i_l] = nn_l;
+                }
+            } else
             // rows out, 16 lanes per own atom of the group, four atoms at once: slots become global indices and every entry goes to
             // one of the row's two sections (RowPartArgs, kernels.h) - front: what this atom evaluates, back: mirrored entries
             // (partner in the same pairing group, both local, and the balanced rule gives the pair to the partner).  One ballot
@@ -776,8 +805,13 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         g2.nactive = g.order2 ? g.norder2 : g.M / 8;
         const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
         const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2 + TB_ROWPAD * 2;
-        if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-        hipLaunchKernelGGL((k_tile_build<2>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, pt);
+        if (pt.group) {
+            if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+            hipLaunchKernelGGL((k_tile_build<2, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, pt);
+        } else {
+            if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+            hipLaunchKernelGGL((k_tile_build<2, false>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, pt);
+        }
     } else {
         int split = 1;
         while (split < 4 && occupied * split * 2 <= 900) split *= 2;
@@ -785,8 +819,13 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         const dim3 tgrid((g.nactive * split + 7) / 8 * 8);
         const size_t dyn = (size_t)g.maxh * 16 + (size_t)BRK_WAVES * TB_G * n_col * 2 + TB_ROWPAD * 2;
         if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
-        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        hipLaunchKernelGGL((k_tile_build<4>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, pt);
+        if (pt.group) {
+            if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            hipLaunchKernelGGL((k_tile_build<4, true>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, pt);
+        } else {
+            if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            hipLaunchKernelGGL((k_tile_build<4, false>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, pt);
+        }
     }
     if (excl && excl->tagc && nlocal > 0) {
         const int nw = (nlocal + 63) / 64;                                  // one wave per 64 consecutive atoms

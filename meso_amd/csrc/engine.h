@@ -342,7 +342,8 @@ private:
     int xcd_balance = 1;            // option: the force launch deals bulk and border workgroups out over the XCDs separately (PairArgs::bulk_hint)
     int check_launches = 0;         // option (debugging): synchronise and ask for HIP errors after every stage of a rebuild
     int launch_check(const char *stage);
-    int row_part = 1;               // option: 1 rows in two sections (front: what the atom evaluates, back: mirrored entries); 0 plain rows
+    int row_part = -1;              // option: 1 rows in two sections (front: what the atom evaluates, back: mirrored entries); 0 plain rows;
+                                    // -1 by rebuild interval and style (build_cells_and_table)
     int *pair_nback = nullptr;      // [nmax] back entries per atom
     int *pair_back = nullptr;       // the back table: chunked-8 rows of nb_col entries
     int nb_col = 0;

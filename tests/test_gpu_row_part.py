@@ -163,3 +163,16 @@ def test_exclusion_filter_keeps_the_sections(Meso, special):
     assert res[0][0] == res[1][0]
     for a, b in zip(res[0][1:], res[1][1:]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("style,every,parted", [("dpd/fast/meso", 1, False), ("dpd/fast/meso", 3, False), ("dpd/fast/meso", 4, True),
+                                                 ("dpd/meso", 1, False), ("dpd/meso", 2, True), ("dpd/meso", 5, True)])
+def test_sections_are_written_when_they_pay(Meso, style, every, parted):
+    """option row_part -1 (default): the two sections cost the list builder and save every force launch of the interval - they are
+    written from a rebuild interval of 4 steps (fp32 style) / 2 steps (fp64 style) on; plain rows come out of the cheaper row-out"""
+    x, v, lo, hi = make_box(8)
+    m = _start(Meso, x, v, lo, hi, style, every=every)
+    m.run(2 * every + 1)
+    p = m.neigh_parts()
+    assert p["parted"] == parted and (p["nback"].sum() > 0) == parted
+    m.close()
