@@ -455,8 +455,10 @@ def main():
     # default workload only), so that they reach the driver's record; and the reference's dp.run protocol (README.md:27-35,
     # example/simple/dp.run) beside sp.run: configs[1] (25^3 dpd/meso, rebuild every step), the one-GPU leg of configs[3] (64^3
     # dpd/meso) and the per-rank size of 64^3 on 8 GPUs (32^3 dpd/fast/meso), each with its own force-kernel roofline block.
-    # (Not under --opt: an ablation run measures its one workload.)
-    if rank == 0 and a.gpus == 1 and L == 64 and bonds is None and a.other_boxes and not a.opt and a.style == "dpd/fast/meso" and a.every == 5:
+    # (Not under --opt or --no-cpu-baseline: an ablation or a profiling run measures its one workload - under rocprofv3 the other boxes
+    # would launch the same kernel instantiations and spoil the per-dispatch means.)
+    if (rank == 0 and a.gpus == 1 and L == 64 and bonds is None and a.other_boxes and not a.opt and not a.no_cpu_baseline
+            and a.style == "dpd/fast/meso" and a.every == 5):
         m.close()
         line["other_boxes"] = []
         for ob_l in [int(t) for t in a.other_boxes.split(",") if t]:
