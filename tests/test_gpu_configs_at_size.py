@@ -296,3 +296,33 @@ def test_256cube_on_one_gpu_beyond_2_25_atoms():
         assert np.array_equal(tag, np.arange(1, n + 1))
         assert np.abs(vg.sum(0)).max() < 1e-5 * n
         assert 0.8 < m.temperature() < 2.0
+
+
+@pytest.mark.parametrize("style", ["dpd/fast/meso", "dpd/meso"])
+def test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows(style):
+    """configs[2] / the one-GPU leg of configs[3] at size: with the list builder's rows in two sections (round 5, RowPartArgs in
+    kernels.h; XCD-balanced launch, ghost refresh in the epilogue) the ring kernel's forces and 12 steps with two rebuilds equal
+    those of plain rows (row_part 0, one range of atoms per XCD, refresh kernel) bit for bit - the same pairs, summed as integers.
+    The run starts from the ring kernel's forces (setup's come from the lane-per-atom kernel, whose per-thread sums follow the entry
+    order)."""
+    from meso_amd.api import Meso
+    x, v, lo, hi = make_box(64)
+    res = []
+    for opts in ((("row_part", 1),), (("row_part", 0), ("xcd_balance", 0), ("ghost_epilogue", 0))):
+        with Meso() as m:
+            for k, val in opts:
+                m.set_option(k, val)
+            m.read_atoms(x, v, lo, hi)
+            m.neighbor(0.3)
+            m.neigh_modify(delay=0, every=5, check=False)
+            m.pair_style(style, 1.0, 419084618)
+            m.pair_coeff(1, 1, 15.0, 4.5, 3.0, 1.0, 1.0)
+            m.timestep(0.005)
+            m.setup()
+            assert m.neigh_parts()["parted"] == bool(opts[0][1])
+            m.force_clear(); m.compute(0, 0)
+            f0 = m.gather()[2]
+            m.run(12)
+            res.append((f0,) + tuple(m.gather()[:3]))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
