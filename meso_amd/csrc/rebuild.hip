@@ -47,7 +47,9 @@ namespace meso {
 #ifndef FR_PLACE_THREADS
 #define FR_PLACE_THREADS 256  // k_fr_place: the ~600 atoms of a tile in one or two trips (few workgroups have atoms: latency counts)
 #endif
+#ifndef FR_DIRECT_TILES
 #define FR_DIRECT_TILES 4096  // up to this many tiles every tile adds up the tile totals in front of it directly
+#endif
 
 __device__ inline u32 compact3(u32 x)      // inverse of bit_space3: every third bit
 {

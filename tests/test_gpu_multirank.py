@@ -215,3 +215,20 @@ def test_border_message_capacity_is_checked():
     [t.start() for t in th]
     join_ranks(th, None, 120)
     assert all(e and "capacity" in e for e in errs), errs
+
+
+@pytest.mark.parametrize("style,tol", [("dpd/meso", 1e-10), ("dpd/fast/meso", 1e-5)])
+def test_two_section_rows_on_eight_ranks(style, tol):
+    """Rows in two sections (round 5) under the bulk / border split of several ranks: every rank partitions for its own pairing group
+    and both of its force launches pair inside it.  sigma = 0 (no thermostat to amplify the last-bit difference of setup's
+    lane-per-atom forces): 12 steps with two rebuilds and migration equal the run on plain rows, and no atom is lost."""
+    a0, a1, ca, _, (x, v, lo, hi) = _run_ranks(8, (2, 2, 2), 12, style, 0.0, 12, opts=(("row_part", 1),))
+    b0, b1, cb, _, _ = _run_ranks(8, (2, 2, 2), 12, style, 0.0, 12, opts=(("row_part", 0),))
+    n = len(x)
+    assert np.array_equal(a1[3], np.arange(1, n + 1)) and ca == cb
+    scale = np.abs(b0[2]).max()
+    assert np.abs(a0[2] - b0[2]).max() < 1e-5 * scale
+    prd = hi - lo
+    d = a1[0] - b1[0]
+    d -= np.round(d / prd) * prd
+    assert np.abs(d).max() < tol and np.abs(a1[1] - b1[1]).max() < 100 * tol

@@ -621,6 +621,12 @@ def test_option_matrix_sigma0_trajectories(Meso, style, tol):
         d = out[0] - ref[0]
         d -= np.round(d / prd) * prd
         assert np.abs(d).max() < tol and np.abs(out[1] - ref[1]).max() < 50 * tol, ("npart", npart, fp, sh)
+    # round 5: rows in one or two sections, with every number of lanes per atom (the pairing group the builder partitions for)
+    for rp, npart in itertools.product((0, 1), (0, 1, 2, 4)):
+        out = run({"row_part": rp, "pair_npart": npart})
+        d = out[0] - ref[0]
+        d -= np.round(d / prd) * prd
+        assert np.abs(d).max() < tol and np.abs(out[1] - ref[1]).max() < 50 * tol, ("row_part", rp, npart)
 
 
 @pytest.mark.parametrize("style", ["dpd/fast/meso", "dpd/meso"])
