@@ -1,5 +1,5 @@
-// TEST INFRASTRUCTURE ONLY - an in-process stand-in for the eight librccl entry points the engine calls (ncclGetUniqueId,
-// ncclCommInitRank, ncclCommCount, ncclCommDestroy, ncclGroupStart, ncclGroupEnd, ncclSend, ncclRecv).
+// TEST INFRASTRUCTURE ONLY - an in-process stand-in for the nine librccl entry points the engine calls (ncclGetUniqueId,
+// ncclCommInitRank, ncclCommCount, ncclGetErrorString, ncclCommDestroy, ncclGroupStart, ncclGroupEnd, ncclSend, ncclRecv).
 //
 // RCCL refuses two ranks on one device ("Duplicate GPU detected", tests/test_gpu_multiproc.py), so on the one-GPU test box the
 // engine's RCCL branch - Engine::comm_init("rccl") and the grouped send / receive schedule of Engine::xchg (comm.hip) - never ran.
@@ -144,6 +144,8 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     *comm = reinterpret_cast<ncclComm_t>(c);
     return ncclSuccess;
 }
+
+const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "stand-in error"; }
 
 ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
 {

@@ -3,7 +3,7 @@
 RCCL itself refuses two ranks on one device (tests/test_gpu_multiproc.py records the refusal), so Engine::comm_init("rccl") and the
 grouped ncclSend / ncclRecv schedule of Engine::xchg (meso_amd/csrc/comm.hip; replaces MesoComm::borders / exchange /
 forward_comm, /root/reference/src/USER-MESO/comm_meso.cu:41-186,256-550) never executed with more than one rank before round 4.
-Here a child process preloads tests/c/librccl_stand_in.so - the eight librccl entry points the engine calls, re-implemented for
+Here a child process preloads tests/c/librccl_stand_in.so - the nine librccl entry points the engine calls, re-implemented for
 in-process ranks with RCCL's matching rules (per-pair FIFO, equal byte counts, grouped posting) - and runs the 2x2x2 and 2x1x1
 decks over transport "rccl" and again over "local": trajectories must be bit-identical.  What this does NOT cover is RCCL itself
 (its kernels, its IPC set-up): that needs the driver's multi-GPU node.  Nor does it cover stream-ordering or buffer-reuse hazards of an
