@@ -339,6 +339,9 @@ private:
     int mr_gcnt_n = 0;
     int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
     // partitioned rows (RowPartArgs, kernels.h): the list builder decides the Newton pairing of in-group pairs once per rebuild
+    int fuse_count = 1;             // option: the rebuild's count kernel runs in the epilogue of the force launch in front of the rebuild
+    bool count_in_epilogue = false; // ... and has done so for the rebuild that follows
+    int prepare_count_in_epilogue(FrCountArgs &c, bool &ok);
     int xcd_balance = 1;            // option: the force launch deals bulk and border workgroups out over the XCDs separately (PairArgs::bulk_hint)
     int check_launches = 0;         // option (debugging): synchronise and ask for HIP errors after every stage of a rebuild
     int launch_check(const char *stage);

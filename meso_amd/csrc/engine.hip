@@ -319,6 +319,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "row_part") { row_part = (int)val; return 0; }
     if (key == "check_launches") { check_launches = (int)val; return 0; }
     if (key == "xcd_balance") { xcd_balance = (int)val; return 0; }
+    if (key == "fuse_count") { fuse_count = (int)val; return 0; }
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
@@ -1325,7 +1326,8 @@ int Engine::rebuild_fused()
     a.ghost_cap = std::min(nmax - nlocal - 1, send_cap);
     a.dir_start = d_dir_start;
     a.report = h_flags_dev;
-    launch_fused_rebuild(a, stream);
+    launch_fused_rebuild(a, stream, count_in_epilogue);
+    count_in_epilogue = false;
     std::swap(cur, alt);
     merged_in_reorder = true;
     if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
@@ -1648,6 +1650,12 @@ int Engine::reneighbor()
     mr_runs = false;
     mr_images_ready = false;
     fwd_packed = false;
+    if (count_in_epilogue && !fused_ok()) {
+        // the force kernel's epilogue counted for a fused rebuild that does not happen: the counters are cleared before their next use
+        count_in_epilogue = false;
+        fused_dirty = true;
+        if (rcount) HIPCHK(hipMemsetAsync(rcount, 0, (2 * (size_t)bargs.M + 1) * sizeof(int), stream));
+    }
     if (fused_ok()) {
         TRY(rebuild_fused());
         TRY(launch_check("fused rebuild (count, place, gather, ghosts)"));
@@ -1822,6 +1830,30 @@ int Engine::setup()
     return 0;
 }
 
+// The rebuild's count in the epilogue of the force launch in front of it (FrCountArgs, kernels.h; option fuse_count).  Everything the
+// rebuild would do before its first kernel happens here, ahead of that force launch: the previous rebuild's counts are read, the arrays
+// get the capacity the rebuild asks for (they may move: the caller builds its launch arguments afterwards), the fused rebuild's buffers
+// are there and clean.  ok = false: this rebuild keeps its own count kernel (several ranks, a rebuild that will not take the fused
+// path, a list builder stage that is about to grow).
+int Engine::prepare_count_in_epilogue(FrCountArgs &c, bool &ok)
+{
+    ok = false;
+    if (!fuse_count || nranks != 1 || reorder_sort || dist_check || mig_holes || fused_dirty) return 0;
+    TRY(resolve_counts());
+    if (!fused_ok() || !params_ready) return 0;
+    if ((h_flags[6] || h_flags[11]) && !brick2_off) return 0;                                   // the 2-brick stage is about to change
+    if (neigh_kernel == 1 && (long)std::max(h_flags[5], h_flags[10]) * 100 > (long)bargs.maxh * 93) return 0;      // ... or the 4-brick's
+    const int bound = (int)(nghost_prev * async_grid_scale) + 1024;
+    TRY(ensure_capacity(nlocal + bound + bound / 2));
+    TRY(fused_alloc());
+    wrap_in_reorder = true;
+    FusedArgs a;
+    fused_locals_args(a);
+    c = fused_count_args(a);
+    ok = true;
+    return 0;
+}
+
 int Engine::run(int nsteps)
 {
     if (!is_setup) return fail(3, "run before setup");
@@ -1840,6 +1872,16 @@ int Engine::run(int nsteps)
             permute_forces = true;
             if (rr) return rr;
             merged = true; ghosts_fresh = true;    // the rebuild merged with this step's seed
+        }
+        // the step in front of a rebuild inside this run: its force launch can run the rebuild's count in its epilogue (arrays may be
+        // regrown here, before any launch argument of this step is taken)
+        bool count_here = false;
+        FrCountArgs frc_args;
+        {
+            const int a1_ = ago + 1;
+            const bool next_rebuild_ = dist_check || (a1_ >= delay && a1_ % every == 0);
+            const bool fusable = fuse_pair && fuse_step && it + 1 < nsteps && !have_bonds && ring_selected() && nranks == 1;
+            if (next_rebuild_ && fusable) TRY(prepare_count_in_epilogue(frc_args, count_here));
         }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
@@ -1874,6 +1916,8 @@ int Engine::run(int nsteps)
         const bool bonded_first = have_bonds && nbondtypes > 0 && !split;
         const bool boundary_in_pair = fuse_pair && fuse_step && it + 1 < nsteps && (!have_bonds || bonded_first) && ring_selected();
         p.fuse_nve = boundary_in_pair ? 1 : 0;
+        p.frc_on = 0;
+        if (count_here && boundary_in_pair && next_rebuild && !split) { p.frc_on = 1; p.frc = frc_args; count_in_epilogue = true; }
         if (boundary_in_pair && bonded_first) {
             if (fuse_bonds && !have_angles) {
                 // ... or, without angles, inside the force kernel's epilogue: each atom's few bonds are evaluated there (the same

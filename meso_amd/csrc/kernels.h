@@ -126,6 +126,26 @@ struct NveArgs {
 NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,
                       float4 *veloc4_next, double cx, double cy, double cz, uint32_t seed_next);
 
+// First kernel of the one-rank rebuild (k_fr_count, rebuild.hip) as a per-atom function: the periodic wrap, the atom's extended
+// cell code and sub-cell key, its rank inside the code, its (key, index) word into the code's bucket, the tile totals.  The force
+// kernel's step-boundary epilogue calls it on the step in front of a rebuild (the new position is in its registers), which spares
+// the rebuild its first launch.
+struct FrCountArgs {
+    double *x[3];
+    int *image;
+    int wrap;                  // MesoDomain::pbc folded in
+    double boxlo[3], boxhi[3];
+    int per[3];
+    BinGeom g;
+    double sl_lo[3], sl_hi[3]; // border slabs
+    int sub_bits, M;
+    int *cnt, cap;             // counts per extended code [2M+1], bucket capacity
+    unsigned long long *bucket, *ovf;
+    int *novf, ovf_cap;
+    int *ttot;                 // atoms per tile of 64 codes
+    int *flags;
+};
+
 // bonds evaluated by the force kernel's epilogue (nbond null: none)
 struct BondArgs {
     const int *nbond, *bond_idx, *bond_type;
@@ -170,6 +190,8 @@ struct PairArgs {
     // ring kernel epilogue: the step boundary of the atoms this launch owns (fuse_nve != 0; forces are then not stored)
     int fuse_nve;
     NveArgs nve;
+    int frc_on;           // with fuse_nve: the epilogue also runs the rebuild's count over the positions it has just written
+    FrCountArgs frc;
     BondArgs bond;        // with fuse_nve: this atom's bond forces are computed in the epilogue and added before the step boundary
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);

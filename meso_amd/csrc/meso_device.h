@@ -330,7 +330,8 @@ __device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p)
     p.vx = a.v[0][i]; p.vy = a.v[1][i]; p.vz = a.v[2][i];
     p.mass = a.mass[i]; p.mask = a.mask[i]; p.tag = a.tag[i]; p.type = a.type[i];
 }
-__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre = nullptr)
+// (xo, yo, zo: the atom's position after the step boundary)
+__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre, double &xo, double &yo, double &zo)
 {
     double x = pre ? pre->x : a.x[0][i], y = pre ? pre->y : a.x[1][i], z = pre ? pre->z : a.x[2][i];
     double vx = pre ? pre->vx : a.v[0][i], vy = pre ? pre->vy : a.v[1][i], vz = pre ? pre->vz : a.v[2][i];
@@ -342,6 +343,7 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
         a.v[0][i] = vx; a.v[1][i] = vy; a.v[2][i] = vz;
         a.x[0][i] = x; a.x[1][i] = y; a.x[2][i] = z;
     }
+    xo = x; yo = y; zo = z;
     if (a.merge) {
         float4 c;
         c.x = (float)(x - a.cx); c.y = (float)(y - a.cy); c.z = (float)(z - a.cz);
@@ -382,6 +384,12 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
             }
         }
     }
+}
+
+__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre = nullptr)
+{
+    double x, y, z;
+    nve_boundary_atom(a, i, fx, fy, fz, pre, x, y, z);
 }
 
 // One atom of the reorder gather (gpu_permute_copy / gpu_deinterleave with permutation, atom_vec_meso.h:11-67): atom j of the old
@@ -515,6 +523,57 @@ __device__ inline void wave_group_add(u32 group, bool valid, int *__restrict__ t
     }
 }
 
+// one atom of the rebuild's count (FrCountArgs, kernels.h): every lane of the wave calls (valid: the lane holds an atom to count),
+// (cx, cy, cz) = the atom's position.  FR_COUNT_TILE codes per tile of the placing kernel (rebuild.hip)
+#define FR_COUNT_TILE 64
+__device__ inline void fr_count_atom(const FrCountArgs &a, int i, bool valid, double cx, double cy, double cz)
+{
+    u32 e = 0, key = 0;
+    if (valid) {
+        double c[3] = {cx, cy, cz};
+        if (a.wrap) {
+            const int img = a.image[i];
+            int im[3] = {img & 1023, (img >> 10) & 1023, img >> 20};
+            bool moved = false;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                if (!a.per[d]) continue;
+                const double p = a.boxhi[d] - a.boxlo[d];
+                if (c[d] < a.boxlo[d]) { c[d] += p; im[d] = (im[d] - 1) & 1023; moved = true; }
+                if (c[d] >= a.boxhi[d]) { c[d] -= p; c[d] = fmax(c[d], a.boxlo[d]); im[d] = (im[d] + 1) & 1023; moved = true; }
+            }
+            if (moved) {
+                a.x[0][i] = c[0]; a.x[1][i] = c[1]; a.x[2][i] = c[2];
+                a.image[i] = im[0] | (im[1] << 10) | (im[2] << 20);
+            }
+        }
+        const int res = 1 << (a.sub_bits / 3);
+        u32 b[3], sc[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            b[d] = (u32)clampi((int)((c[d] - a.g.lo[d]) * a.g.bininv[d] + 1), 0, a.g.mbin[d]);
+            sc[d] = (u32)clampi((int)((c[d] - a.g.lo[d] - ((double)b[d] - 1) * a.g.binsize[d]) * (res * a.g.bininv[d])), 0, res);
+        }
+        e = interleave3(b[0], b[1], b[2]);
+        key = interleave3(sc[0], sc[1], sc[2]);      // sub-cell Morton key: the order inside the cell (gpu_build_reorder_keypair)
+        const bool border = c[0] <= a.sl_lo[0] || c[0] >= a.sl_hi[0] || c[1] <= a.sl_lo[1] || c[1] >= a.sl_hi[1] || c[2] <= a.sl_lo[2] ||
+                            c[2] >= a.sl_hi[2];
+        if (border) e += (u32)a.M;
+    }
+    // rank inside the code, one atomic per run of equal codes; tile totals: one atomic per tile and wave
+    const int rank = run_rank(e, valid, a.cnt);
+    wave_group_add(e / FR_COUNT_TILE, valid, a.ttot);
+    if (!valid) return;
+    // (sub-cell key, old index) travels as one word: the placing kernel orders a cell without touching the coordinates
+    const unsigned long long ent = ((unsigned long long)key << 32) | (u32)i;
+    if (rank < a.cap) a.bucket[(size_t)e * a.cap + rank] = ent;
+    else {
+        const int o = atomicAdd(a.novf, 1);
+        if (o < a.ovf_cap) { a.ovf[2 * o] = (unsigned long long)e; a.ovf[2 * o + 1] = ent; }
+        else atomicMax(a.flags, 300000);
+    }
+}
+
 __device__ inline size_t row_word8(int i, int c, int n_col) { return ((size_t)(i >> 6) * (n_col >> 3) + c) * 64 + (i & 63); }
 
 // x -> two's-complement 64-bit fixed point with 32 fractional bits: floor(x) in the high word, fract(x) * 2^32 in the low
@@ -586,7 +645,8 @@ struct FusedArgs {
     int *flags;                // device flags ([0] overflow code)
     int *report;               // pinned host memory as the device sees it
 };
-void launch_fused_rebuild(const FusedArgs &a, hipStream_t s);
+void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted = false);      // counted: the count ran in the force kernel's epilogue
+FrCountArgs fused_count_args(const FusedArgs &a);
 int fused_tile_codes();
 int fused_gtile_codes();
 int fused_direct_tiles();

@@ -446,6 +446,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     const unsigned long long st_drained = __builtin_amdgcn_s_memtime();
 #endif
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
+    double xn0 = 0.0, xn1 = 0.0, xn2 = 0.0;       // the atom's position after the step boundary (for the rebuild's count below)
     if (mine && part == 0) {
         double fx, fy, fz;
         if constexpr (F32) { fx = from_fixed16(facc[ob]); fy = from_fixed16(facc[NB + ob]); fz = from_fixed16(facc[2 * NB + ob]); }
@@ -467,11 +468,14 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                     fx += bx; fy += by; fz += bz;
                 }
             }
-            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre);
-            else nve_boundary_atom(a.nve, i, fx, fy, fz);
+            if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre, xn0, xn1, xn2);
+            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, xn0, xn1, xn2);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }
+    // the step in front of a rebuild: the rebuild's first kernel - wrap, cell code, rank inside the cell, bucket entry, tile totals
+    // (fr_count_atom, meso_device.h) - over the position the step boundary has just produced; every lane of the wave takes part
+    if (a.fuse_nve && a.frc_on) fr_count_atom(a.frc, i, mine && part == 0, xn0, xn1, xn2);
 #ifdef RG_STAMP
     if (g_stamp_dev && lane == 0) {
         const unsigned long long st_end = __builtin_amdgcn_s_memtime();

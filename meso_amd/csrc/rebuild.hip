@@ -94,54 +94,33 @@ __device__ inline int fr_block_sum(int v, int *wsum)
 // ---------------------------------------------------------------------------------------------------------------------------
 // 1: count
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fr_count(FusedArgs a)
+FrCountArgs fused_count_args(const FusedArgs &a)
 {
+    FrCountArgs c;
+    for (int d = 0; d < 3; d++) {
+        c.x[d] = a.src.x[d];
+        c.boxlo[d] = a.boxlo[d]; c.boxhi[d] = a.boxhi[d]; c.per[d] = a.per[d];
+        c.sl_lo[d] = a.sl.lo[d]; c.sl_hi[d] = a.sl.hi[d];
+    }
+    c.image = a.src.image;
+    c.wrap = a.wrap;
+    c.g = a.g;
+    c.sub_bits = a.sub_bits; c.M = a.M;
+    c.cnt = a.cnt; c.cap = a.cap;
+    c.bucket = a.bucket; c.ovf = a.ovf; c.novf = a.novf; c.ovf_cap = a.ovf_cap;
+    c.ttot = a.ttot;
+    c.flags = a.flags;
+    return c;
+}
+
+__global__ void __launch_bounds__(256) k_fr_count(FrCountArgs a, const int *__restrict__ skip, int skip_n, int n)
+{
+    static_assert(FR_COUNT_TILE == FR_TILE, "tile of the count and of the placing kernel");
     const int i = blockDim.x * blockIdx.x + threadIdx.x;
-    const bool valid = i < a.n && !(a.skip && i < a.skip_n && a.skip[i] != 13);
-    u32 e = 0, key = 0;
-    if (valid) {
-        double c[3] = {a.src.x[0][i], a.src.x[1][i], a.src.x[2][i]};
-        if (a.wrap) {
-            const int img = a.src.image[i];
-            int im[3] = {img & 1023, (img >> 10) & 1023, img >> 20};
-            bool moved = false;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                if (!a.per[d]) continue;
-                const double p = a.boxhi[d] - a.boxlo[d];
-                if (c[d] < a.boxlo[d]) { c[d] += p; im[d] = (im[d] - 1) & 1023; moved = true; }
-                if (c[d] >= a.boxhi[d]) { c[d] -= p; c[d] = fmax(c[d], a.boxlo[d]); im[d] = (im[d] + 1) & 1023; moved = true; }
-            }
-            if (moved) {
-                a.src.x[0][i] = c[0]; a.src.x[1][i] = c[1]; a.src.x[2][i] = c[2];
-                a.src.image[i] = im[0] | (im[1] << 10) | (im[2] << 20);
-            }
-        }
-        const int res = 1 << (a.sub_bits / 3);
-        u32 b[3], sc[3];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            b[d] = (u32)clampi((int)((c[d] - a.g.lo[d]) * a.g.bininv[d] + 1), 0, a.g.mbin[d]);
-            sc[d] = (u32)clampi((int)((c[d] - a.g.lo[d] - ((double)b[d] - 1) * a.g.binsize[d]) * (res * a.g.bininv[d])), 0, res);
-        }
-        e = interleave3(b[0], b[1], b[2]);
-        key = interleave3(sc[0], sc[1], sc[2]);      // sub-cell Morton key: the order inside the cell (gpu_build_reorder_keypair)
-        const bool border = c[0] <= a.sl.lo[0] || c[0] >= a.sl.hi[0] || c[1] <= a.sl.lo[1] || c[1] >= a.sl.hi[1] || c[2] <= a.sl.lo[2] ||
-                            c[2] >= a.sl.hi[2];
-        if (border) e += (u32)a.M;
-    }
-    // rank inside the code, one atomic per run of equal codes; tile totals: one atomic per tile and wave
-    const int rank = run_rank(e, valid, a.cnt);
-    wave_group_add(e / FR_TILE, valid, a.ttot);
-    if (!valid) return;
-    // (sub-cell key, old index) travels as one word: the placing kernel orders a cell without touching the coordinates
-    const unsigned long long ent = ((unsigned long long)key << 32) | (u32)i;
-    if (rank < a.cap) a.bucket[(size_t)e * a.cap + rank] = ent;
-    else {
-        const int o = atomicAdd(a.novf, 1);
-        if (o < a.ovf_cap) { a.ovf[2 * o] = (unsigned long long)e; a.ovf[2 * o + 1] = ent; }
-        else atomicMax(a.flags, 300000);
-    }
+    const bool valid = i < n && !(skip && i < skip_n && skip[i] != 13);
+    double c[3] = {0.0, 0.0, 0.0};
+    if (valid) { c[0] = a.x[0][i]; c[1] = a.x[1][i]; c[2] = a.x[2][i]; }
+    fr_count_atom(a, i, valid, c[0], c[1], c[2]);
 }
 
 // the tile's first index: supertile totals in front of its supertile + tile totals in front of it inside the supertile
@@ -617,10 +596,10 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
     }
 }
 
-void launch_fused_rebuild(const FusedArgs &a, hipStream_t s)
+void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted)
 {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL(k_fr_count, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+    if (!counted) hipLaunchKernelGGL(k_fr_count, dim3((a.n + 255) / 256), dim3(256), 0, s, fused_count_args(a), a.skip, a.skip_n, a.n);
     const int ntl = 2 * a.M / FR_TILE, ntg = a.M / FR_GTILE;
     if (a.stot) hipLaunchKernelGGL(k_fr_super, dim3((ntl + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.ttot, ntl, a.stot);
     const size_t dyn2 = (size_t)a.lds_cap * 8, dyn3 = (size_t)a.lds_cap;

@@ -695,7 +695,9 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
                  # split_gather: the placing kernel only orders, a streaming pass moves the payload (default from 200 000 local atoms on)
                  (("split_gather", 1),), (("split_gather", 1), ("fused_cap", 2), ("ghost_epilogue", 0)), (("split_gather", 0),),
                  # check_launches: every stage of a rebuild synchronised and asked for HIP errors (debugging option)
-                 (("check_launches", 1),), (("check_launches", 1), ("fused_rebuild", 0))):
+                 (("check_launches", 1),), (("check_launches", 1), ("fused_rebuild", 0)),
+                 # fuse_count: the rebuild's count kernel in the epilogue of the force launch in front of the rebuild (default) or on its own
+                 (("fuse_count", 0),), (("fuse_count", 0), ("split_gather", 1)), (("fuse_count", 1), ("split_gather", 1), ("fused_cap", 2))):
         m, _ = _engine(Meso, 16, style=style, opts=opts)
         m.run(23)
         res.append(m.gather())
