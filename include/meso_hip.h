@@ -79,6 +79,9 @@ int meso_device_sync(meso_ctx *ctx);
  *                    same neighbour sets and forces, measured 4-7 % slower at every size; test_rebuild_variants_give_the_same_trajectory)
  *   fuse_count    1  one rank: on the step in front of a rebuild the force kernel's step-boundary epilogue also runs the rebuild's first
  *                    kernel (wrap, cell code, rank inside the cell, bucket entry: k_fr_count) over the positions it has just written
+ *   lean_boundary 1  the force kernel's step-boundary epilogue takes the atom's type from the merged coordinate record it holds and the mass
+ *                    from the per-type table, and skips the mask of group "all" (16 bytes per atom less to read); 0 = per-atom arrays
+ *                    (test_rebuild_variants_give_the_same_trajectory)
  *   xcd_balance   1  force launches of more than one round of workgroups: bulk and border workgroups are dealt out over the eight XCDs
  *                    separately (in Morton order an XCD's border share lies next to its bulk share); 0 = one contiguous range of atoms
  *                    per XCD, which leaves every border atom - a fifth more pairs, the periodic images - to the last XCD

@@ -339,6 +339,7 @@ private:
     int mr_gcnt_n = 0;
     int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
     // partitioned rows (RowPartArgs, kernels.h): the list builder decides the Newton pairing of in-group pairs once per rebuild
+    int lean_boundary = 1;          // option: the force kernel's step-boundary epilogue takes type and mass from what it holds (NveArgs::mass_type)
     int fuse_count = 1;             // option: the rebuild's count kernel runs in the epilogue of the force launch in front of the rebuild
     bool count_in_epilogue = false; // ... and has done so for the rebuild that follows
     int prepare_count_in_epilogue(FrCountArgs &c, bool &ok);

@@ -320,6 +320,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "check_launches") { check_launches = (int)val; return 0; }
     if (key == "xcd_balance") { xcd_balance = (int)val; return 0; }
     if (key == "fuse_count") { fuse_count = (int)val; return 0; }
+    if (key == "lean_boundary") { lean_boundary = (int)val; return 0; }
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
@@ -1939,6 +1940,7 @@ int Engine::run(int nsteps)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
                                   0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
                                   premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
+        if (boundary_in_pair && lean_boundary) p.nve.mass_type = d_mass_type;      // (type from the merged record, mass per type, no mask of group "all")
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
         if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }

@@ -106,6 +106,7 @@ struct NveArgs {
     double *x[3], *v[3];
     const double *mass;
     const int *mask, *tag, *type;
+    const double *mass_type;      // per-type masses [ntypes + 1] for callers that know the atom's type (nve_prefetch); null: per-atom reads
     double dtf, dtv;
     int groupbit;
     int merge;

@@ -118,6 +118,7 @@ NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, in
     NveArgs nv;
     for (int d = 0; d < 3; d++) { nv.x[d] = a.x[d]; nv.v[d] = a.v[d]; }
     nv.mass = a.mass; nv.mask = a.mask; nv.tag = a.tag; nv.type = a.type;
+    nv.mass_type = nullptr;
     nv.dtf = dtf; nv.dtv = dtv; nv.groupbit = groupbit; nv.merge = merge;
     nv.coord4_next = coord4_next; nv.veloc4_next = veloc4_next;
     nv.cx = cx; nv.cy = cy; nv.cz = cz; nv.seed_next = seed_next;

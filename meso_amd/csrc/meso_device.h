@@ -324,19 +324,29 @@ __device__ inline double from_fixed36(u64 a) { return (double)(long long)a * (1.
 // for the stand-alone boundary kernel and for the force kernel's epilogue, so both produce the same bits.
 // (pre: the atom's state requested ahead of time by the caller - same values, same arithmetic)
 struct NvePre { double x, y, z, vx, vy, vz, mass; int mask, tag, type; };
-__device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p)
+// (ty > 0: the caller knows the atom's type - the force kernel has it in the merged coordinate record - and, with a.mass_type set, the
+// mass comes from the per-type table [every atom's mass IS its type's, launch_unpack_mass] and the group mask is not read when the
+// group is "all" [bit 0 of every mask is set, group.cpp]: 16 of the 68 bytes the step boundary reads per atom stay where they are)
+__device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p, int ty = 0)
 {
     p.x = a.x[0][i]; p.y = a.x[1][i]; p.z = a.x[2][i];
     p.vx = a.v[0][i]; p.vy = a.v[1][i]; p.vz = a.v[2][i];
-    p.mass = a.mass[i]; p.mask = a.mask[i]; p.tag = a.tag[i]; p.type = a.type[i];
+    const bool lean = a.mass_type && ty > 0;
+    p.type = lean ? ty : a.type[i];
+    p.mass = lean ? a.mass_type[ty] : a.mass[i];
+    p.mask = (lean && a.groupbit == 1) ? 1 : a.mask[i];
+    p.tag = a.tag[i];
 }
 // (xo, yo, zo: the atom's position after the step boundary)
-__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre, double &xo, double &yo, double &zo)
+__device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre, double &xo, double &yo, double &zo,
+                                         int ty = 0)
 {
     double x = pre ? pre->x : a.x[0][i], y = pre ? pre->y : a.x[1][i], z = pre ? pre->z : a.x[2][i];
     double vx = pre ? pre->vx : a.v[0][i], vy = pre ? pre->vy : a.v[1][i], vz = pre ? pre->vz : a.v[2][i];
-    if ((pre ? pre->mask : a.mask[i]) & a.groupbit) {
-        const double dtfm = a.dtf * rcp_poly(pre ? pre->mass : a.mass[i]);
+    const bool lean = !pre && a.mass_type && ty > 0;
+    const int type_i = pre ? pre->type : lean ? ty : a.type[i];
+    if ((pre ? pre->mask : (lean && a.groupbit == 1) ? 1 : a.mask[i]) & a.groupbit) {
+        const double dtfm = a.dtf * rcp_poly(pre ? pre->mass : lean ? a.mass_type[ty] : a.mass[i]);
         vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // final_integrate, step s
         vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // initial_integrate, step s+1
         x += a.dtv * vx; y += a.dtv * vy; z += a.dtv * vz;
@@ -347,7 +357,7 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
     if (a.merge) {
         float4 c;
         c.x = (float)(x - a.cx); c.y = (float)(y - a.cy); c.z = (float)(z - a.cz);
-        c.w = __uint_as_float((u32)((pre ? pre->type : a.type[i]) - 1));
+        c.w = __uint_as_float((u32)(type_i - 1));
         a.coord4_next[i] = c;
         float4 v;
         v.x = (float)vx; v.y = (float)vy; v.z = (float)vz;

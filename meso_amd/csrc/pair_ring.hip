@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
 #endif
     constexpr bool PRE = NPART > 1 || (RG_PRE_ALL && FAST && TY == 0);
     NvePre npre;
-    if (PRE && a.fuse_nve && mine && part == 0) nve_prefetch(a.nve, i, npre);
+    if (PRE && a.fuse_nve && mine && part == 0) nve_prefetch(a.nve, i, npre, (int)__float_as_uint(c1.w) + 1);
     const int ob = w * APW + slot;                           // my atom's slot in the workgroup's accumulators
     if (part == 0) {
         own_c[slot] = c1;
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                 }
             }
             if (PRE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre, xn0, xn1, xn2);
-            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, xn0, xn1, xn2);
+            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, xn0, xn1, xn2, (int)__float_as_uint(c1.w) + 1);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }

@@ -697,7 +697,9 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
                  # check_launches: every stage of a rebuild synchronised and asked for HIP errors (debugging option)
                  (("check_launches", 1),), (("check_launches", 1), ("fused_rebuild", 0)),
                  # fuse_count: the rebuild's count kernel in the epilogue of the force launch in front of the rebuild (default) or on its own
-                 (("fuse_count", 0),), (("fuse_count", 0), ("split_gather", 1)), (("fuse_count", 1), ("split_gather", 1), ("fused_cap", 2))):
+                 (("fuse_count", 0),), (("fuse_count", 0), ("split_gather", 1)), (("fuse_count", 1), ("split_gather", 1), ("fused_cap", 2)),
+                 # lean_boundary: the epilogue takes type and mass from the merged record and the per-type table (default) or from the atom arrays
+                 (("lean_boundary", 0),)):
         m, _ = _engine(Meso, 16, style=style, opts=opts)
         m.run(23)
         res.append(m.gather())
@@ -706,6 +708,36 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
         m.close()
     for other in res[1:]:
         for a, b in zip(res[0][:3], other[:3]):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("style", ["dpd/meso", "dpd/fast/meso"])
+def test_step_boundary_reads_type_and_mass_from_what_the_kernel_holds(Meso, style):
+    """option lean_boundary (default): the force kernel's step-boundary epilogue takes the atom's type from the merged coordinate record
+    and the mass from the per-type table instead of the per-atom arrays.  Two types of DIFFERENT mass: positions, velocities and forces
+    after 23 steps equal those of the per-atom reads (lean_boundary 0) and of the stand-alone boundary kernel (fuse_pair 0) bit for bit."""
+    from meso_amd.datagen import make_polymer_box
+    x, v, types, _, lo, hi = make_polymer_box(11, frac=0.4)
+    res = []
+    for opts in ((), (("lean_boundary", 0),), (("fuse_pair", 0),), (("pair_npart", 1),), (("pair_npart", 1), ("lean_boundary", 0))):
+        m = Meso()
+        for k, val in opts:
+            m.set_option(k, val)
+        m.read_atoms(x, v, lo, hi, types=types, ntypes=2, masses=[0.0, 1.0, 2.5])
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style(style, 1.0, DP_RUN["seed"])
+        for (i, j), a0 in {(1, 1): 15.0, (2, 2): 15.0, (1, 2): 40.0}.items():
+            m.pair_coeff(i, j, a0, 4.5, 3.0, 1.0, 1.0)
+        m.timestep(0.005)
+        m.setup()
+        m.force_clear(); m.compute(0, 0)      # (the ring kernel's forces: independent of the entry order, which pair_npart changes)
+        m.run(23)
+        res.append(m.gather()[:3])
+        m.close()
+    assert np.abs(res[0][1]).max() > 0.5
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
             assert np.array_equal(a, b)
 
 
