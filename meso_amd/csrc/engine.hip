@@ -1944,6 +1944,8 @@ int Engine::run(int nsteps)
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
         if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }
+        // (fused rebuild: the order is [bulk][border] and estart[M] is the first border atom - only those can have images)
+        if (img_step && fused_active && lean_boundary) p.nve.img_first = estart + bargs.M;
         // several ranks: the epilogue writes the next step's refresh messages into the send staging (tables from the rebuild's
         // border kernel); bulk atoms have no entries, so with the bulk/border split only the border launch writes
         const bool mr_img_step = boundary_in_pair && !next_rebuild && nranks > 1 && mr_images_ready && stage_send == mr_img_stage;

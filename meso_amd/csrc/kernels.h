@@ -116,6 +116,7 @@ struct NveArgs {
     // one rank, small boxes: the atom also writes the merged pair of its periodic images (the per-step ghost refresh without a
     // k_pack_forward launch).  img_cnt[i] images, img[8 i + m] = destination index | direction << 26; null: disabled
     const int *img_cnt, *img;
+    const int *img_first;         // nullable, one rank: atoms in front of *img_first (the bulk section of the order) have no images - img_cnt is not read for them
     const double *img_shift;      // [27][3] period shifts
     // where the images go: the merged arrays of the next step (one rank, dest = ghost index) or - several ranks - the send staging of
     // the per-step ghost refresh (dest = slot of the coordinates, the velocities img_vofs[d] slots behind; img_center: the receiver's

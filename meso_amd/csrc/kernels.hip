@@ -122,7 +122,7 @@ NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, in
     nv.dtf = dtf; nv.dtv = dtv; nv.groupbit = groupbit; nv.merge = merge;
     nv.coord4_next = coord4_next; nv.veloc4_next = veloc4_next;
     nv.cx = cx; nv.cy = cy; nv.cz = cz; nv.seed_next = seed_next;
-    nv.img_cnt = nullptr; nv.img = nullptr; nv.img_shift = nullptr;
+    nv.img_cnt = nullptr; nv.img = nullptr; nv.img_first = nullptr; nv.img_shift = nullptr;
     nv.img_c4 = coord4_next; nv.img_v4 = veloc4_next; nv.img_vofs = nullptr; nv.img_center = nullptr;
     return nv;
 }

@@ -365,7 +365,7 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
         a.veloc4_next[i] = v;
         if (a.img_cnt && !a.img_center) {
             // the ghost refresh of step s+1 for my own periodic images (what k_pack_forward computes: same expression, same bits)
-            const int ni = min(a.img_cnt[i], 8);
+            const int ni = (a.img_first && i < *a.img_first) ? 0 : min(a.img_cnt[i], 8);
             for (int m = 0; m < ni; m++) {
                 const int e = a.img[(size_t)i * 8 + m];
                 const int d = e >> 26, dest = e & 0x03FFFFFF;
