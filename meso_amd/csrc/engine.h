@@ -264,6 +264,8 @@ private:
     double *e_pair = nullptr;
     double *xhold = nullptr;
     double *d_mass_type = nullptr, *d_coeff64 = nullptr;
+    double *d_dtfm_type = nullptr;  // 0.5 dt / mass per type (launch_dtfm_table) for the step-boundary epilogue; dtfm_for: the 0.5 dt it holds
+    double dtfm_for = -1.0;
     float *d_coeff32 = nullptr;
 
     // neighbour

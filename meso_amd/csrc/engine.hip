@@ -79,7 +79,7 @@ void Engine::free_all()
     for (int k = 0; k < 6; k++) dfree(virial[k]);
     dfree(d_bond_kr0); dfree(e_bond); dfree(bond_idx); dfree(tagmap); dfree(tagc); dfree(tagbits);
     dfree(d_angle_cf); dfree(e_angle); dfree(angle_idx);
-    dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
+    dfree(e_pair); dfree(xhold); dfree(d_mass_type); dfree(d_dtfm_type); dfree(d_coeff64); dfree(d_coeff32); dfree(d_poly); dfree(d_ftab);
     dfree(pair_count); dfree(pair_nback); dfree(pair_table); dfree(pair_back);
     dfree(bin_key); dfree(bin_key_alt); dfree(bin_val); dfree(bin_val_alt); dfree(img_cnt); dfree(img); dfree(d_shift27);
     dfree(rkey); dfree(rkey_alt); dfree(rval); dfree(rval_alt);
@@ -1025,10 +1025,12 @@ int Engine::init_params()
     for (int d = 0; d < 3; d++)
         if (periodic[d] && !(prd[d] > 2.0 * cutghost)) img_ok = false;
     // coefficient tables (prepare_coeff pair_dpd_meso.cu:68-89)
-    dfree(d_coeff64); dfree(d_coeff32); dfree(d_mass_type);
+    dfree(d_coeff64); dfree(d_coeff32); dfree(d_mass_type); dfree(d_dtfm_type);
+    dtfm_for = -1.0;
     HIPCHK(dalloc(d_coeff64, coeff.size()));
     HIPCHK(dalloc(d_coeff32, coeff.size()));
     HIPCHK(dalloc(d_mass_type, mass_type.size()));
+    HIPCHK(dalloc(d_dtfm_type, mass_type.size()));
     std::vector<float> c32(coeff.begin(), coeff.end());
     HIPCHK(hipMemcpy(d_coeff64, coeff.data(), coeff.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_coeff32, c32.data(), c32.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1940,7 +1942,11 @@ int Engine::run(int nsteps)
             p.nve = make_nve_args(cur, 0.5 * dt, dt, groupbit, next_rebuild ? 0 : 1, coord4_next, veloc4_next,
                                   0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
                                   premix_tea<64>((u32)seed, (u32)(ntimestep + 1)));
-        if (boundary_in_pair && lean_boundary) p.nve.mass_type = d_mass_type;      // (type from the merged record, mass per type, no mask of group "all")
+        if (boundary_in_pair && lean_boundary) {
+            // (type from the merged record, mass - as dtf / m, evaluated once per type - from the per-type table, no mask of group "all")
+            if (dtfm_for != 0.5 * dt) { launch_dtfm_table(d_mass_type, ntypes, 0.5 * dt, d_dtfm_type, stream); dtfm_for = 0.5 * dt; }
+            p.nve.mass_type = d_mass_type; p.nve.dtfm_type = lean_boundary == 2 ? nullptr : d_dtfm_type;      // (2: timing ablation, mass from the table and the reciprocal per atom)
+        }
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
         if (img_step) { p.nve.img_cnt = img_cnt; p.nve.img = img; p.nve.img_shift = d_shift27; }

@@ -44,6 +44,7 @@ void launch_pbc(const AtomSoA &a, const double *boxlo, const double *boxhi, cons
 void launch_copy_f4(const float4 *src, float4 *dst, size_t n, hipStream_t s);     // bandwidth probe (meso_membw_probe)
 void launch_fill_f64(double *p, double val, int n, hipStream_t s);
 void launch_fill_i32(int *p, int val, int n, hipStream_t s);
+void launch_dtfm_table(const double *mass_type, int ntypes, double dtf, double *dtfm_type, hipStream_t s);
 void launch_unpack_mass(const int *type, const double *mass_type, int ntypes, double *mass, int beg, int end,
                         hipStream_t s);
 void launch_max_disp2(const AtomSoA &a, const double *xhold, int n, int stride, double *partial, double *result,
@@ -107,6 +108,7 @@ struct NveArgs {
     const double *mass;
     const int *mask, *tag, *type;
     const double *mass_type;      // per-type masses [ntypes + 1] for callers that know the atom's type (nve_prefetch); null: per-atom reads
+    const double *dtfm_type;      // nullable: dtf / mass per type (launch_dtfm_table), so that no reciprocal sits on the path that ends every wave
     double dtf, dtv;
     int groupbit;
     int merge;

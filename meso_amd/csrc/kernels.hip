@@ -118,7 +118,7 @@ NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, in
     NveArgs nv;
     for (int d = 0; d < 3; d++) { nv.x[d] = a.x[d]; nv.v[d] = a.v[d]; }
     nv.mass = a.mass; nv.mask = a.mask; nv.tag = a.tag; nv.type = a.type;
-    nv.mass_type = nullptr;
+    nv.mass_type = nullptr; nv.dtfm_type = nullptr;
     nv.dtf = dtf; nv.dtv = dtv; nv.groupbit = groupbit; nv.merge = merge;
     nv.coord4_next = coord4_next; nv.veloc4_next = veloc4_next;
     nv.cx = cx; nv.cy = cy; nv.cz = cz; nv.seed_next = seed_next;
@@ -308,6 +308,16 @@ __global__ void __launch_bounds__(256) k_unpack_mass(const int *__restrict__ typ
 {
     for (int i = beg + blockDim.x * blockIdx.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x)
         mass[i] = mt[type[i]];
+}
+// dtf / m per type, with the expression of the step boundary (nve_boundary_atom: dtf * rcp_poly(m)) - the same bits, computed once
+__global__ void __launch_bounds__(64) k_dtfm_table(const double *__restrict__ mt, int ntypes, double dtf, double *__restrict__ out)
+{
+    const int t = threadIdx.x + blockIdx.x * blockDim.x;
+    if (t <= ntypes) out[t] = t > 0 ? dtf * rcp_poly(mt[t]) : 0.0;
+}
+void launch_dtfm_table(const double *mass_type, int ntypes, double dtf, double *dtfm_type, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dtfm_table, dim3((ntypes + 64) / 64), dim3(64), 0, s, mass_type, ntypes, dtf, dtfm_type);
 }
 void launch_unpack_mass(const int *type, const double *mass_type, int, double *mass, int beg, int end, hipStream_t s)
 {

@@ -323,7 +323,7 @@ __device__ inline double from_fixed36(u64 a) { return (double)(long long)a * (1.
 // and, when step s+1 keeps the neighbour table, gpu_merge_xvt for step s+1 (atom_vec_meso.cu:142-167).  One definition
 // for the stand-alone boundary kernel and for the force kernel's epilogue, so both produce the same bits.
 // (pre: the atom's state requested ahead of time by the caller - same values, same arithmetic)
-struct NvePre { double x, y, z, vx, vy, vz, mass; int mask, tag, type; };
+struct NvePre { double x, y, z, vx, vy, vz, dtfm; int mask, tag, type; };
 // (ty > 0: the caller knows the atom's type - the force kernel has it in the merged coordinate record - and, with a.mass_type set, the
 // mass comes from the per-type table [every atom's mass IS its type's, launch_unpack_mass] and the group mask is not read when the
 // group is "all" [bit 0 of every mask is set, group.cpp]: 16 of the 68 bytes the step boundary reads per atom stay where they are)
@@ -333,7 +333,8 @@ __device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p, int ty =
     p.vx = a.v[0][i]; p.vy = a.v[1][i]; p.vz = a.v[2][i];
     const bool lean = a.mass_type && ty > 0;
     p.type = lean ? ty : a.type[i];
-    p.mass = lean ? a.mass_type[ty] : a.mass[i];
+    // dtf / m: from the per-type table when there is one (k_dtfm_table: the same expression evaluated once per type), else here and now
+    p.dtfm = (lean && a.dtfm_type) ? a.dtfm_type[ty] : a.dtf * rcp_poly(lean ? a.mass_type[ty] : a.mass[i]);
     p.mask = (lean && a.groupbit == 1) ? 1 : a.mask[i];
     p.tag = a.tag[i];
 }
@@ -346,7 +347,7 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
     const bool lean = !pre && a.mass_type && ty > 0;
     const int type_i = pre ? pre->type : lean ? ty : a.type[i];
     if ((pre ? pre->mask : (lean && a.groupbit == 1) ? 1 : a.mask[i]) & a.groupbit) {
-        const double dtfm = a.dtf * rcp_poly(pre ? pre->mass : lean ? a.mass_type[ty] : a.mass[i]);
+        const double dtfm = pre ? pre->dtfm : (lean && a.dtfm_type) ? a.dtfm_type[ty] : a.dtf * rcp_poly(lean ? a.mass_type[ty] : a.mass[i]);
         vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // final_integrate, step s
         vx += dtfm * fx; vy += dtfm * fy; vz += dtfm * fz;       // initial_integrate, step s+1
         x += a.dtv * vx; y += a.dtv * vy; z += a.dtv * vz;

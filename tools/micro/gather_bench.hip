@@ -39,7 +39,13 @@ __global__ void __launch_bounds__(256) k_gather(const T *__restrict__ tab, u32 m
             else if (MODE == 3) j = ((__shfl(r, 0, 64) & mask) & ~63u) | lane;
             else if (MODE == 4) j = ((__shfl(r, lane & ~7u, 64) & mask) & ~31u) | ((r >> 20) & 31u);      // 8 lanes inside one 32-element window
             else if (MODE == 5) j = ((__shfl(r, lane & ~7u, 64) & mask) & ~15u) | ((r >> 20) & 15u);      // 8 lanes inside one 16-element window
-            else j = ((__shfl(r, lane & ~7u, 64) & mask) & ~7u) | ((r >> 20) & 7u);                       // 8 lanes inside one 8-element window (one 128-B line of b128)
+            else if (MODE == 6) j = ((__shfl(r, lane & ~7u, 64) & mask) & ~7u) | ((r >> 20) & 7u);        // 8 lanes inside one 8-element window (one 128-B line of b128)
+            else j = r & mask;
+            // MODE 7 / 8: random, 7 / 12 of every 16 lanes switched off (exec mask) - does a gather cost per instruction or per active lane?
+            if (MODE == 7 || MODE == 8) {
+                T z; for (int k = 0; k < (int)(sizeof(T) / 4); k++) ((u32 *)&z)[k] = 0;
+                v[q] = ((r >> 18) & 15u) >= (MODE == 7 ? 7u : 12u) ? t[j] : z;
+            } else
             v[q] = t[j];
         }
 #pragma unroll
@@ -138,6 +144,10 @@ int main()
     run<u32x4, 5>("global b128 8 lanes in a 16-elem window, 16 KiB", 1024, 1024, (const u32x4 *)tab, out);
     run<u32x4, 6>("global b128 8 lanes in an 8-elem window, 16 KiB", 1024, 1024, (const u32x4 *)tab, out);
     run<u32x4, 4>("global b128 8 lanes in a 32-elem window, 64 KiB", 4096, 4096, (const u32x4 *)tab, out);
+    run<u32x4, 7>("global b128 random, 7/16 lanes off, 16 KiB", 1024, 1024, (const u32x4 *)tab, out);
+    run<u32x4, 8>("global b128 random, 12/16 lanes off, 16 KiB", 1024, 1024, (const u32x4 *)tab, out);
+    run<u32x4, 7>("global b128 random, 7/16 lanes off, 64 KiB", 4096, 4096, (const u32x4 *)tab, out);
+    run<u32, 7>("global b32 random, 7/16 lanes off, 16 KiB", 4096, 4096, (const u32 *)tab, out);
     run<u32x2, 2>("global b64  lane quads adjacent, 16 KiB", 2048, 2048, (const u32x2 *)tab, out);
     run<u32x2, 3>("global b64  coalesced, 16 KiB", 2048, 2048, (const u32x2 *)tab, out);
     run<u32, 3>("global b32  coalesced, 16 KiB", 4096, 4096, (const u32 *)tab, out);
