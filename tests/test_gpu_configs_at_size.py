@@ -308,7 +308,10 @@ def test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows(style):
     from meso_amd.api import Meso
     x, v, lo, hi = make_box(64)
     res = []
-    for opts in ((("row_part", 1),), (("row_part", 0), ("xcd_balance", 0), ("ghost_epilogue", 0))):
+    # (third and fourth variant - the rebuild at this size, more than 4096 tiles of cells: the count kernel on its own instead of in
+    # the force kernel's epilogue, per-atom reads in the step boundary; the chain of small launches instead of the fused rebuild)
+    for opts in ((("row_part", 1),), (("row_part", 0), ("xcd_balance", 0), ("ghost_epilogue", 0)),
+                 (("row_part", 1), ("fuse_count", 0), ("lean_boundary", 0)), (("row_part", 1), ("fused_rebuild", 0))):
         with Meso() as m:
             for k, val in opts:
                 m.set_option(k, val)
@@ -324,5 +327,6 @@ def test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows(style):
             f0 = m.gather()[2]
             m.run(12)
             res.append((f0,) + tuple(m.gather()[:3]))
-    for a, b in zip(*res):
-        assert np.array_equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
