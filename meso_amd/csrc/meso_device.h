@@ -16,6 +16,32 @@
 namespace meso {
 
 typedef uint32_t u32;
+
+// Kernel arguments live in device memory, cold in every cache when a kernel starts; the compiler loads them where they are first needed,
+// in stages that depend on each other through the control flow (the ring kernel: five stages, ~0.6 us each, in front of its first vector
+// load).  One scalar load per 64-byte line at the top of the kernel brings the whole block into the scalar cache in ONE round trip.
+#ifndef MESO_KA_PREFETCH
+#define MESO_KA_PREFETCH 1
+#endif
+#define MESO_KA_LINE(n) ".if %c2 > " #n "\n\ts_load_dword %0, %1, 64*" #n "\n\t.endif\n\t"
+template <int BYTES> __device__ inline void prefetch_kernargs()
+{
+    if (!MESO_KA_PREFETCH) return;
+    static_assert(BYTES <= 40 * 64, "kernel argument block of at most 40 lines");
+    // (ONE asm statement: every request is out before the wait, and nothing of it is in flight when the compiler's code goes on -
+    // it does not know that the statement loads, so a result register must not be pending behind it)
+    const char __attribute__((address_space(4))) *ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    u32 t;
+    asm volatile("s_load_dword %0, %1, 0\n\t"
+                 MESO_KA_LINE(1) MESO_KA_LINE(2) MESO_KA_LINE(3) MESO_KA_LINE(4) MESO_KA_LINE(5) MESO_KA_LINE(6) MESO_KA_LINE(7)
+                 MESO_KA_LINE(8) MESO_KA_LINE(9) MESO_KA_LINE(10) MESO_KA_LINE(11) MESO_KA_LINE(12) MESO_KA_LINE(13) MESO_KA_LINE(14)
+                 MESO_KA_LINE(15) MESO_KA_LINE(16) MESO_KA_LINE(17) MESO_KA_LINE(18) MESO_KA_LINE(19) MESO_KA_LINE(20) MESO_KA_LINE(21)
+                 MESO_KA_LINE(22) MESO_KA_LINE(23) MESO_KA_LINE(24) MESO_KA_LINE(25) MESO_KA_LINE(26) MESO_KA_LINE(27) MESO_KA_LINE(28)
+                 MESO_KA_LINE(29) MESO_KA_LINE(30) MESO_KA_LINE(31) MESO_KA_LINE(32) MESO_KA_LINE(33) MESO_KA_LINE(34) MESO_KA_LINE(35)
+                 MESO_KA_LINE(36) MESO_KA_LINE(37) MESO_KA_LINE(38) MESO_KA_LINE(39)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t) : "s"(ka), "i"((BYTES + 63) / 64) : "memory");
+}
 typedef unsigned long long u64;
 
 #define MESO_WAVE 64

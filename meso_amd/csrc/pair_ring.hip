@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
 #endif
     k_pair_dpd_ring(PairArgs a)
 {
+    prefetch_kernargs<sizeof(PairArgs)>();
     // (no contraction left to the compiler: the pair evaluation is inlined at every drain point of the light phase, and copies that
     // fuse different multiply-adds would give one pair two forces that differ in the last bit, depending on which copy - and, for a
     // pair evaluated from both sides, which side - got it.  The fused operations of the fp32 style are written out below.)
