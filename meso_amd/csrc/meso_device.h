@@ -350,6 +350,17 @@ __device__ inline double from_fixed36(u64 a) { return (double)(long long)a * (1.
 // for the stand-alone boundary kernel and for the force kernel's epilogue, so both produce the same bits.
 // (pre: the atom's state requested ahead of time by the caller - same values, same arithmetic)
 struct NvePre { double x, y, z, vx, vy, vz, dtfm; int mask, tag, type; };
+// the atom's periodic images (one rank): their number and the first four table entries, requested ahead like NvePre (a face atom has
+// one image, an edge atom three: the dependent pair of loads - count, then entries - otherwise ends the kernel's border waves)
+struct NveImgPre { int ni; int4 e; };
+__device__ inline void nve_prefetch_images(const NveArgs &a, int i, NveImgPre &p)
+{
+    p.ni = 0; p.e = make_int4(0, 0, 0, 0);
+    if (a.img_cnt && !a.img_center && !(a.img_first && i < *a.img_first)) {
+        p.ni = a.img_cnt[i];
+        p.e = *reinterpret_cast<const int4 *>(a.img + (size_t)i * 8);
+    }
+}
 // (ty > 0: the caller knows the atom's type - the force kernel has it in the merged coordinate record - and, with a.mass_type set, the
 // mass comes from the per-type table [every atom's mass IS its type's, launch_unpack_mass] and the group mask is not read when the
 // group is "all" [bit 0 of every mask is set, group.cpp]: 16 of the 68 bytes the step boundary reads per atom stay where they are)
@@ -366,7 +377,7 @@ __device__ inline void nve_prefetch(const NveArgs &a, int i, NvePre &p, int ty =
 }
 // (xo, yo, zo: the atom's position after the step boundary)
 __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, double fy, double fz, const NvePre *pre, double &xo, double &yo, double &zo,
-                                         int ty = 0)
+                                         int ty = 0, const NveImgPre *ipre = nullptr)
 {
     double x = pre ? pre->x : a.x[0][i], y = pre ? pre->y : a.x[1][i], z = pre ? pre->z : a.x[2][i];
     double vx = pre ? pre->vx : a.v[0][i], vy = pre ? pre->vy : a.v[1][i], vz = pre ? pre->vz : a.v[2][i];
@@ -392,9 +403,9 @@ __device__ inline void nve_boundary_atom(const NveArgs &a, int i, double fx, dou
         a.veloc4_next[i] = v;
         if (a.img_cnt && !a.img_center) {
             // the ghost refresh of step s+1 for my own periodic images (what k_pack_forward computes: same expression, same bits)
-            const int ni = (a.img_first && i < *a.img_first) ? 0 : min(a.img_cnt[i], 8);
+            const int ni = ipre ? min(ipre->ni, 8) : (a.img_first && i < *a.img_first) ? 0 : min(a.img_cnt[i], 8);
             for (int m = 0; m < ni; m++) {
-                const int e = a.img[(size_t)i * 8 + m];
+                const int e = (ipre && m < 4) ? (m == 0 ? ipre->e.x : m == 1 ? ipre->e.y : m == 2 ? ipre->e.z : ipre->e.w) : a.img[(size_t)i * 8 + m];
                 const int d = e >> 26, dest = e & 0x03FFFFFF;
                 float4 g;
                 g.x = (float)((x + a.img_shift[3 * d]) - a.cx);

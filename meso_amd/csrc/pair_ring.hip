@@ -453,6 +453,11 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     // the wave waits for the other waves of its workgroup)
     constexpr bool LATE = RG_LATE_PRE && !PRE;
     if (LATE && a.fuse_nve && mine && part == 0) nve_prefetch(a.nve, i, npre, (int)__float_as_uint(c1.w) + 1);
+#ifndef RG_IMG_PRE
+#define RG_IMG_PRE 1
+#endif
+    NveImgPre ipre;
+    if (RG_IMG_PRE && a.fuse_nve && mine && part == 0) nve_prefetch_images(a.nve, i, ipre);
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
     double xn0 = 0.0, xn1 = 0.0, xn2 = 0.0;       // the atom's position after the step boundary (for the rebuild's count below)
     if (mine && part == 0) {
@@ -476,8 +481,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
                     fx += bx; fy += by; fz += bz;
                 }
             }
-            if (PRE || LATE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre, xn0, xn1, xn2);
-            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, xn0, xn1, xn2, (int)__float_as_uint(c1.w) + 1);
+            if (PRE || LATE) nve_boundary_atom(a.nve, i, fx, fy, fz, &npre, xn0, xn1, xn2, 0, RG_IMG_PRE ? &ipre : nullptr);
+            else nve_boundary_atom(a.nve, i, fx, fy, fz, nullptr, xn0, xn1, xn2, (int)__float_as_uint(c1.w) + 1, RG_IMG_PRE ? &ipre : nullptr);
         } else if (a.accumulate) { a.f[0][i] += fx; a.f[1][i] += fy; a.f[2][i] += fz; }
         else { a.f[0][i] = fx; a.f[1][i] = fy; a.f[2][i] = fz; }
     }
