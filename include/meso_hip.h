@@ -71,7 +71,7 @@ int meso_device_sync(meso_ctx *ctx);
  *                    decided per entry and step from the two indices (round-4 form; bit-identical forces).  -1 = two sections when
  *                    they pay: rebuild interval of at least 4 steps (fp32 styles) / 2 steps (dpd/meso), or neigh_modify check yes
  *   split_gather -1  one rank: the rebuild's placing kernel only orders and a streaming pass moves the payload
- *                    (-1 = boxes of at least 200 000 local atoms, 0 off, 1 on)
+ *                    (-1 = boxes of at least 50 000 local atoms (25^3: +2-3 %, 32^3: the same, larger: faster), 0 off, 1 on)
  *   ghost_epilogue -1  one rank: the step-boundary epilogue of the force kernel also writes the merged pairs of each atom's periodic
  *                    images (no k_pack_forward launch between rebuilds); -1 = on (without xcd_balance: up to 524 288 local atoms), 0 off, 1 on
  *   overlap_rebuild 0  with async_counts: 1 = reorder of the locals on the main stream, border lists + ghost creation + ghost

@@ -1275,7 +1275,7 @@ void Engine::fused_locals_args(FusedArgs &a)
     a.estart = estart;
     a.perm = rval;
     // large boxes: order first, then a streaming gather (64^3: the fused form moves its 190 MB at 2.4 TB/s, a streaming pass at 5)
-    a.split_gather = (nranks == 1 && (split_gather == 1 || (split_gather < 0 && nlocal >= 200000))) ? 1 : 0;
+    a.split_gather = (nranks == 1 && (split_gather == 1 || (split_gather < 0 && nlocal >= 50000))) ? 1 : 0;
     a.scratch = fr_scratch;
     a.lds_cap = reorder_cap;
     a.mg.coord4 = coord4; a.mg.veloc4 = veloc4;

@@ -692,7 +692,7 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
                  (("async_grid_scale", 0.05), ("fused_rebuild", 0)), (("overlap_rebuild", 1), ("async_grid_scale", 0.05)),
                  (("ghost_epilogue", 0),), (("ghost_epilogue", 0), ("fused_rebuild", 0)), (("ghost_epilogue", 1), ("async_counts", 0)),
                  (("fused_cap", 2),), (("fused_cap", 2), ("reorder_cap", 64), ("ghost_epilogue", 0)),
-                 # split_gather: the placing kernel only orders, a streaming pass moves the payload (default from 200 000 local atoms on)
+                 # split_gather: the placing kernel only orders, a streaming pass moves the payload (default from 50 000 local atoms on)
                  (("split_gather", 1),), (("split_gather", 1), ("fused_cap", 2), ("ghost_epilogue", 0)), (("split_gather", 0),),
                  # check_launches: every stage of a rebuild synchronised and asked for HIP errors (debugging option)
                  (("check_launches", 1),), (("check_launches", 1), ("fused_rebuild", 0)),
