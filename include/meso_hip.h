@@ -79,6 +79,9 @@ int meso_device_sync(meso_ctx *ctx);
  *                    same neighbour sets and forces, measured 4-7 % slower at every size; test_rebuild_variants_give_the_same_trajectory)
  *   fuse_count    1  one rank: on the step in front of a rebuild the force kernel's step-boundary epilogue also runs the rebuild's first
  *                    kernel (wrap, cell code, rank inside the cell, bucket entry: k_fr_count) over the positions it has just written
+ *   merge_ghosts  1  one rank, with split_gather: the ghost tiles of a rebuild run in the launch of its gather (they read the old order
+ *                    through the permutation; the count books every border atom's periodic images): one launch less, the ghost
+ *                    tiles' latency chains under the stream (test_rebuild_variants_give_the_same_trajectory)
  *   lean_boundary 1  the force kernel's step-boundary epilogue takes the atom's type from the merged coordinate record it holds and the mass
  *                    from the per-type table, and skips the mask of group "all" (16 bytes per atom less to read); 0 = per-atom arrays
  *                    (test_rebuild_variants_give_the_same_trajectory)

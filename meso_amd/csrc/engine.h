@@ -341,6 +341,7 @@ private:
     int mr_gcnt_n = 0;
     int brick2_floor = 0;           // the 2-brick's LDS stage (atoms) after it grew during the run
     // partitioned rows (RowPartArgs, kernels.h): the list builder decides the Newton pairing of in-group pairs once per rebuild
+    int merge_ghosts = 1;           // option: one rank, split_gather: the ghost tiles run in the gather's launch (k_fr_gather_ghosts)
     int lean_boundary = 1;          // option: the force kernel's step-boundary epilogue takes type and mass from what it holds (NveArgs::mass_type)
     int fuse_count = 1;             // option: the rebuild's count kernel runs in the epilogue of the force launch in front of the rebuild
     bool count_in_epilogue = false; // ... and has done so for the rebuild that follows
@@ -361,7 +362,7 @@ private:
     bool fused_dirty = false;       // a fused rebuild failed half-way: counters are cleared before the next one
     bool fused_ok() const;
     int rebuild_fused();
-    void fused_locals_args(FusedArgs &a);
+    void fused_locals_args(FusedArgs &a, bool ghost_stage = false);      // ghost_stage: the one-rank ghost stage follows - the count books the images
     int fused_alloc();
     unsigned long long *fr_bucket = nullptr, *fr_ovf = nullptr;
     int *fr_novf = nullptr, *fr_ttot[2] = {nullptr, nullptr}, *fr_stot[2] = {nullptr, nullptr};

@@ -321,6 +321,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "xcd_balance") { xcd_balance = (int)val; return 0; }
     if (key == "fuse_count") { fuse_count = (int)val; return 0; }
     if (key == "lean_boundary") { lean_boundary = (int)val; return 0; }
+    if (key == "merge_ghosts") { merge_ghosts = (int)val; return 0; }
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
@@ -1252,7 +1253,7 @@ int Engine::fused_alloc()
 }
 
 // arguments of the count + place kernels (the locals' half of the fused rebuild)
-void Engine::fused_locals_args(FusedArgs &a)
+void Engine::fused_locals_args(FusedArgs &a, bool ghost_stage)
 {
     memset(&a, 0, sizeof a);
     a.src = cur; a.dst = alt;
@@ -1273,6 +1274,15 @@ void Engine::fused_locals_args(FusedArgs &a)
     a.ttot = fr_ttot[par]; a.ttot_next = fr_ttot[par ^ 1];
     a.stot = 2 * bargs.M / fused_tile_codes() > fused_direct_tiles() ? fr_stot[0] : nullptr;
     a.estart = estart;
+    if (ghost_stage) {
+        // one rank: the count books every border atom's periodic images per tile of ghost cells (k_fr_ghosts then needs nothing
+        // from the gather: the two run as one launch)
+        a.gttot = fr_gttot[par];
+        a.dir_mask = 0;
+        for (int d = 0; d < 27; d++)
+            if (d != 13 && send_active[d]) a.dir_mask |= 1u << d;
+        a.img_booked = 1;
+    }
     a.perm = rval;
     // large boxes: order first, then a streaming gather (64^3: the fused form moves its 190 MB at 2.4 TB/s, a streaming pass at 5)
     a.split_gather = (nranks == 1 && (split_gather == 1 || (split_gather < 0 && nlocal >= 50000))) ? 1 : 0;
@@ -1307,7 +1317,7 @@ int Engine::rebuild_fused()
     TRY(fused_alloc());
     if (!h_flags_dev) HIPCHK(hipHostGetDevicePointer((void **)&h_flags_dev, h_flags, 0));
     FusedArgs a;
-    fused_locals_args(a);
+    fused_locals_args(a, true);
     const int par = (int)(fr_epoch & 1u);
     a.gttot = fr_gttot[par]; a.gttot_next = fr_gttot[par ^ 1];
     // (the separate plan kernel - option tile_plan, and rows narrower than 64 entries, whose stage cannot lend the inline plan its
@@ -1329,6 +1339,7 @@ int Engine::rebuild_fused()
     a.ghost_cap = std::min(nmax - nlocal - 1, send_cap);
     a.dir_start = d_dir_start;
     a.report = h_flags_dev;
+    a.merged_ghosts = merge_ghosts ? 1 : 0;      // (honoured with the order-only placing kernel: launch_fused_rebuild)
     launch_fused_rebuild(a, stream, count_in_epilogue);
     count_in_epilogue = false;
     std::swap(cur, alt);
@@ -1851,7 +1862,7 @@ int Engine::prepare_count_in_epilogue(FrCountArgs &c, bool &ok)
     TRY(fused_alloc());
     wrap_in_reorder = true;
     FusedArgs a;
-    fused_locals_args(a);
+    fused_locals_args(a, true);
     c = fused_count_args(a);
     ok = true;
     return 0;

@@ -147,6 +147,8 @@ struct FrCountArgs {
     unsigned long long *bucket, *ovf;
     int *novf, ovf_cap;
     int *ttot;                 // atoms per tile of 64 codes
+    int *gttot;                // nullable (one rank): ghosts per tile of 32 ghost cells - every periodic image of a border atom is booked here
+    unsigned dir_mask;         // directions that have a receiver
     int *flags;
 };
 

@@ -571,12 +571,53 @@ __device__ inline void wave_group_add(u32 group, bool valid, int *__restrict__ t
     }
 }
 
+// Bit d of the result: the atom has a periodic image in direction d = (sx+1) + 3 (sy+1) + 9 (sz+1).  fl: near_flags of its
+// coordinate; (bx, by, bz): its cell.  An image sent up (s = +1) comes from the last cell below the high face, one sent down
+// from the first cell above the low face (an atom ON the slab plane of a box whose cells are exactly one ghost cutoff wide can
+// sit in the cell next to it: not an image for any kernel here - they all use this function).
+__device__ inline u32 image_mask(int fl, int bx, int by, int bz, const int *mbin, u32 dir_mask)
+{
+    const u32 mx = 2u | ((fl & 1) && bx == 1 ? 1u : 0u) | ((fl & 2) && bx == mbin[0] - 2 ? 4u : 0u);
+    const u32 my = 2u | ((fl & 4) && by == 1 ? 1u : 0u) | ((fl & 8) && by == mbin[1] - 2 ? 4u : 0u);
+    const u32 mz = 2u | ((fl & 16) && bz == 1 ? 1u : 0u) | ((fl & 32) && bz == mbin[2] - 2 ? 4u : 0u);
+    u32 row = 0;                                   // 9 bits: (sx, sy)
+#pragma unroll
+    for (int k = 0; k < 3; k++) row |= ((my >> k) & 1u) ? mx << (3 * k) : 0u;
+    u32 m = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) m |= ((mz >> k) & 1u) ? row << (9 * k) : 0u;
+    return m & ~(1u << 13) & dir_mask;
+}
+
+// The periodic images of a wave's border atoms booked per tile of FR_COUNT_GTILE ghost cells (k_fr_ghosts PULLS the ghosts of a ghost
+// cell from the cell they are images of, so all it needs beforehand is the number of ghosts per tile: its first slot is the sum of the
+// totals in front of it).  emask: image_mask of the lane's atom (0: none); (bx, by, bz): its cell.  The ghost cell of an image is the
+// geometric image of the atom's own cell.  No returning atomics: nothing waits.  Every lane of the wave calls.
+#define FR_COUNT_GTILE 32
+__device__ inline void book_images(u32 emask, int bx, int by, int bz, const int *mbin, int *__restrict__ gttot)
+{
+    u32 any = emask;                  // directions some lane of the wave has an image in
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) any |= (u32)__shfl_xor((int)any, o, 64);
+    any = (u32)__builtin_amdgcn_readfirstlane((int)any);
+    while (any) {
+        const int dir = __builtin_ctz(any);
+        any &= any - 1u;
+        const bool em = (emask >> dir) & 1u;
+        const int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
+        const u32 gc = interleave3((u32)(sx == 0 ? bx : (sx > 0 ? 0 : mbin[0] - 1)), (u32)(sy == 0 ? by : (sy > 0 ? 0 : mbin[1] - 1)),
+                                   (u32)(sz == 0 ? bz : (sz > 0 ? 0 : mbin[2] - 1)));
+        wave_group_add(em ? gc / FR_COUNT_GTILE : 0u, em, gttot);
+    }
+}
+
 // one atom of the rebuild's count (FrCountArgs, kernels.h): every lane of the wave calls (valid: the lane holds an atom to count),
 // (cx, cy, cz) = the atom's position.  FR_COUNT_TILE codes per tile of the placing kernel (rebuild.hip)
 #define FR_COUNT_TILE 64
 __device__ inline void fr_count_atom(const FrCountArgs &a, int i, bool valid, double cx, double cy, double cz)
 {
-    u32 e = 0, key = 0;
+    u32 e = 0, key = 0, emask = 0;
+    int cell[3] = {0, 0, 0};
     if (valid) {
         double c[3] = {cx, cy, cz};
         if (a.wrap) {
@@ -607,10 +648,13 @@ __device__ inline void fr_count_atom(const FrCountArgs &a, int i, bool valid, do
         const bool border = c[0] <= a.sl_lo[0] || c[0] >= a.sl_hi[0] || c[1] <= a.sl_lo[1] || c[1] >= a.sl_hi[1] || c[2] <= a.sl_lo[2] ||
                             c[2] >= a.sl_hi[2];
         if (border) e += (u32)a.M;
+        cell[0] = (int)b[0]; cell[1] = (int)b[1]; cell[2] = (int)b[2];
+        if (border && a.gttot) emask = image_mask(near_flags(c[0], c[1], c[2], a.sl_lo, a.sl_hi), cell[0], cell[1], cell[2], a.g.mbin, a.dir_mask);
     }
     // rank inside the code, one atomic per run of equal codes; tile totals: one atomic per tile and wave
     const int rank = run_rank(e, valid, a.cnt);
     wave_group_add(e / FR_COUNT_TILE, valid, a.ttot);
+    if (a.gttot) book_images(emask, cell[0], cell[1], cell[2], a.g.mbin, a.gttot);
     if (!valid) return;
     // (sub-cell key, old index) travels as one word: the placing kernel orders a cell without touching the coordinates
     const unsigned long long ent = ((unsigned long long)key << 32) | (u32)i;
@@ -678,6 +722,8 @@ struct FusedArgs {
     MergeOut mg;               // merged pairs of the new order (+ the ghosts'), image counters cleared
     // ghosts (gttot null: no ghost stage - several ranks create their ghosts by exchange): ghosts per tile of 64 ghost cells
     int *gttot, *gttot_next, *gstot;
+    int img_booked;            // the count booked the periodic images (gttot): the placing / gathering kernels do not
+    int merged_ghosts;         // the ghost tiles run in the gather's launch (k_fr_gather_ghosts): set by launch_fused_rebuild's caller
     unsigned dir_mask;         // bit d: direction d is a periodic image direction of this rank
     int *gstart;               // out [M+1]
     int *gcnt_out;             // out, nullable: ghosts per cell [M]; with it only the tiles listed in gorder run

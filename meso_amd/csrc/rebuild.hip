@@ -42,6 +42,7 @@ namespace meso {
 #ifndef FR_GTILE
 #define FR_GTILE 32           // ghost cells per tile of k_fr_ghosts (<= 64)
 #endif
+static_assert(FR_GTILE == FR_COUNT_GTILE, "ghost tile of the count's image booking (meso_device.h) and of k_fr_ghosts");
 #define FR_SUPER 256          // tiles per supertile
 #define FR_THREADS 256       // k_fr_ghosts, k_fr_super
 #ifndef FR_PLACE_THREADS
@@ -59,24 +60,6 @@ __device__ inline u32 compact3(u32 x)      // inverse of bit_space3: every third
     x = (x ^ (x >> 8)) & 0xff0000ff;
     x = (x ^ (x >> 16)) & 0x000003ff;
     return x;
-}
-
-// Bit d of the result: the atom has a periodic image in direction d = (sx+1) + 3 (sy+1) + 9 (sz+1).  fl: near_flags of its
-// coordinate; (bx, by, bz): its cell.  An image sent up (s = +1) comes from the last cell below the high face, one sent down
-// from the first cell above the low face (an atom ON the slab plane of a box whose cells are exactly one ghost cutoff wide can
-// sit in the cell next to it: not an image for any kernel here - they all use this function).
-__device__ inline u32 image_mask(int fl, int bx, int by, int bz, const int *mbin, u32 dir_mask)
-{
-    const u32 mx = 2u | ((fl & 1) && bx == 1 ? 1u : 0u) | ((fl & 2) && bx == mbin[0] - 2 ? 4u : 0u);
-    const u32 my = 2u | ((fl & 4) && by == 1 ? 1u : 0u) | ((fl & 8) && by == mbin[1] - 2 ? 4u : 0u);
-    const u32 mz = 2u | ((fl & 16) && bz == 1 ? 1u : 0u) | ((fl & 32) && bz == mbin[2] - 2 ? 4u : 0u);
-    u32 row = 0;                                   // 9 bits: (sx, sy)
-#pragma unroll
-    for (int k = 0; k < 3; k++) row |= ((my >> k) & 1u) ? mx << (3 * k) : 0u;
-    u32 m = 0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) m |= ((mz >> k) & 1u) ? row << (9 * k) : 0u;
-    return m & ~(1u << 13) & dir_mask;
 }
 
 __device__ inline int fr_block_sum(int v, int *wsum)
@@ -109,6 +92,7 @@ FrCountArgs fused_count_args(const FusedArgs &a)
     c.cnt = a.cnt; c.cap = a.cap;
     c.bucket = a.bucket; c.ovf = a.ovf; c.novf = a.novf; c.ovf_cap = a.ovf_cap;
     c.ttot = a.ttot;
+    c.gttot = a.img_booked ? a.gttot : nullptr; c.dir_mask = a.dir_mask;
     c.flags = a.flags;
     return c;
 }
@@ -271,7 +255,10 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_
             if (!GATHER) {
 #pragma unroll
                 for (int u = 0; u < FR_U; u++)
-                    if (jj[u] >= 0) a.perm[nn[u]] = jj[u];
+                    if (jj[u] >= 0) {
+                        a.perm[nn[u]] = jj[u];
+                        if (a.merged_ghosts && border_tile && a.mg.zero) a.mg.zero[nn[u]] = 0;      // (see fr_gather_block)
+                    }
                 continue;
             }
 #pragma unroll
@@ -312,11 +299,8 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_
                 }
                 if (a.perm) a.perm[n] = j;
             }
-            if (border_tile && a.gttot) {
-                // periodic images of a border atom: k_fr_ghosts PULLS the ghosts of a ghost cell from the cell they are images of,
-                // so all that is needed here is the number of ghosts per tile of ghost cells (its first slot is the sum of the
-                // totals in front of it).  The ghost cell of an image is the geometric image of the atom's own cell.  No returning
-                // atomics: nothing waits (a chain of rank atomics, one per direction, cost 25-40 us here)
+            if (border_tile && a.gttot && !a.img_booked) {
+                // periodic images of a border atom, booked per tile of ghost cells (book_images, meso_device.h) - unless the count did
 #pragma unroll
                 for (int u = 0; u < FR_U; u++) {
                     if (__ballot(jj[u] >= 0) == 0ull) continue;
@@ -324,19 +308,7 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_
                     const u32 lc = (u32)(code0 - a.M) + (u32)cc[u];           // Morton code of the atom's cell
                     const int bx = (int)compact3(lc), by = (int)compact3(lc >> 1), bz = (int)compact3(lc >> 2);
                     if (jj[u] >= 0) emask = image_mask(near_flags(X[u][0], X[u][1], X[u][2], a.sl.lo, a.sl.hi), bx, by, bz, a.g.mbin, a.dir_mask);
-                    u32 any = emask;                  // directions some lane of the wave has an image in
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) any |= (u32)__shfl_xor((int)any, o, 64);
-                    any = (u32)__builtin_amdgcn_readfirstlane((int)any);
-                    while (any) {
-                        const int dir = __builtin_ctz(any);
-                        any &= any - 1u;
-                        const bool em = (emask >> dir) & 1u;
-                        const int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
-                        const u32 gc = interleave3((u32)(sx == 0 ? bx : (sx > 0 ? 0 : a.g.mbin[0] - 1)), (u32)(sy == 0 ? by : (sy > 0 ? 0 : a.g.mbin[1] - 1)),
-                                                   (u32)(sz == 0 ? bz : (sz > 0 ? 0 : a.g.mbin[2] - 1)));
-                        wave_group_add(em ? gc / FR_GTILE : 0u, em, a.gttot);
-                    }
+                    book_images(emask, bx, by, bz, a.g.mbin, a.gttot);
                 }
             }
         }
@@ -348,9 +320,9 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_
 // 2b: the payload of the order-only form: atom perm[n] of the old order becomes atom n of the new one (lane = n; gpu_permute_copy,
 // atom_vec_meso.h:11-67, with gpu_merge_xvt folded in), border atoms book their periodic images per tile of ghost cells exactly as
 // the fused form does (the cell from the coordinate, as k_fr_count computed it)
-__global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a)
+__device__ __forceinline__ void fr_gather_block(const FusedArgs &a, const int bidx)
 {
-    const int n = blockDim.x * blockIdx.x + threadIdx.x;
+    const int n = (int)blockDim.x * bidx + (int)threadIdx.x;
     const bool valid = n < a.n;
     double X[3] = {0.0, 0.0, 0.0};
     if (valid) {
@@ -363,7 +335,8 @@ __global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a)
         }
         const int TG = a.src.tag[j], TY = a.src.type[j], MK = a.src.mask[j], IM = a.src.image[j];
         const double MS = a.src.mass[j];
-        if (a.mg.zero) a.mg.zero[n] = 0;
+        // (ghost tiles of the same launch write the counters of border atoms: those were cleared by the ordering kernel)
+        if (a.mg.zero && !(a.merged_ghosts && n >= a.estart[a.M])) a.mg.zero[n] = 0;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             a.dst.x[d][n] = X[d]; a.dst.v[d][n] = V[d];
@@ -378,7 +351,7 @@ __global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a)
         a.mg.veloc4[n] = v;
         a.dst.tag[n] = TG; a.dst.type[n] = TY; a.dst.mask[n] = MK; a.dst.image[n] = IM; a.dst.mass[n] = MS;
     }
-    if (!a.gttot) return;
+    if (!a.gttot || a.img_booked) return;
     // (whole waves: the image counting is a wave-level operation; the border section starts at estart[M], written by the ordering kernel)
     const int nb = a.estart[a.M];
     const bool bord = valid && n >= nb;
@@ -391,25 +364,18 @@ __global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a)
         bz = clampi((int)((X[2] - a.g.lo[2]) * a.g.bininv[2] + 1), 0, a.g.mbin[2]);
         emask = image_mask(near_flags(X[0], X[1], X[2], a.sl.lo, a.sl.hi), bx, by, bz, a.g.mbin, a.dir_mask);
     }
-    u32 any = emask;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) any |= (u32)__shfl_xor((int)any, o, 64);
-    any = (u32)__builtin_amdgcn_readfirstlane((int)any);
-    while (any) {
-        const int dir = __builtin_ctz(any);
-        any &= any - 1u;
-        const bool em = (emask >> dir) & 1u;
-        const int sx = dir % 3 - 1, sy = (dir / 3) % 3 - 1, sz = dir / 9 - 1;
-        const u32 gc = interleave3((u32)(sx == 0 ? bx : (sx > 0 ? 0 : a.g.mbin[0] - 1)), (u32)(sy == 0 ? by : (sy > 0 ? 0 : a.g.mbin[1] - 1)),
-                                   (u32)(sz == 0 ? bz : (sz > 0 ? 0 : a.g.mbin[2] - 1)));
-        wave_group_add(em ? gc / FR_GTILE : 0u, em, a.gttot);
-    }
+    book_images(emask, bx, by, bz, a.g.mbin, a.gttot);
 }
+
+__global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a) { fr_gather_block(a, (int)blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 3: ghosts
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
+// (bidx: the tile's place in the launch; via_perm: the gather of this rebuild runs in the SAME launch - the atoms a ghost is an image
+// of are read from the old order through the permutation the ordering kernel wrote)
+template <bool VIA_PERM>
+__device__ __forceinline__ void fr_ghosts_tile(const FusedArgs &a, const int bidx)
 {
     extern __shared__ unsigned char fr_em[];      // per candidate of the pass: 1 = becomes a ghost of this cell
     __shared__ int cstart[FR_GTILE + 1];           // candidates (atoms of the source cell) in front of each of my cells
@@ -420,7 +386,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
     __shared__ int wsum[FR_THREADS / 64];
     // (gorder: only the tiles that hold ghost cells run - nine tenths of the tiles of a large box are interior; the list builder
     // then takes a cell's ghosts from (gstart, gcnt) of ghost cells only)
-    const int t = a.gorder ? a.gorder[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
+    const int t = a.gorder ? a.gorder[bidx] : bidx, tid = threadIdx.x;
     const int ntiles = a.M / FR_GTILE;
     const int code0 = t * FR_GTILE;
     int nc = 0;
@@ -448,7 +414,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
         src0[tid] = first; sdir[tid] = dir; scell[tid] = sb[0] | (sb[1] << 10) | (sb[2] << 20);
     }
     const int base = fr_tile_base(a.gttot, a.gstot, t, wsum);
-    if (blockIdx.x == 0) {
+    if (bidx == 0) {
         // the rebuild's counts, reported by the tile that starts first: on the device for the kernels that follow, in pinned host
         // memory for the engine (four words: every store to host memory is a trip over the host link)
         int part = 0;
@@ -500,7 +466,9 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
                 if (cstart[mid] <= s0 + p) lo = mid; else hi = mid;
             }
             const int j = src0[lo] + (s0 + p - cstart[lo]);
-            const int fl = near_flags(a.dst.x[0][j], a.dst.x[1][j], a.dst.x[2][j], a.sl.lo, a.sl.hi);
+            const int jo = VIA_PERM ? a.perm[j] : j;
+            const AtomSoA &from = VIA_PERM ? a.src : a.dst;
+            const int fl = near_flags(from.x[0][jo], from.x[1][jo], from.x[2][jo], a.sl.lo, a.sl.hi);
             const bool em = fl && in_dir(fl, sdir[lo]);
             fr_em[p] = em ? 1 : 0;
             if (em) atomicAdd(&gl[lo], 1);        // (LDS)
@@ -546,7 +514,9 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
                     if (cstart[mid] <= s0 + p) lo = mid; else hi = mid;
                 }
                 const int j = src0[lo] + (s0 + p - cstart[lo]);
-                const int fl = near_flags(a.dst.x[0][j], a.dst.x[1][j], a.dst.x[2][j], a.sl.lo, a.sl.hi);
+                const int jo = VIA_PERM ? a.perm[j] : j;
+                const AtomSoA &from = VIA_PERM ? a.src : a.dst;
+                const int fl = near_flags(from.x[0][jo], from.x[1][jo], from.x[2][jo], a.sl.lo, a.sl.hi);
                 fr_em[p] = (fl && in_dir(fl, sdir[lo])) ? 1 : 0;
             }
             __syncthreads();
@@ -566,16 +536,18 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
             const int j = src0[lo] + (p - q0), d = sdir[lo];
             const int gi = a.n + k;
             // pack_border_vel (atom_vec_dpd_atomic_meso.cu:61-135): x + shift, tag, type, mask
-            const double xj = a.dst.x[0][j], yj = a.dst.x[1][j], zj = a.dst.x[2][j];
+            const int jo = VIA_PERM ? a.perm[j] : j;
+            const AtomSoA &from = VIA_PERM ? a.src : a.dst;
+            const double xj = from.x[0][jo], yj = from.x[1][jo], zj = from.x[2][jo];
             const double gx = xj + a.sh.s[d][0], gy = yj + a.sh.s[d][1], gz = zj + a.sh.s[d][2];
             a.dst.x[0][gi] = gx; a.dst.x[1][gi] = gy; a.dst.x[2][gi] = gz;
-            const int tg = a.dst.tag[j], ty = a.dst.type[j];
-            a.dst.tag[gi] = tg; a.dst.type[gi] = ty; a.dst.mask[gi] = a.dst.mask[j];
+            const int tg = from.tag[jo], ty = from.type[jo];
+            a.dst.tag[gi] = tg; a.dst.type[gi] = ty; a.dst.mask[gi] = from.mask[jo];
             // pack_comm_vel + gpu_merge_xvt for the ghost (k_pack_forward's expressions: same bits)
             float4 c, v;
             c.x = (float)(gx - a.ce.c[d][0]); c.y = (float)(gy - a.ce.c[d][1]); c.z = (float)(gz - a.ce.c[d][2]);
             c.w = __uint_as_float((u32)(ty - 1));
-            v.x = (float)a.dst.v[0][j]; v.y = (float)a.dst.v[1][j]; v.z = (float)a.dst.v[2][j];
+            v.x = (float)from.v[0][jo]; v.y = (float)from.v[1][jo]; v.z = (float)from.v[2][jo];
             v.w = __uint_as_float(signature(a.mg.seed, tg, v.x, v.y, v.z));
             a.mg.coord4[gi] = c;
             a.mg.veloc4[gi] = v;
@@ -596,6 +568,18 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a)
     }
 }
 
+__global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a) { fr_ghosts_tile<false>(a, (int)blockIdx.x); }
+
+// gather + ghosts as ONE launch (one rank, order-only placing kernel, images booked by the count): the first nghost_blocks workgroups
+// are ghost tiles - latency chains that need nothing of the gather, only the permutation and the cell starts of the ordering kernel
+// and the ghost totals of the count - the rest stream the payload
+__global__ void __launch_bounds__(FR_THREADS) k_fr_gather_ghosts(FusedArgs a, int nghost_blocks)
+{
+    static_assert(FR_THREADS == 256, "one workgroup size for both halves");
+    if ((int)blockIdx.x < nghost_blocks) fr_ghosts_tile<true>(a, (int)blockIdx.x);
+    else fr_gather_block(a, (int)blockIdx.x - nghost_blocks);
+}
+
 void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted)
 {
     if (a.n <= 0) return;
@@ -614,8 +598,17 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted)
     const bool split = a.split_gather && !lists && a.perm && !a.skip;
     if (lists) hipLaunchKernelGGL((k_fr_place<true, true>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     else if (split) {
-        hipLaunchKernelGGL((k_fr_place<false, false>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
-        hipLaunchKernelGGL(k_fr_gather, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+        // (merged_ghosts, the engine's wish, holds only with the order-only placing kernel and images booked by the count)
+        FusedArgs b = a;
+        b.merged_ghosts = (a.merged_ghosts && a.gttot && a.img_booked) ? 1 : 0;
+        hipLaunchKernelGGL((k_fr_place<false, false>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, b);
+        if (b.merged_ghosts) {
+            if (a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
+            const int ngb = a.gorder ? a.ngorder : ntg;
+            hipLaunchKernelGGL(k_fr_gather_ghosts, dim3(ngb + (a.n + 255) / 256), dim3(256), dyn3, s, b, ngb);
+            return;
+        }
+        hipLaunchKernelGGL(k_fr_gather, dim3((a.n + 255) / 256), dim3(256), 0, s, b);
     } else hipLaunchKernelGGL((k_fr_place<false, true>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     if (a.gttot && a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
     if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(a.gorder ? a.ngorder : ntg), dim3(FR_THREADS), dyn3, s, a);

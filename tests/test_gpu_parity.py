@@ -699,7 +699,10 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
                  # fuse_count: the rebuild's count kernel in the epilogue of the force launch in front of the rebuild (default) or on its own
                  (("fuse_count", 0),), (("fuse_count", 0), ("split_gather", 1)), (("fuse_count", 1), ("split_gather", 1), ("fused_cap", 2)),
                  # lean_boundary: the epilogue takes type and mass from the merged record and the per-type table (default) or from the atom arrays
-                 (("lean_boundary", 0),)):
+                 (("lean_boundary", 0),),
+                 # merge_ghosts: the ghost tiles in the gather's launch (default with split_gather) or in a launch of their own
+                 (("split_gather", 1),), (("split_gather", 1), ("merge_ghosts", 0)), (("split_gather", 1), ("merge_ghosts", 1), ("fuse_count", 0)),
+                 (("split_gather", 1), ("merge_ghosts", 1), ("lean_boundary", 0), ("fused_cap", 2))):
         m, _ = _engine(Meso, 16, style=style, opts=opts)
         m.run(23)
         res.append(m.gather())
