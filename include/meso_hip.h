@@ -78,7 +78,9 @@ int meso_device_sync(meso_ctx *ctx);
  *                    binning on the side stream, joined by events (north_star's "reorder on a side stream overlapped with halo pack":
  *                    same neighbour sets and forces, measured 4-7 % slower at every size; test_rebuild_variants_give_the_same_trajectory)
  *   fuse_count    1  one rank: on the step in front of a rebuild the force kernel's step-boundary epilogue also runs the rebuild's first
- *                    kernel (wrap, cell code, rank inside the cell, bucket entry: k_fr_count) over the positions it has just written
+ *                    kernel (wrap, cell code, rank inside the cell, bucket entry: k_fr_count) over the positions it has just written;
+ *                    0 = the count as a launch of its own (test_rebuild_variants_give_the_same_trajectory, the 64^3 case in
+ *                    test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows)
  *   merge_ghosts  1  one rank, with split_gather: the ghost tiles of a rebuild run in the launch of its gather (they read the old order
  *                    through the permutation; the count books every border atom's periodic images): one launch less, the ghost
  *                    tiles' latency chains under the stream (test_rebuild_variants_give_the_same_trajectory)
@@ -88,6 +90,7 @@ int meso_device_sync(meso_ctx *ctx);
  *   xcd_balance   1  force launches of more than one round of workgroups: bulk and border workgroups are dealt out over the eight XCDs
  *                    separately (in Morton order an XCD's border share lies next to its bulk share); 0 = one contiguous range of atoms
  *                    per XCD, which leaves every border atom - a fifth more pairs, the periodic images - to the last XCD
+ *                    (test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows)
  *   check_launches 0  debugging: every stage of a rebuild (migration, reorder, borders, list builder) is synchronised and asked for
  *                    HIP errors, so that a fault names the stage instead of surfacing at the end of meso_run
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */
