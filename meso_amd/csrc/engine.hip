@@ -1956,7 +1956,7 @@ int Engine::run(int nsteps)
         if (boundary_in_pair && lean_boundary) {
             // (type from the merged record, mass - as dtf / m, evaluated once per type - from the per-type table, no mask of group "all")
             if (dtfm_for != 0.5 * dt) { launch_dtfm_table(d_mass_type, ntypes, 0.5 * dt, d_dtfm_type, stream); dtfm_for = 0.5 * dt; }
-            p.nve.mass_type = d_mass_type; p.nve.dtfm_type = lean_boundary == 2 ? nullptr : d_dtfm_type;      // (2: timing ablation, mass from the table and the reciprocal per atom)
+            p.nve.mass_type = d_mass_type; p.nve.dtfm_type = d_dtfm_type;
         }
         // small boxes on one rank: the epilogue also writes the merged pairs of the atom's periodic images for step s+1
         const bool img_step = boundary_in_pair && !next_rebuild && images_ready && images_on() && !split;
