@@ -1894,7 +1894,7 @@ int Engine::run(int nsteps)
         {
             const int a1_ = ago + 1;
             const bool next_rebuild_ = dist_check || (a1_ >= delay && a1_ % every == 0);
-            const bool fusable = fuse_pair && fuse_step && it + 1 < nsteps && !have_bonds && ring_selected() && nranks == 1;
+            const bool fusable = fuse_pair && fuse_step && it + 1 < nsteps && (!have_bonds || nbondtypes > 0) && ring_selected() && nranks == 1;
             if (next_rebuild_ && fusable) TRY(prepare_count_in_epilogue(frc_args, count_here));
         }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);

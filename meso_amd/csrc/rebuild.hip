@@ -320,12 +320,18 @@ __global__ void __launch_bounds__(FR_PLACE_THREADS, LISTS ? 5 : FR_PLACE_OCC) k_
 // 2b: the payload of the order-only form: atom perm[n] of the old order becomes atom n of the new one (lane = n; gpu_permute_copy,
 // atom_vec_meso.h:11-67, with gpu_merge_xvt folded in), border atoms book their periodic images per tile of ghost cells exactly as
 // the fused form does (the cell from the coordinate, as k_fr_count computed it)
+// (LISTS: bonded systems - the general gather, topology lists travel too: permute_one, meso_device.h)
+template <bool LISTS>
 __device__ __forceinline__ void fr_gather_block(const FusedArgs &a, const int bidx)
 {
     const int n = (int)blockDim.x * bidx + (int)threadIdx.x;
     const bool valid = n < a.n;
     double X[3] = {0.0, 0.0, 0.0};
-    if (valid) {
+    if (valid && LISTS) {
+        MergeOut mg = a.mg;
+        if (a.merged_ghosts && n >= a.estart[a.M]) mg.zero = nullptr;      // (border atoms: cleared by the ordering kernel, see below)
+        permute_one(a.src, a.dst, a.perm[n], n, a.with_f, mg, X);
+    } else if (valid) {
         const int j = a.perm[n];
         double V[3], F[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -367,7 +373,7 @@ __device__ __forceinline__ void fr_gather_block(const FusedArgs &a, const int bi
     book_images(emask, bx, by, bz, a.g.mbin, a.gttot);
 }
 
-__global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a) { fr_gather_block(a, (int)blockIdx.x); }
+template <bool LISTS> __global__ void __launch_bounds__(256) k_fr_gather(FusedArgs a) { fr_gather_block<LISTS>(a, (int)blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 3: ghosts
@@ -573,11 +579,12 @@ __global__ void __launch_bounds__(FR_THREADS) k_fr_ghosts(FusedArgs a) { fr_ghos
 // gather + ghosts as ONE launch (one rank, order-only placing kernel, images booked by the count): the first nghost_blocks workgroups
 // are ghost tiles - latency chains that need nothing of the gather, only the permutation and the cell starts of the ordering kernel
 // and the ghost totals of the count - the rest stream the payload
+template <bool LISTS>
 __global__ void __launch_bounds__(FR_THREADS) k_fr_gather_ghosts(FusedArgs a, int nghost_blocks)
 {
     static_assert(FR_THREADS == 256, "one workgroup size for both halves");
     if ((int)blockIdx.x < nghost_blocks) fr_ghosts_tile<true>(a, (int)blockIdx.x);
-    else fr_gather_block(a, (int)blockIdx.x - nghost_blocks);
+    else fr_gather_block<LISTS>(a, (int)blockIdx.x - nghost_blocks);
 }
 
 void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted)
@@ -595,8 +602,8 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted)
     }
     // large boxes of one rank: order, then a streaming gather (split_gather: the engine's choice; needs the permutation array and
     // no holes in the old order)
-    const bool split = a.split_gather && !lists && a.perm && !a.skip;
-    if (lists) hipLaunchKernelGGL((k_fr_place<true, true>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
+    const bool split = a.split_gather && a.perm && !a.skip;
+    if (lists && !split) hipLaunchKernelGGL((k_fr_place<true, true>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     else if (split) {
         // (merged_ghosts, the engine's wish, holds only with the order-only placing kernel and images booked by the count)
         FusedArgs b = a;
@@ -605,10 +612,12 @@ void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted)
         if (b.merged_ghosts) {
             if (a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
             const int ngb = a.gorder ? a.ngorder : ntg;
-            hipLaunchKernelGGL(k_fr_gather_ghosts, dim3(ngb + (a.n + 255) / 256), dim3(256), dyn3, s, b, ngb);
+            if (lists) hipLaunchKernelGGL(k_fr_gather_ghosts<true>, dim3(ngb + (a.n + 255) / 256), dim3(256), dyn3, s, b, ngb);
+            else hipLaunchKernelGGL(k_fr_gather_ghosts<false>, dim3(ngb + (a.n + 255) / 256), dim3(256), dyn3, s, b, ngb);
             return;
         }
-        hipLaunchKernelGGL(k_fr_gather, dim3((a.n + 255) / 256), dim3(256), 0, s, b);
+        if (lists) hipLaunchKernelGGL(k_fr_gather<true>, dim3((a.n + 255) / 256), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL(k_fr_gather<false>, dim3((a.n + 255) / 256), dim3(256), 0, s, b);
     } else hipLaunchKernelGGL((k_fr_place<false, true>), dim3(2 * a.M / FR_TILE), dim3(FR_PLACE_THREADS), dyn2, s, a);
     if (a.gttot && a.gstot) hipLaunchKernelGGL(k_fr_super, dim3((ntg + FR_SUPER - 1) / FR_SUPER), dim3(FR_THREADS), 0, s, a.gttot, ntg, a.gstot);
     if (a.gttot) hipLaunchKernelGGL(k_fr_ghosts, dim3(a.gorder ? a.ngorder : ntg), dim3(FR_THREADS), dyn3, s, a);

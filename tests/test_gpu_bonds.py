@@ -219,7 +219,12 @@ def test_bonded_rebuild_without_host_round_trip_gives_the_same_trajectory():
     from meso_amd.api import Meso
     x, v, types, bonds, lo, hi = make_polymer_box(14, frac=0.4)
     res = []
-    for opts in ((("async_counts", 0), ("ghost_epilogue", 0)), (), (("async_grid_scale", 0.05),), (("ghost_epilogue", 0),)):
+    # (round 5, bonded decks too: the rebuild's count in the epilogue of the force launch in front of it - fuse_count -, the ordering
+    # kernel + a streaming gather that moves the topology lists as well - split_gather, by default from 50 000 atoms on -, the ghost
+    # tiles in the gather's launch - merge_ghosts)
+    for opts in ((("async_counts", 0), ("ghost_epilogue", 0)), (), (("async_grid_scale", 0.05),), (("ghost_epilogue", 0),),
+                 (("fuse_count", 0), ("split_gather", 0)), (("split_gather", 1),), (("split_gather", 1), ("merge_ghosts", 0)),
+                 (("split_gather", 1), ("fuse_count", 0), ("lean_boundary", 0)), (("fused_rebuild", 0),)):
         with Meso() as m:
             for k, val in opts:
                 m.set_option(k, val)
