@@ -771,10 +771,55 @@ __global__ void __launch_bounds__(256) k_filter_exclusion(ExclArgs ex, int nloca
             }
             return nout;
         };
-        const int nf = section(table + row_word8(i, 0, n_col) * 8, on ? n_a : 0);
+        // Rows of ordinary length (front <= 64 entries, back <= 32 - wave-uniform test): every entry of both sections is requested
+        // before anything is looked at, then every tag: two round trips for the atom instead of two per batch of 16 entries and section
+        // (the filter is a chain of dependent round trips: that is its whole cost).  All reads precede all writes here.
+        int *rowF = table + row_word8(i, 0, n_col) * 8, *rowB = nback ? back + row_word8(i, 0, nb_col) * 8 : rowF;
+        const int nF = on ? n_a : 0, nB = (on && nback) ? nb_a : 0;
+        int nFmax = nF, nBmax = nB;
+#pragma unroll
+        for (int o = 32; o >= 16; o >>= 1) { nFmax = max(nFmax, __shfl_xor(nFmax, o, 64)); nBmax = max(nBmax, __shfl_xor(nBmax, o, 64)); }
+        nFmax = __builtin_amdgcn_readfirstlane(nFmax); nBmax = __builtin_amdgcn_readfirstlane(nBmax);
+        if (nFmax <= 64 && nBmax <= 32 && nspmax <= 16) {
+            int jf[4], jb[2], tf[4], tb[2];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int e = 16 * q + l16; jf[q] = e < nF ? rowF[(size_t)(e >> 3) * 512 + (e & 7)] : i; }
+#pragma unroll
+            for (int q = 0; q < 2; q++) { const int e = 16 * q + l16; jb[q] = e < nB ? rowB[(size_t)(e >> 3) * 512 + (e & 7)] : i; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) tf[q] = ex.tagc[jf[q]];
+#pragma unroll
+            for (int q = 0; q < 2; q++) tb[q] = ex.tagc[jb[q]];
+            auto compact = [&](int *row, int n, const int *jj, const int *tt, int iters, int nmax) -> int {
+                int nout = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q >= iters || 16 * q >= nmax) break;
+                    bool keep = 16 * q + l16 < n;
+                    for (int sp = 0; sp < nspmax; sp++) keep = keep & (__shfl(sp_l, (lane & 48) + sp, 64) != tt[q]);
+                    const u32 m16 = (u32)(__builtin_amdgcn_ballot_w64(keep) >> (16 * g)) & 0xffffu;
+                    const int pos = nout + __popc(m16 & below);
+                    if (keep) row[(size_t)(pos >> 3) * 512 + (pos & 7)] = jj[q];
+                    nout += __popc(m16);
+                }
+                if (on) {
+                    const int e = nout + l16;
+                    if (e < ((nout + 7) & ~7)) row[(size_t)(e >> 3) * 512 + (e & 7)] = i;
+                }
+                return nout;
+            };
+            const int nf = compact(rowF, nF, jf, tf, 4, nFmax);
+            if (on && l16 == 0) count[i] = nf;
+            if (nback) {
+                const int nb = compact(rowB, nB, jb, tb, 2, nBmax);
+                if (on && l16 == 0) nback[i] = nb;
+            }
+            continue;
+        }
+        const int nf = section(rowF, nF);
         if (on && l16 == 0) count[i] = nf;
         if (nback) {
-            const int nb = section(back + row_word8(i, 0, nb_col) * 8, on ? nb_a : 0);
+            const int nb = section(rowB, nB);
             if (on && l16 == 0) nback[i] = nb;
         }
     }
