@@ -170,12 +170,25 @@ def other_box(Meso, make_box, L, a, style=None, every=None, steps=None, roofline
         if calls:
             b = len(x) * (16 + 16 + 4 + 4.0 * nbar + 24)
             t = ms / calls * 1e-3
+            tb = _touched_bytes(m, len(x))
             out["roofline"] = {"bound": "hbm", "achieved": b / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / t / 1e9 / HBM_PEAK_GBS,
+                               "bytes_touched": tb, "frac_of_bytes_touched": (tb / t / 1e9 / HBM_PEAK_GBS) if tb else None,
                                "traffic": None, "kernel": "k_pair_dpd_ring (force only, SURVEY.md 8d B_pair)", "kernel_variant": m.pair_kernel_name(),
                                "bytes_per_launch": b, "us_per_launch": t * 1e6, "avg_neighbors": nbar}
             out["rebuild_us"] = {k: (1e3 * v[0] / v[1] if v[1] else None) for k, v in ph.items()}
     m.close()
     return out
+
+
+def _touched_bytes(m, n):
+    """Bytes a force-only launch over n atoms asks for: own records 32, count 4, the row chunks it walks (two-section rows: the front
+    section, padded to whole 32-byte chunks; plain rows: all of the row), 24 of force."""
+    try:
+        pt = m.neigh_parts()
+        cnt = pt["nfront"] if pt["parted"] else pt["nfront"] + pt["nback"]
+        return float(n * (32 + 4 + 24) + 4.0 * float(((cnt[:n] + 7) // 8 * 8).sum()))
+    except Exception:
+        return None
 
 
 def _kernel_source_hash():
@@ -344,6 +357,9 @@ def main():
             raise SystemExit("bench: the force-only pass recorded no launch")
         t_alone = (ms / max(a.every, min(a.profile_steps, 100)) if world > 1 else ms / calls) * 1e-3
     achieved = b_pair_only / t_alone / 1e9
+    # (rows in two sections: a pairing launch walks the FRONT section only - whole 32-byte chunks of it.  The graded figure stays
+    # SURVEY.md 8(d)'s formula over the entries the table stores; the bytes this launch really asks for are reported beside it)
+    touched = _touched_bytes(m, n_rank)
     # measured peak beside the nominal one: a 1 GiB float4 copy on the same device (read + write bytes)
     copy_gbs = m.membw_probe(1 << 30, 5)
     # ---- the timed region: W untimed warm-up steps, then exactly K steps between barriers
@@ -390,6 +406,15 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    # what the rebuild of the timed region ran (north_star words the reorder as "rocPRIM radix sort on a side HIP stream overlapped with
+    # halo pack/unpack": built, tested equal, measured slower - DESIGN.md section 6 - so the line says which form this number is for)
+    optd = dict(kv.split("=", 1) for kv in a.opt if "=" in kv)
+    if optd.get("reorder_sort", "0") not in ("0", "0.0"):
+        reorder_note = "rocPRIM radix_sort_pairs (option reorder_sort 1)"
+    else:
+        reorder_note = "counting reorder per [border][Morton(bin)] code"
+    reorder_note += (", reorder and ghost half of the rebuild on two streams (option overlap_rebuild 1)" if optd.get("overlap_rebuild", "0") not in ("0", "0.0")
+                     else ", one stream (the rocPRIM / side-stream variant measured 4-7 % slower: options reorder_sort, overlap_rebuild)")
     ws_bytes = (195 if fp32 else 207) + 88 + 192 + 175.0 / max(a.every, 1)
     line = {
         "metric": "DPD timesteps/s, %d^3 rho=4 box" % L,
@@ -405,15 +430,18 @@ def main():
         "dtype": "f32" if fp32 else "f64",
         "data": "synthetic",
         "config": {"workload": "%d^3 box rho=4 (N=%d)%s, pair_style %s, neighbor 0.3 bin, rebuild every %d, dt 0.005, "
-                               "%d MI355X, procgrid %dx%dx%d" % ((L, n, ", %.0f %% of the beads in bonded A2B4 chains" % (100 * a.polymer)
-                                                                  if a.polymer > 0 else "", a.style, a.every, a.gpus) + tuple(grid)),
+                               "%d MI355X, procgrid %dx%dx%d; reorder: %s" % ((L, n, ", %.0f %% of the beads in bonded A2B4 chains" % (100 * a.polymer)
+                                                                  if a.polymer > 0 else "", a.style, a.every, a.gpus) + tuple(grid) + (reorder_note,)),
                    "M_particle_steps_per_s": steps_per_s * n / 1e6,
                    "avg_neighbors": info["avg_count"], "temperature_end": T},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                      "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "kernel_variant": variant, "bytes_per_launch": b_pair_only,
-                     "us_per_launch": t_alone * 1e6, "fused": fused_rec, "limiter_from_profile": limiter},
+                     "us_per_launch": t_alone * 1e6, "fused": fused_rec, "limiter_from_profile": limiter,
+                     "bytes_definition": "graded frac: SURVEY.md 8(d) B_pair = N (36 + 4 x stored row entries [front + back] + 24); "
+                                         "bytes_touched: what this launch reads and writes (front sections only, padded to 32-byte chunks)",
+                     "bytes_touched": touched, "frac_of_bytes_touched": (touched / t_alone / 1e9 / HBM_PEAK_GBS) if touched else None},
         "phases_ms": {k: p["ms_per_call"] for k, p in phases.items()},
         # the whole step against the whole-step floor of SURVEY.md 8(d) (context, not the graded figure): pair 195 (fp32 sums; 207 with
         # fp64 ones) + merge 88 + NVE 108 + 84 + list build 175 per rebuild; non-bonded decks only

@@ -22,6 +22,11 @@ typedef struct meso_ctx meso_ctx;
 enum { MESO_OK = 0, MESO_ERR_ARG = 1, MESO_ERR_HIP = 2, MESO_ERR_STATE = 3, MESO_ERR_OVERFLOW = 4, MESO_ERR_COMM = 5 };
 
 /* pair styles: PairStyle(dpd/meso,MesoPairDPD) pair_dpd_meso.h:3 ; PairStyle(dpd/fast/meso,...) pair_dpd_fast_meso.h:3 */
+/* Units of the fp32 styles (dpd/fast/meso, dpd/mini/meso, dpd/polyforce/meso, dpd/tableforce/meso): the force kernel adds an atom's
+ * pair forces as 32-bit fixed point with 16 fractional bits - a term is truncated to 1.5e-5 force units and a component of the sum
+ * holds +-32768.  Reduced DPD units stay three orders of magnitude inside that.  A sum beyond HALF the range is reported by meso_run /
+ * meso_pair_compute as MESO_ERR_OVERFLOW ("... fixed-point sums ...", tests/test_gpu_parity.py::test_fp32_force_sums_out_of_range_are_
+ * reported) instead of wrapping; dpd/meso adds in 64 bits (36 fractional: 1.5e-11 resolution, +-1.3e8) and is the style for such decks. */
 /* MESO_PAIR_DPD_MINI: PairStyle(dpd/mini/meso) pair_dpd_minimal_meso.h:3 - fp32 arithmetic, cutoff 1, one (a0, gamma, sigma)
  * for all types (pair_coeff * * a0 gamma sigma), pair noise from the logistic map mean0var1<8> (:50-89) instead of TEA */
 enum { MESO_PAIR_DPD = 0, MESO_PAIR_DPD_FAST = 1, MESO_PAIR_DPD_MINI = 2, MESO_PAIR_DPD_POLYFORCE = 3, MESO_PAIR_DPD_TABLEFORCE = 4 };

@@ -23,6 +23,15 @@
 
 namespace meso {
 
+// MESO_RCCL_TIMEOUT (seconds) bounds the two waits of a communicator's first use; unset, empty, unparsable or not positive: 180
+static double rccl_timeout_s()
+{
+    const char *te = getenv("MESO_RCCL_TIMEOUT");
+    const double v = (te && *te) ? atof(te) : 0.0;
+    return v > 0.0 ? v : 180.0;
+}
+
+
 #define HIPCHK(call)                                                      \
     do {                                                                  \
         int _rc = check((call), #call);                                   \
@@ -174,8 +183,7 @@ int Engine::comm_init(int nr, int rk, const int *pg, int tr, const void *uid, si
             join->cv.notify_all();
         }).detach();
         {
-            const char *te = getenv("MESO_RCCL_TIMEOUT");
-            const double limit = te ? atof(te) : 180.0;
+            const double limit = rccl_timeout_s();
             std::unique_lock<std::mutex> lk(join->mu);
             if (!join->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return join->done; })) {
                 char msg[256];
@@ -276,15 +284,23 @@ int Engine::xchg(int np, const int *peer, void *const *sbuf, const size_t *sbyte
                     if (ncclRecv(rp[q].p, rp[q].n, ncclChar, peer[k], c, stream) != ncclSuccess) return fail(5, "ncclRecv failed");
             }
             if (ncclGroupEnd() != ncclSuccess) return fail(5, "ncclGroupEnd failed");
-            if (timed) { HIPCHK(hipEventRecord(xe.b, stream)); xchg_events.push_back(xe); }
+            if (timed) {
+                HIPCHK(hipEventRecord(xe.b, stream));
+                xchg_events.push_back(xe);
+                // (a long profiled run: the events of finished groups are booked and destroyed every few hundred groups)
+                if (xchg_events.size() >= 512) xchg_events_flush();
+            }
             if (!rccl_first_done) {
                 // the first group of a communicator sets up the connections to every peer: it is waited for here, for at most
                 // MESO_RCCL_TIMEOUT seconds, so that a peer that never posts its side is reported by name instead of hanging the job
-                const char *te = getenv("MESO_RCCL_TIMEOUT");
-                const double limit = te ? atof(te) : 180.0;
+                const double limit = rccl_timeout_s();
                 const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(limit);
                 hipError_t q;
-                while ((q = hipStreamQuery(stream)) == hipErrorNotReady && std::chrono::steady_clock::now() < t_end) std::this_thread::yield();
+                // (connection set-up takes milliseconds to seconds: the first hundred polls yield, later ones sleep)
+                for (int polls = 0; (q = hipStreamQuery(stream)) == hipErrorNotReady && std::chrono::steady_clock::now() < t_end; polls++) {
+                    if (polls < 100) std::this_thread::yield();
+                    else std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
                 if (q == hipErrorNotReady) {
                     std::string peers;
                     for (int k = 0; k < np; k++) if (peer[k] != rank && (sbytes[k] || rbytes[k])) peers += (peers.empty() ? "" : " ") + std::to_string(peer[k]);

@@ -467,8 +467,7 @@ int Engine::alloc_atoms(int cap)
     if (n_col > 0) {
         table_tiles = ((size_t)cap + 63) / 64;
         dfree(pair_table); dfree(pair_back);
-        HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
-        HIPCHK(dalloc(pair_back, table_tiles * 64 * (size_t)nb_col));
+        HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));      // (pair_back: when a build first writes two sections)
         dfree(brick_own);
         HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
@@ -887,8 +886,7 @@ int Engine::init_params()
         nb_col = std::max(8, (n_col / 2 + 7) & ~7);      // back section of a partitioned row: about half of the in-group partners, at most half a row
         table_tiles = ((size_t)nmax + 63) / 64;
         dfree(pair_table); dfree(pair_back);
-        HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));
-        HIPCHK(dalloc(pair_back, table_tiles * 64 * (size_t)nb_col));
+        HIPCHK(dalloc(pair_table, table_tiles * 64 * (size_t)n_col));      // (pair_back: when a build first writes two sections)
         dfree(brick_own);
         HIPCHK(dalloc(brick_own, table_tiles * 64));
     }
@@ -1526,6 +1524,9 @@ int Engine::build_cells_and_table()
                 rows_part = part_pays && pair_share != 0 && ring_selected() && pair_debug != 9 &&
                             (counts_pending ? (long)nmax : (long)nlocal + nghost) <= (1L << 25);
                 part_group = rows_part ? pair_ring_group_for(nlocal, pair_npart) : 0;
+                // the back table (half a row per atom) exists only for decks that partition: plain rows, the wide records of very
+                // large systems and the lane-per-atom builder never pay for it (21 GB at 256^3)
+                if (rows_part && !pair_back) HIPCHK(dalloc(pair_back, table_tiles * 64 * (size_t)nb_col));
                 RowPartArgs pt = {part_group, nlocal, pair_nback, pair_back, nb_col};
                 launch_tile_build(bb, coord4, rc2, n_col, pair_count, pair_table, d_flags, have_bonds ? &ex : nullptr, nlocal,
                                   pair_debug >= 10 ? pair_debug - 10 : 0, stream, &pt);
@@ -1568,8 +1569,14 @@ int Engine::resolve_counts()
 
 int Engine::check_overflow()
 {
-    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 7 * sizeof(int), hipMemcpyDeviceToHost, stream));      // [5]: fullest brick neighbourhood so far, [6]: 2-brick near its stage
+    HIPCHK(hipMemcpyAsync(h_flags, d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));      // [5]: fullest brick neighbourhood so far, [6]: 2-brick near its stage, [7]: fp32 force sums out of range
     HIPCHK(hipStreamSynchronize(stream));
+    if (h_flags[7]) {
+        h_flags[7] = 0;
+        HIPCHK(hipMemsetAsync(d_flags + 7, 0, sizeof(int), stream));
+        return fail(4, "Force on an atom beyond the range of the fp32 styles' 32-bit fixed-point sums (|F| >= 16384 force units: overlapping "
+                       "atoms, or a deck far from reduced units): the forces of this run are not valid - use pair_style dpd/meso (64-bit sums)");
+    }
     if (have_bonds && h_flags[4]) {
         HIPCHK(hipMemsetAsync(d_flags + 4, 0, sizeof(int), stream));
         return fail(4, "Bond atoms missing: a bonded (or angle) partner is outside the ghost cutoff");
@@ -1603,6 +1610,9 @@ int Engine::check_overflow()
         if (h_flags[0] >= 100000)
             snprintf(buf, sizeof buf, "Brick halo overflow: %d atoms in one brick neighbourhood (capacity %d); local density too "
                      "high - raise option brick_margin or use neigh_kernel 0", h_flags[0] - 100000, bargs.maxh);
+        else if (h_flags[0] == n_col + 1 && rows_part)
+            snprintf(buf, sizeof buf, "Pair table overflow: a row's back section (mirrored in-group partners) holds more than nb_col = %d entries "
+                     "or the row more than n_col = %d; local density too high - option row_part 0 stores plain rows", nb_col, n_col);
         else
             snprintf(buf, sizeof buf, "Pair table overflow: %d > %d; local density too high", h_flags[0], n_col);
         return fail(4, buf);
@@ -1756,6 +1766,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.nback = rows_part ? pair_nback : nullptr;
     p.table_back = pair_back; p.nb_col = nb_col;
     p.part_group = part_group;
+    p.range_flag = d_flags + 7;
     if (rows_part) p.npart = 4 * 64 / part_group;      // every launch of the interval pairs inside the groups the rows were partitioned for
     p.poly = pair_poly ? d_poly : nullptr;
     p.ftab = pair_ftab ? d_ftab : nullptr;
@@ -1858,7 +1869,10 @@ int Engine::prepare_count_in_epilogue(FrCountArgs &c, bool &ok)
     if ((h_flags[6] || h_flags[11]) && !brick2_off) return 0;                                   // the 2-brick stage is about to change
     if (neigh_kernel == 1 && (long)std::max(h_flags[5], h_flags[10]) * 100 > (long)bargs.maxh * 93) return 0;      // ... or the 4-brick's
     const int bound = (int)(nghost_prev * async_grid_scale) + 1024;
-    TRY(ensure_capacity(nlocal + bound + bound / 2));
+    // No regrow here: alloc_atoms() keeps the atoms but not the neighbour table nor the merged records, and this step's force launch
+    // still reads both.  A rebuild that needs more room runs its own count kernel and regrows where the table is rebuilt anyway
+    // (rebuild_fused); tests/test_gpu_parity.py::test_count_in_epilogue_does_not_regrow_ahead_of_the_force_launch.
+    if (nlocal + bound + bound / 2 > nmax) return 0;
     TRY(fused_alloc());
     wrap_in_reorder = true;
     FusedArgs a;

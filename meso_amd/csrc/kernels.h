@@ -199,6 +199,9 @@ struct PairArgs {
     int frc_on;           // with fuse_nve: the epilogue also runs the rebuild's count over the positions it has just written
     FrCountArgs frc;
     BondArgs bond;        // with fuse_nve: this atom's bond forces are computed in the epilogue and added before the step boundary
+    // ring kernel, fp32 styles: set to 1 when the 32-bit fixed-point force sum of an atom (16 fractional bits: +-32768 force units)
+    // is beyond half its range (nullable).  Engine::check_overflow turns it into an error instead of a silently wrapped force.
+    int *range_flag;
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // fp32 style on chunked-8 rows: light cutoff scan per lane, hits compacted into a per-wave LDS ring of 4-byte

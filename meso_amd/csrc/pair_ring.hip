@@ -462,7 +462,13 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     double xn0 = 0.0, xn1 = 0.0, xn2 = 0.0;       // the atom's position after the step boundary (for the rebuild's count below)
     if (mine && part == 0) {
         double fx, fy, fz;
-        if constexpr (F32) { fx = from_fixed16(facc[ob]); fy = from_fixed16(facc[NB + ob]); fz = from_fixed16(facc[2 * NB + ob]); }
+        if constexpr (F32) {
+            const int sx = (int)facc[ob], sy = (int)facc[NB + ob], sz = (int)facc[2 * NB + ob];
+            fx = from_fixed16((u32)sx); fy = from_fixed16((u32)sy); fz = from_fixed16((u32)sz);
+            // a sum beyond half the accumulator's range (|F| >= 16384 force units on one atom; a single term beyond the range saturates
+            // in to_fixed16 and lands here too): reported, not wrapped silently (meso_hip.h, "units of the fp32 styles")
+            if (a.range_flag && max(max(abs(sx), abs(sy)), abs(sz)) > 0x3FFFFFFF) *a.range_flag = 1;
+        }
         else if (FAST) { fx = from_fixed(facc[ob]); fy = from_fixed(facc[NB + ob]); fz = from_fixed(facc[2 * NB + ob]); }
         else { fx = from_fixed36(facc[ob]); fy = from_fixed36(facc[NB + ob]); fz = from_fixed36(facc[2 * NB + ob]); }
         if (a.fuse_nve) {

@@ -714,6 +714,48 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
             assert np.array_equal(a, b)
 
 
+def test_fp32_force_sums_out_of_range_are_reported(Meso):
+    """The fp32 styles add forces as 32-bit fixed point (16 fractional bits: +-32768 force units per atom and component).  A deck whose
+    forces leave half that range (here a0 = 4e4 in reduced units) must end with an error that says so, not with wrapped forces; the
+    fp64 style (64-bit sums) runs the same deck, and the ordinary deck raises nothing."""
+    from meso_amd.api import MesoError
+    x, v, lo, hi = make_box(8)
+    for style, a0, dt, expect in (("dpd/fast/meso", 4.0e4, 1.0e-4, True), ("dpd/meso", 4.0e4, 1.0e-4, False), ("dpd/fast/meso", 15.0, 0.005, False)):
+        m = Meso()
+        m.read_atoms(x, v, lo, hi)
+        m.neighbor(0.3)
+        m.neigh_modify(delay=0, every=5, check=False)
+        m.pair_style(style, 1.0, DP_RUN["seed"])
+        m.pair_coeff(1, 1, a0, 4.5, 3.0, 1.0, 1.0)
+        m.timestep(dt)
+        err = None
+        try:
+            m.setup()
+            m.run(3)
+        except MesoError as e:
+            err = str(e)
+        m.close()
+        assert (err is not None and "fixed-point" in err) == expect, (style, a0, err)
+
+
+@pytest.mark.parametrize("style", ["dpd/meso", "dpd/fast/meso"])
+def test_count_in_epilogue_does_not_regrow_ahead_of_the_force_launch(Meso, style):
+    """The rebuild's count rides in the force launch IN FRONT of the rebuild (fuse_count).  When that rebuild will need more room than
+    the atom arrays have (here: async_grid_scale 3 asks for three times the ghosts' head-room, beyond the capacity chosen at upload),
+    the preparation must not reallocate ahead of that force launch - the neighbour table and the merged records it still reads would be
+    lost - but leave the growth to the rebuild itself (engine.hip prepare_count_in_epilogue).  Same bits as the plain path."""
+    res = []
+    for opts in ((("fuse_count", 0), ("async_counts", 0)), (("fuse_count", 1), ("async_grid_scale", 3.0))):
+        m, _ = _engine(Meso, 16, style=style, opts=opts)
+        m.run(23)
+        res.append(m.gather()[:3])
+        assert m.neigh_info()["nbuild"] >= 4
+        m.close()
+    assert np.abs(res[0][2]).max() > 0.5
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("style", ["dpd/meso", "dpd/fast/meso"])
 def test_step_boundary_reads_type_and_mass_from_what_the_kernel_holds(Meso, style):
     """option lean_boundary (default): the force kernel's step-boundary epilogue takes the atom's type from the merged coordinate record
