@@ -96,6 +96,10 @@ int meso_device_sync(meso_ctx *ctx);
  *                    separately (in Morton order an XCD's border share lies next to its bulk share); 0 = one contiguous range of atoms
  *                    per XCD, which leaves every border atom - a fifth more pairs, the periodic images - to the last XCD
  *                    (test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows)
+ *   tile_persist  0  1 = the tile list builder runs as persistent workgroups (as many as the card holds at once) that draw their bricks
+ *                    from 32 counters - the reference's builder is a grid-stride loop, neigh_build_meso.cu:58; measured 6 % slower than
+ *                    one workgroup per brick (64^3: 219 against 206 us per build), so off (test_config2_64cube_two_section_rows_are_bit_
+ *                    identical_to_plain_rows keeps it alive)
  *   check_launches 0  debugging: every stage of a rebuild (migration, reorder, borders, list builder) is synchronised and asked for
  *                    HIP errors, so that a fault names the stage instead of surfacing at the end of meso_run
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */

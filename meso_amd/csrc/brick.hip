@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 #define TB_EXPANDED 0        // 1: distances in the expanded form on brick-relative coordinates (see the scan); 0: (o - c)^2 on absolute ones
 #endif
 #define TB_ROWPAD 64               // entries behind the last staged row (see the scan step)
-#define TB_ROWCAP_MAX 1024         // rows are staged in LDS at their full capacity n_col (2 bytes per entry)
+#define TB_ROWCAP_MAX 1024
+#define TBQ_N 32                   // persistent workgroups: brick counters (BrickArgs::queue)
+#define TBQ_PITCH 32               // ... ints between two of them (a 128-byte line each); [0]: workgroups done         // rows are staged in LDS at their full capacity n_col (2 bytes per entry)
 
 // E: brick edge in bins.  4: the 4x4x4 brick (64 Morton codes, 6x6x6-bin neighbourhood, 10 waves) of rounds 1-2.  2 (default):
 // a 2x2x2 brick (8 codes, 4x4x4-bin neighbourhood, 4 waves of 2 bins each): eight times as many workgroups of a fifth of
@@ -185,10 +187,22 @@ __global__ void __launch_bounds__(256) k_brick_plan(BrickArgs g, int *__restrict
 // The 4-brick remains the fallback when a 2-brick neighbourhood nears its LDS stage (which does not grow).
 // PART: rows in two sections (RowPartArgs, kernels.h); false: plain rows - every entry keeps its place, which spares the row-out the
 // classification and the per-entry address arithmetic (64^3: 177 against 201 us per build; what decks that rebuild on every step use)
-template <int E, bool PART>
-__global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3 : 2) k_tile_build(BrickArgs g, const float4 *__restrict__ coord4, float rc2,
-                                                              int n_col, int *__restrict__ count, int *__restrict__ table,
-                                                              int *__restrict__ overflow, int split, int dbg, RowPartArgs pt)
+// (the body of the kernel for ONE brick: vblock = the workgroup id a launch of one workgroup per brick would have had)
+// (G, P: BrickArgs and RowPartArgs where the caller has them - the by-value kernel argument, or the kernel-argument segment itself
+// read through a constant-address-space reference, see the persistent loop)
+struct TileKArgs {
+    BrickArgs g;
+    const float4 *coord4;
+    float rc2;
+    int n_col;
+    int *count, *table, *overflow;
+    int split, dbg;
+    RowPartArgs pt;
+};
+template <int E, bool PART, typename G, typename P>
+__device__ __forceinline__ void tile_build_brick(G &g, const float4 *__restrict__ coord4, float rc2,
+                                                 int n_col, int *__restrict__ count, int *__restrict__ table,
+                                                 int *__restrict__ overflow, int split, int dbg, P &pt, int vblock)
 {
 #pragma clang fp contract(fast)
     constexpr int CODES = E * E * E, H = E + 2, NHB = H * H * H, THREADS = E == 4 ? BRK_THREADS : TB2_THREADS, WAVES = THREADS / 64;
@@ -201,11 +215,15 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
     unsigned short *rowbuf = (unsigned short *)(hgi + maxh);          // [wave][TB_G][n_col]
     __shared__ int hoff[NHB + 1];
     __shared__ int hloc[NHB];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // (opaque to the optimiser: under the persistent loop everything derived from the thread id would otherwise be hoisted out of the
+    // loop and kept in registers across the whole brick - 95 VGPRs, five waves per SIMD, instead of 70 and seven)
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, w = tid >> 6;
     // few bricks (small boxes, sub-boxes of many ranks): `split` workgroups share one brick, each staging the neighbourhood
     // and taking every split-th group of own bins - a brick then finishes sooner, which is what the launch waits for
-    const int part = (int)blockIdx.x % split;
-    const int slot = (int)blockIdx.x / split;
+    const int part = vblock % split;
+    const int slot = vblock / split;
     if (slot >= g.nactive) return;
     int nh;
     if (g.plan_inline) {
@@ -597,6 +615,55 @@ __global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3
     }
 }
 
+// One workgroup per brick (queue null: the grid covers every brick), or PERSISTENT workgroups (round 6, BrickArgs::queue: the grid is
+// what the card holds at once and every workgroup draws bricks from a counter until none is left - the reference's builder is a
+// grid-stride loop over bins too, neigh_build_meso.cu:58).  The draw for the NEXT brick is posted before this one is staged, so its
+// round trip is hidden; the last workgroup to leave puts the counter back to zero for the next launch (no memset between launches).
+template <int E, bool PART, bool PERSIST = false>
+__global__ void __launch_bounds__(E == 4 ? BRK_THREADS : TB2_THREADS, E == 4 ? 3 : (PERSIST ? 7 : 2)) k_tile_build(TileKArgs a)
+{
+    if constexpr (!PERSIST) {
+        tile_build_brick<E, PART>(a.g, a.coord4, a.rc2, a.n_col, a.count, a.table, a.overflow, a.split, a.dbg, a.pt, (int)blockIdx.x);
+        return;
+    }
+    const BrickArgs &g = a.g;
+    const int split = a.split;
+    // (the first brick is drawn too: should the runtime's occupancy answer exceed what the card really holds at once, the workgroups
+    // that start late find the counters past the end and leave - with blockIdx as the first brick they would add a whole round)
+    // TBQ_N counters, each in a 128-byte line of its own: 15 600 draws from ONE address took as long as the whole build (same-address
+    // atomics of eight XCDs meet at the memory side, ~17 ns each); counter q hands out the bricks q, q + TBQ_N, q + 2 TBQ_N, ...
+    __shared__ int next_vb;
+    const int total = g.nactive * split;
+    const int nq = min(TBQ_N, (int)gridDim.x);      // (every counter needs a workgroup that draws from it)
+    const int q = (int)blockIdx.x % nq;
+    int *ctr = g.queue + TBQ_PITCH * (1 + q);
+    if (threadIdx.x == 0) next_vb = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * nq + q;
+    __syncthreads();
+    int vb = __builtin_amdgcn_readfirstlane(next_vb);      // (scalar, as blockIdx is: the brick's geometry stays SALU work)
+    __syncthreads();
+    while (vb < total) {
+        int drawn = 0;
+        if (threadIdx.x == 0) drawn = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            // the arguments are read from the kernel-argument segment anew for every brick (the pointer is opaque to the optimiser):
+            // kept in scalar registers across the loop they were spilled - 92 SGPRs into lanes of ten more VGPRs, a wave per SIMD less
+            typedef const __attribute__((address_space(4))) TileKArgs *KP;
+            KP ka = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            tile_build_brick<E, PART>(ka->g, ka->coord4, ka->rc2, ka->n_col, ka->count, ka->table, ka->overflow, ka->split, ka->dbg, ka->pt, vb);
+        }
+        if (threadIdx.x == 0) next_vb = drawn * nq + q;
+        __syncthreads();           // every wave is through with the brick's LDS; the next brick's number is there
+        vb = __builtin_amdgcn_readfirstlane(next_vb);
+        __syncthreads();           // ... and read by all before thread 0 writes the one after it
+    }
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(g.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        // the last workgroup out: every other one has made its last draw
+        __hip_atomic_store(g.queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < TBQ_N; k++) __hip_atomic_store(g.queue + TBQ_PITCH * (1 + k), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // =========================================================================================
 // cell structure kernels
 // =========================================================================================
@@ -838,6 +905,7 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
     RowPartArgs pt = {0, 0, nullptr, nullptr, 8};
     if (part) pt = *part;
     if (!pt.nback || !pt.back) { pt.group = 0; pt.back = table; pt.nback = count; }      // (plain rows: nothing is ever written behind)
+    auto kargs = [&](const BrickArgs &gg, int split_, int dbg_) { return TileKArgs{gg, coord4, rc2, n_col, count, table, overflow, split_, dbg_, pt}; };
     // (the scan's expanded distance form loses < 1e-4 absolute to cancellation: the list cutoff is widened by more than that)
     if (TB_EXPANDED) rc2 += 4.0e-4f;
     // few bricks (small boxes, sub-boxes of many ranks): several workgroups share a brick as long as all of them still fit the
@@ -848,16 +916,37 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         // 2x2x2 bricks: eight times as many workgroups of 4 waves
         BrickArgs g2 = g;
         g2.nactive = g.order2 ? g.norder2 : g.M / 8;
-        const dim3 tgrid2((g2.nactive + 7) / 8 * 8);
+        dim3 tgrid2((g2.nactive + 7) / 8 * 8);
         const size_t dyn2 = (size_t)g.maxh2 * 16 + (size_t)(TB2_THREADS / 64) * TB_G * n_col * 2 + TB_ROWPAD * 2;
-        if (pt.group) {
+        if (g2.queue) {
+            // persistent workgroups: as many as are resident at once (asked of the runtime once per stage size and row form)
+            static int per_cu[2] = {0, 0}, ncu = 0;
+            static size_t per_cu_dyn[2] = {0, 0};
+            const int f = pt.group ? 1 : 0;
+            if (!ncu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+            if (!per_cu[f] || per_cu_dyn[f] != dyn2) {
+                if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute(f ? (const void *)k_tile_build<2, true, true> : (const void *)k_tile_build<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
+                int nb = 0;
+                if (f) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile_build<2, true, true>, TB2_THREADS, dyn2);
+                else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile_build<2, false, true>, TB2_THREADS, dyn2);
+                per_cu[f] = nb > 0 ? nb : 1; per_cu_dyn[f] = dyn2;
+            }
+            const int resident = per_cu[f] * (ncu > 0 ? ncu : 256);
+            if (g2.nactive > resident) tgrid2 = dim3(resident); else g2.queue = nullptr;      // (a launch of one round needs no queue)
+        }
+        if (g2.queue) {
+            if (pt.group) hipLaunchKernelGGL((k_tile_build<2, true, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, kargs(g2, 1, dbg));
+            else hipLaunchKernelGGL((k_tile_build<2, false, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, kargs(g2, 1, dbg));
+        } else if (pt.group) {
             if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-            hipLaunchKernelGGL((k_tile_build<2, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, pt);
+            hipLaunchKernelGGL((k_tile_build<2, true>), tgrid2, dim3(TB2_THREADS), dyn2, s, kargs(g2, 1, dbg));
         } else {
             if (dyn2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2);
-            hipLaunchKernelGGL((k_tile_build<2, false>), tgrid2, dim3(TB2_THREADS), dyn2, s, g2, coord4, rc2, n_col, count, table, overflow, 1, dbg, pt);
+            hipLaunchKernelGGL((k_tile_build<2, false>), tgrid2, dim3(TB2_THREADS), dyn2, s, kargs(g2, 1, dbg));
         }
     } else {
+        BrickArgs g4 = g;
+        g4.queue = nullptr;          // (the 4-brick fallback: one workgroup per brick)
         int split = 1;
         while (split < 4 && occupied * split * 2 <= 900) split *= 2;
         if (dbg >= 100) { split = dbg - 100; dbg = 0; }     // timing experiments: pair_debug 110 + split
@@ -866,10 +955,10 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
         if (getenv("MESO_DEBUG_BUILD")) fprintf(stderr, "tile build: bricks %d split %d maxh %d n_col %d LDS %zu mbin %d %d %d\n", g.nactive, split, g.maxh, n_col, dyn, g.mbin[0], g.mbin[1], g.mbin[2]);
         if (pt.group) {
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            hipLaunchKernelGGL((k_tile_build<4, true>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, pt);
+            hipLaunchKernelGGL((k_tile_build<4, true>), tgrid, dim3(BRK_THREADS), dyn, s, kargs(g4, split, dbg));
         } else {
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_build<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            hipLaunchKernelGGL((k_tile_build<4, false>), tgrid, dim3(BRK_THREADS), dyn, s, g, coord4, rc2, n_col, count, table, overflow, split, dbg, pt);
+            hipLaunchKernelGGL((k_tile_build<4, false>), tgrid, dim3(BRK_THREADS), dyn, s, kargs(g4, split, dbg));
         }
     }
     if (excl && excl->tagc && nlocal > 0) {
@@ -880,5 +969,6 @@ void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int 
 }
 
 int tile_build_rowcap() { return TB_ROWCAP_MAX; }
+int tile_build_queue_ints() { return TBQ_PITCH * (1 + TBQ_N); }
 
 } // namespace meso

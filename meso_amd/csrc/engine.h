@@ -311,6 +311,9 @@ private:
     // one rank: the rebuild in three launches (rebuild.hip) - count, place + gather + ghost emission, ghosts
     int *brick_order2 = nullptr;    // launch order of the 2-bricks (those that own real cells, fullest first)
     int brick2 = 1;                 // option: 2x2x2 bricks in the list builder (0: the 4x4x4 bricks of rounds 1-2)
+    int tile_persist = 0;           // option: the 2-brick list builder as persistent workgroups that draw bricks from counters (launches of more than one
+                                    // round; 64^3: 219 against 206 us per build with one workgroup per brick - profiles/r06_notes.md section 1)
+    int *tile_queue = nullptr;      // [2] next brick, workgroups done (put back to zero by the last workgroup of every launch)
     int brick2_limit = 1 << 30;     // ... while the bin grid spans at most this many 4-bricks (measured faster at every size:
                                     // 32^3 77 -> 52 us, 48^3 205 -> 137, 64^3 303 -> 265, 128^3 2257 -> 1784 per build)
     bool brick2_off = false;        // a 2-brick neighbourhood outgrew the largest stage that leaves five workgroups per CU: 4-bricks from then on

@@ -89,7 +89,7 @@ void Engine::free_all()
     sort_temp = nullptr;
     dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(mr_gcnt); dfree(mig_cnt); dfree(mig_lst); dfree(d_vofs); dfree(d_center27);
     dfree(binrange);
-    dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own); dfree(brick_order2);
+    dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own); dfree(brick_order2); dfree(tile_queue);
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
     dfree(d_partial); dfree(d_scalar); dfree(d_flags); dfree(sendlist_aux); dfree(d_mr);
     if (stage_send) (void)hipFree(stage_send);
@@ -325,6 +325,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "split_gather") { split_gather = (int)val; return 0; }
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
+    if (key == "tile_persist") { tile_persist = (int)val; return 0; }
     if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
@@ -1515,6 +1516,11 @@ int Engine::build_cells_and_table()
                 bb.gcnt = (fused_active && fused_gcnt_valid) ? fr_gcnt : (mr_runs ? mr_gcnt : nullptr);
                 if (brick2_off || !brick2) bb.maxh2 = 0;
                 bb.brick2_limit = brick2_limit;
+                if (tile_persist && !tile_queue) {
+                    HIPCHK(dalloc(tile_queue, (size_t)tile_build_queue_ints()));
+                    HIPCHK(hipMemsetAsync(tile_queue, 0, (size_t)tile_build_queue_ints() * sizeof(int), stream));
+                }
+                bb.queue = tile_persist ? tile_queue : nullptr;
                 // partitioned rows (RowPartArgs): the pairing group is the ring kernel's workgroup for a launch over this rank's atoms
                 // (every force launch of the interval is then made with the same lanes per atom, launch_pair)
                 // (not for the wide records of more than 2^25 atoms on a rank, whose launches walk one row per atom)

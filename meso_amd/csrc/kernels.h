@@ -238,6 +238,7 @@ struct BrickArgs {
     int maxown;          // atoms a brick may own (0: unlimited - only the brick-layout kernels have a static bound)
     int nactive;         // launch bound: number of active bricks, or of all bricks when the count is only on the device
     const int *nactive_dev;   // null: nactive is exact
+    int *queue;          // tile list builder, 2-bricks: null = one workgroup per brick; else tile_build_queue_ints() zeroed ints (workgroups done, brick counters): persistent workgroups
     // written by the plan kernel once per rebuild (pitches: brick_*_pitch())
     int *hoff;           // [slot][217] first halo slot of each halo bin
     uint32_t *hmap;      // [slot][nh]  halo slot -> global atom index
@@ -275,6 +276,7 @@ struct RowPartArgs {
     int nb_col;
 };
 // cell-ordered layout: wave-per-bin ballot builder on the LDS-staged neighbourhood, chunked-8 global-index rows
+int tile_build_queue_ints();
 void launch_tile_build(const BrickArgs &g, const float4 *coord4, float rc2, int n_col, int *count, int *table, int *overflow,
                        const ExclArgs *excl, int nlocal, int dbg, hipStream_t s, const RowPartArgs *part = nullptr);
 int tile_build_rowcap();

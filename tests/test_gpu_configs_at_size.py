@@ -311,7 +311,10 @@ def test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows(style):
     # (third and fourth variant - the rebuild at this size, more than 4096 tiles of cells: the count kernel on its own instead of in
     # the force kernel's epilogue, per-atom reads in the step boundary; the chain of small launches instead of the fused rebuild)
     for opts in ((("row_part", 1),), (("row_part", 0), ("xcd_balance", 0), ("ghost_epilogue", 0)),
-                 (("row_part", 1), ("fuse_count", 0), ("lean_boundary", 0)), (("row_part", 1), ("fused_rebuild", 0))):
+                 (("row_part", 1), ("fuse_count", 0), ("lean_boundary", 0)), (("row_part", 1), ("fused_rebuild", 0)),
+                 # tile_persist: the list builder as persistent workgroups drawing bricks from counters (round 6; measured 6 % slower
+                 # than one workgroup per brick, default off) - the same table, entry for entry
+                 (("row_part", 1), ("tile_persist", 1)), (("row_part", 0), ("tile_persist", 1))):
         with Meso() as m:
             for k, val in opts:
                 m.set_option(k, val)
