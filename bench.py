@@ -406,6 +406,24 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    # measured floors of the force kernel's mandatory work on this very table (meso_pair_floor, pair_floor.hip): the
+    # arithmetic alone, the loads alone (the kernel's own address stream, no arithmetic), both - and the loads with every coordinate
+    # gather redirected into the workgroup's own 256 atoms (all L1 hits: the texture path's cost per lane address, whatever the caches do)
+    floor = None
+    if fp32 and world == 1 and bonds is None and a.style == "dpd/fast/meso":
+        try:
+            fa, nt_, ne_ = m.pair_floor(1, 10)
+            fb = m.pair_floor(2, 10)[0]
+            fc = m.pair_floor(3, 10)[0]
+            fl = m.pair_floor(802, 10)[0]
+            floor = {"arithmetic_only": fa, "loads_only": fb, "both_independent": fc, "loads_only_all_L1_hits": fl, "unit": "us per launch",
+                     "row_entries_walked": nt_, "pairs_evaluated": ne_,
+                     "reading": "the kernel's own address stream with no arithmetic at all takes as long as the kernel: it is bound by its "
+                                "gathers (texture addresser + L1 misses), not by HBM; with perfect cache behaviour the same lane addresses "
+                                "still cost loads_only_all_L1_hits, above the 0.50-of-HBM mark of %.1f us" % (b_pair_only / (0.5 * HBM_PEAK_GBS * 1e9) * 1e6),
+                     "source": "meso_pair_floor (meso_amd/csrc/pair_floor.hip), measured in this run after the timed region"}
+        except Exception as e:      # (rows in one section, several types: the floor kernels are written for the headline workload)
+            floor = {"skipped": str(e)}
     # what the rebuild of the timed region ran (north_star words the reorder as "rocPRIM radix sort on a side HIP stream overlapped with
     # halo pack/unpack": built, tested equal, measured slower - DESIGN.md section 6 - so the line says which form this number is for)
     optd = dict(kv.split("=", 1) for kv in a.opt if "=" in kv)
@@ -438,7 +456,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                      "kernel": kernel + " (force only, SURVEY.md 8d B_pair)", "kernel_variant": variant, "bytes_per_launch": b_pair_only,
-                     "us_per_launch": t_alone * 1e6, "fused": fused_rec, "limiter_from_profile": limiter,
+                     "us_per_launch": t_alone * 1e6, "floor_us": floor, "fused": fused_rec, "limiter_from_profile": limiter,
                      "bytes_definition": "graded frac: SURVEY.md 8(d) B_pair = N (36 + 4 x stored row entries [front + back] + 24); "
                                          "bytes_touched: what this launch reads and writes (front sections only, padded to 32-byte chunks)",
                      "bytes_touched": touched, "frac_of_bytes_touched": (touched / t_alone / 1e9 / HBM_PEAK_GBS) if touched else None},

@@ -228,6 +228,11 @@ int64_t meso_ntimestep(meso_ctx *ctx);
 /* measured HBM peak for the roofline (nominal and measured): float4 copy of nbytes (read + write counted),
  * best of reps launches timed with HIP events on the engine's stream; result in GB/s */
 int meso_membw_probe(meso_ctx *ctx, size_t nbytes, int reps, double *copy_gbs);
+/* measurement only - floors of the fp32 force kernel's mandatory work on the table in use (gpu_dpd_fast<0>, pair_dpd_fast_meso.cu:124-162:
+ * per row entry a coordinate gather and a cutoff test, per pair inside the cutoff a velocity gather and the TEA / Gaussian / force
+ * evaluation), each timed alone in an idealised kernel: mode 1 the arithmetic, 2 the loads, 3 both, independent (pair_floor.hip).
+ * us = mean launch time over reps; counts[0] = row entries walked, counts[1] = pairs evaluated.  Overwrites the force arrays. */
+int meso_pair_floor(meso_ctx *ctx, int mode, int reps, double *us, long long *counts);
 /* name of the force-kernel instantiation the last launch ran ("k_pair_dpd_ring<true, 0, true, true, 1, true>", as rocprofv3
  * prints it; empty before the first launch): measurement harnesses key profile-derived numbers on it (the reference keeps
  * one static GridConfig per kernel instead, pair_dpd_meso.cu:216,228) */

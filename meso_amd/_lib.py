@@ -33,6 +33,7 @@ SIGNATURES = {
     "meso_decomp_plan": (_i, [_vp, _vp, _vp, _vp, _i, _d] + [_vp] * 8),
     "meso_comm_count": (_i, [_vp, C.POINTER(_i)]),
     "meso_membw_probe": (_i, [_vp, _sz, _i, C.POINTER(_d)]),
+    "meso_pair_floor": (_i, [_vp, _i, _i, C.POINTER(_d), C.POINTER(C.c_longlong)]),
     "meso_pair_kernel_name": (_i, [_vp, C.c_char_p, _i]),
     "meso_tally_ev": (_i, [_vp]),
     "meso_xchg_stats": (_i, [_vp, C.c_char_p, _i]),

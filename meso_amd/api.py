@@ -391,6 +391,14 @@ class Meso:
         self._ck(self.lib.meso_membw_probe(self._h, int(nbytes), int(reps), C.byref(g)))
         return g.value
 
+    def pair_floor(self, mode, reps=20):
+        """Measured floor of the fp32 force kernel's mandatory work on the table in use (meso_pair_floor): mode 1 arithmetic, 2 loads,
+        3 both.  Returns (us per launch, row entries walked, pairs evaluated)."""
+        us = C.c_double()
+        cnt = (C.c_longlong * 2)()
+        self._ck(self.lib.meso_pair_floor(self._h, int(mode), int(reps), C.byref(us), cnt))
+        return us.value, int(cnt[0]), int(cnt[1])
+
     def timer(self, name):
         ms, calls = C.c_double(), C.c_int64()
         self._ck(self.lib.meso_timer_get(self._h, name.encode(), C.byref(ms), C.byref(calls)))

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libmeso_hip.so")
-SOURCES = ["pair_ring.hip", "pair_ring_dp.hip", "kernels.hip", "brick.hip", "rebuild.hip", "bond.hip", "sort.hip", "engine.hip", "restart.hip", "comm.hip", "script.hip", "capi.hip"]
+SOURCES = ["pair_ring.hip", "pair_ring_dp.hip", "pair_floor.hip", "kernels.hip", "brick.hip", "rebuild.hip", "bond.hip", "sort.hip", "engine.hip", "restart.hip", "comm.hip", "script.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 

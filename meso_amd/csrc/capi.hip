@@ -247,6 +247,14 @@ int meso_xchg_stats(meso_ctx *ctx, char *buf, int nbuf)
     snprintf(buf, (size_t)nbuf, "%s", ctx->eng->xchg_report().c_str());
     return 0;
 }
+int meso_pair_floor(meso_ctx *ctx, int mode, int reps, double *us, long long *counts)
+{
+    CTX(ctx);
+    long c[2] = {0, 0};
+    const int rc = E.pair_floor(mode, reps, us, c);
+    if (counts) { counts[0] = c[0]; counts[1] = c[1]; }
+    RET(rc);
+}
 int meso_neigh_parts(meso_ctx *ctx, int *parted, int *group, int *nfront, int *nback, int *front, int *back, int stride)
 {
     CTX(ctx);

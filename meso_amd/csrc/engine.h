@@ -122,6 +122,7 @@ public:
     void xchg_events_flush();
     bool rccl_first_done = false;   // the first RCCL group of this communicator has completed (bounded wait, comm.hip xchg)
     int membw_probe(size_t nbytes, int reps, double *gbs);
+    int pair_floor(int mode, int reps, double *us, long *counts);      // pair_floor.hip: measured floors of the force kernel's mandatory work
 
     std::string err;
     int64_t ntimestep = 0;
