@@ -1839,6 +1839,17 @@ int Engine::halo_forward_multi_begin(uint32_t sd, bool async)
     int rc = xchg(np, peers.data(), sb.data(), sn.data(), rb.data(), rn.data(), direct ? rb2.data() : nullptr);
     xs = nullptr;
     if (rc) return rc;
+    if (debug_early_reuse && nsend > 0) {
+        // tests only (tests/test_gpu_rccl_branch.py): the send staging is overwritten from a stream that waits for nothing - the hazard
+        // an asynchronous transport adds and a host-synchronous stand-in cannot see
+        if (!debug_stream) HIPCHK(hipStreamCreateWithFlags(&debug_stream, hipStreamNonBlocking));
+        HIPCHK(hipMemsetAsync(stage_send, 0xFF, std::min<size_t>((size_t)nsend * 2 * sizeof(float4), 1 << 16), debug_stream));
+        // (it races with this exchange only: whatever the engine does next on its own streams waits for the scribble)
+        if (!debug_event) HIPCHK(hipEventCreateWithFlags(&debug_event, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(debug_event, debug_stream));
+        HIPCHK(hipStreamWaitEvent(stream, debug_event, 0));
+        HIPCHK(hipStreamWaitEvent(side, debug_event, 0));
+    }
     if (nghost > 0 && !direct) {
         PeerTab P;
         P.np = np;

@@ -146,6 +146,18 @@ private:
     int reorder_locals();
     int migrate();
     int check_overflow();
+    // a rebuild whose capacities were outgrown is redone inside run() (PairArgs::poison keeps the state; engine.hip prepare_redo)
+    static constexpr int MESO_REDO = -7001, MESO_DEEPER = -7002;
+    bool in_reneighbor = false;
+    int reneighbor_once();
+    int prepare_redo(int code);
+    bool redo_armed = false, ck_swapped = false;
+    int ck_nlocal = 0;
+    long nredo = 0;              // rebuilds redone so far (meso_neigh_info-style introspection for the tests: option query below)
+    int debug_early_reuse = 0;   // option (tests): the refresh's send staging is scribbled from an unordered stream right behind the exchange
+    hipStream_t debug_stream = nullptr;
+    hipEvent_t debug_event = nullptr;
+    int debug_ghost_cap = 0;     // option (tests): the NEXT asynchronous rebuild reserves this many ghosts only
     double reduce_global_sum(double v);
     // multi-rank (comm.hip)
     int xchg(int np, const int *peer, void *const *sbuf, const size_t *sbytes, void *const *rbuf, const size_t *rbytes, void *const *rbuf2 = nullptr);

@@ -172,6 +172,8 @@ int Engine::timer_reset()
 
 int Engine::timer_get(const std::string &name, double *ms, int64_t *calls)
 {
+    // (a counter, not a timer: rebuilds that outgrew a capacity and were redone through the synchronous path, engine.hip prepare_redo)
+    if (name == "rebuilds_redone") { if (ms) *ms = 0.0; if (calls) *calls = nredo; return 0; }
     tflush();
     auto it = timers.find(name);
     if (ms) *ms = it == timers.end() ? 0.0 : it->second.ms;
@@ -326,6 +328,8 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
     if (key == "tile_persist") { tile_persist = (int)val; return 0; }
+    if (key == "debug_early_reuse") { debug_early_reuse = (int)val; return 0; }
+    if (key == "debug_ghost_cap") { debug_ghost_cap = (int)val; return 0; }      // tests: the next asynchronous rebuild reserves this many ghosts only
     if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
     if (key == "profile") { tflush(); profiling = val != 0.0; return 0; }
     if (key == "neigh_kernel") { neigh_kernel = (int)val; return 0; }
@@ -1126,7 +1130,7 @@ int Engine::reorder_locals()
                              images_on() ? img_cnt : nullptr, stream);
     }
     merged_in_reorder = true;      // (alloc_atoms clears it: a regrown coord4 has lost the values)
-    std::swap(cur, alt);
+    std::swap(cur, alt); ck_swapped = !ck_swapped;
     if (!(nranks == 1 && async_ok())) HIPCHK(hipMemcpyAsync(h_flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     tend("reorder");
     if ((nranks == 1 && (nlocal <= 524288 || async_ok())) || (nranks > 1 && nlocal <= 524288)) {
@@ -1194,7 +1198,7 @@ int Engine::rebuild_overlapped()
                          0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep), perm_inverse,
                          images_on() ? img_cnt : nullptr, stream);
     merged_in_reorder = true;
-    std::swap(cur, alt);
+    std::swap(cur, alt); ck_swapped = !ck_swapped;
     // ---- join
     HIPCHK(hipStreamWaitEvent(stream, ev_ghosts, 0));
     launch_translate_list(sendlist, perm_inverse, nsend, ng_dev, estart + bargs.M, h_flags_dev, stream);
@@ -1336,12 +1340,13 @@ int Engine::rebuild_fused()
     a.sendlist = sendlist; a.senddir = senddir;
     a.img_cnt = images_on() ? img_cnt : nullptr; a.img = img;
     a.ghost_cap = std::min(nmax - nlocal - 1, send_cap);
+    if (debug_ghost_cap > 0) { a.ghost_cap = std::min(a.ghost_cap, debug_ghost_cap); debug_ghost_cap = 0; }
     a.dir_start = d_dir_start;
     a.report = h_flags_dev;
     a.merged_ghosts = merge_ghosts ? 1 : 0;      // (honoured with the order-only placing kernel: launch_fused_rebuild)
     launch_fused_rebuild(a, stream, count_in_epilogue);
     count_in_epilogue = false;
-    std::swap(cur, alt);
+    std::swap(cur, alt); ck_swapped = !ck_swapped;
     merged_in_reorder = true;
     if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ev_counts, stream));
@@ -1366,7 +1371,8 @@ int Engine::halo_borders()
         // `bound` sizes the grids of the ghost kernels (they loop, so any count is covered); the hard limit is the capacity
         int bound = (int)(nghost_prev * async_grid_scale) + 1024;
         TRY(ensure_capacity(nlocal + bound + bound / 2));
-        const int cap_bound = std::min(nmax - nlocal - 1, send_cap);
+        int cap_bound = std::min(nmax - nlocal - 1, send_cap);
+        if (debug_ghost_cap > 0) { cap_bound = std::min(cap_bound, debug_ghost_cap); debug_ghost_cap = 0; }
         // border scan: every local atom in small boxes; in large ones from a little before the previous border section
         int beg = 0;
         if (nlocal > 524288) beg = std::max(0, n_bulk_prev - n_bulk_prev / 64 - 4096) & ~255;
@@ -1564,13 +1570,43 @@ int Engine::resolve_counts()
     HIPCHK(hipEventSynchronize(ev_counts));
     counts_pending = false;
     bulk_pending = false;
-    if (h_flags[8]) { mr_pending = false; return check_overflow(); }
+    if (h_flags[8]) {
+        mr_pending = false;
+        // One rank, inside run(): an outgrown ghost list / border range / cell bucket poisoned every launch behind the rebuild that
+        // reported it (PairArgs::poison, the NVE kernels): the state is still what that rebuild was given.  run() goes back to it.
+        const int code = h_flags[8];
+        if (nranks == 1 && redo_armed && (code == 200000 || code == 200001 || code >= 300000)) return prepare_redo(code);
+        return check_overflow();
+    }
     n_bulk = h_flags[9];
     for (int k = 0; k < 28; k++) h_dir_start[k] = (fused_active && k < 27) ? 0 : h_flags[16 + k];      // (fused rebuild: no direction segments)
     if (mr_pending) return mr_resolve();
     nsend = nghost = h_dir_start[27];
     nghost_prev = nghost; n_bulk_prev = n_bulk;
     return 0;
+}
+
+// The rebuild at checkpoint `ck` reported an outgrown capacity (resolve_counts).  Every launch behind it was a no-op; the atoms it
+// reordered from are still in `alt` (the reorder gathers, it does not move).  Back to them, and the rebuild runs again through the
+// synchronous path (exact counts, capacities regrown) - MesoComm::borders grows its buffers on the fly too (comm_meso.cu:122,138,179-181).
+int Engine::prepare_redo(int code)
+{
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+    h_flags[0] = h_flags[8] = 0;
+    counts_pending = bulk_pending = false;
+    count_in_epilogue = false;
+    nghost_prev = -1;            // the redone rebuild (and only it) takes the synchronous path
+    fused_dirty = true;
+    if (code >= 300000) {
+        // a cell bucket and the overflow list together were too small: twice the bucket from here on
+        fr_cap_user = 0;
+        fr_cap_want = std::max(fr_cap_want, fr_cap) * 2;
+    }
+    if (ck_swapped) { std::swap(cur, alt); ck_swapped = false; }
+    nlocal = ck_nlocal;
+    nredo++;
+    return MESO_REDO;
 }
 
 int Engine::check_overflow()
@@ -1604,6 +1640,18 @@ int Engine::check_overflow()
             return fail(4, h_flags[0] == 200000 ? "Ghost list outgrew the capacity reserved from the previous rebuild (the ghost count rose by more "
                                                   "than two thirds within one rebuild interval): run again with option async_counts 0"
                                                 : "Border section moved in front of the scanned range: run again with option async_counts 0");
+        }
+        if (h_flags[0] >= 300000 && nranks == 1 && in_reneighbor) {
+            // seen by the rebuild itself (synchronous path): buckets twice as deep, and reneighbor() builds again from the arrays the
+            // reorder gathered from
+            HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
+            h_flags[0] = 0;
+            counts_pending = bulk_pending = false;
+            nghost_prev = -1;
+            fused_dirty = true;
+            fr_cap_user = 0;
+            fr_cap_want = std::max(fr_cap_want, fr_cap) * 2;
+            return MESO_DEEPER;
         }
         if (h_flags[0] >= 300000) {
             HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), stream));
@@ -1644,6 +1692,21 @@ int Engine::launch_check(const char *stage)
 int Engine::reneighbor()
 {
     TRY(resolve_counts());       // the previous rebuild's counts (long since arrived) size this one
+    int rc = 0;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        in_reneighbor = true;
+        rc = reneighbor_once();
+        in_reneighbor = false;
+        if (rc != MESO_DEEPER) break;
+        if (ck_swapped) { std::swap(cur, alt); ck_swapped = false; }      // (the reorder gathered from intact arrays)
+    }
+    return rc == MESO_DEEPER ? fail(4, "Fused rebuild: a cell holds more atoms than eight doublings of its bucket can take") : rc;
+}
+
+int Engine::reneighbor_once()
+{
+    TRY(resolve_counts());
+    ck_swapped = false; ck_nlocal = nlocal;      // (what prepare_redo needs to undo THIS rebuild, should its report ask for it)
     {
         // denser than expected (chains, phase separation): the LDS stage of a brick neighbourhood grows BEFORE it overflows - the
         // high-water mark of the earlier list builds came with the count report (or with the last check_overflow)
@@ -1730,7 +1793,7 @@ int Engine::decide(int *rebuild)
 int Engine::nve_initial()
 {
     tbegin("nve");
-    launch_nve_initial(cur, 0.5 * dt, dt, groupbit, nlocal, stream);
+    launch_nve_initial(cur, 0.5 * dt, dt, groupbit, nlocal, stream, d_flags);
     tend("nve");
     return 0;
 }
@@ -1738,7 +1801,7 @@ int Engine::nve_initial()
 int Engine::nve_final()
 {
     tbegin("nve");
-    launch_nve_final(cur, 0.5 * dt, groupbit, nlocal, stream);
+    launch_nve_final(cur, 0.5 * dt, groupbit, nlocal, stream, d_flags);
     tend("nve");
     return 0;
 }
@@ -1773,6 +1836,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     p.table_back = pair_back; p.nb_col = nb_col;
     p.part_group = part_group;
     p.range_flag = d_flags + 7;
+    p.poison = d_flags;
     if (rows_part) p.npart = 4 * 64 / part_group;      // every launch of the interval pairs inside the groups the rows were partitioned for
     p.poly = pair_poly ? d_poly : nullptr;
     p.ftab = pair_ftab ? d_ftab : nullptr;
@@ -1893,18 +1957,46 @@ int Engine::run(int nsteps)
     if (!is_setup) return fail(3, "run before setup");
     tbegin("total_steps");
     bool initial_done = false, merged = false, ghosts_by_epilogue = false;
-    for (int it = 0; it < nsteps; it++) {
+    // checkpoint of the last rebuild of this run (host side; the device side is the untouched state itself, see prepare_redo)
+    int ck_it = -1, ck_ago = 0, redo_pending = 0;
+    int64_t ck_step = 0;
+    // TRY inside the loop: a rebuild of this run that has to be redone (MESO_REDO from resolve_counts) restarts the loop at its step
+#define TRY_STEP(call)                                                              \
+    do {                                                                            \
+        int _rc = (call);                                                           \
+        if (_rc == MESO_REDO && ck_it >= 0) { redo_pending = 1; goto redo_rebuild; } \
+        if (_rc) { redo_armed = false; return _rc == MESO_REDO ? fail(4, "A rebuild outgrew its capacities outside a run") : _rc; } \
+    } while (0)
+    redo_armed = true;
+    for (int it = 0; it <= nsteps; it++) {
+        if (it == nsteps) {
+            // the end of the run: the last rebuild's report is read here, while it can still be redone
+            TRY_STEP(resolve_counts());
+            break;
+        }
+        if (false) {
+        redo_rebuild:
+            // back to the step of the rebuild that failed: its initial integration is part of the state, the rebuild is due again
+            it = ck_it; ntimestep = ck_step - 1; ago = ck_ago;
+            initial_done = true; merged = false; ghosts_by_epilogue = false;
+        }
         profile_tick(it, nsteps);
         ntimestep++;
         if (!initial_done) TRY(nve_initial());
         int rebuild = 0;
-        TRY(decide(&rebuild));
+        if (redo_pending) { rebuild = 1; ago++; }
+        else TRY(decide(&rebuild));
         bool ghosts_fresh = false;
         if (rebuild) {
+            const int ago_before = ago - 1;
             permute_forces = false;                     // this step's force kernel overwrites them
             int rr = reneighbor();
             permute_forces = true;
-            if (rr) return rr;
+            // (MESO_REDO here: the report of the PREVIOUS rebuild, read at the top of reneighbor - the checkpoint still names it)
+            if (rr == MESO_REDO && !redo_pending && ck_it >= 0) { redo_pending = 1; goto redo_rebuild; }
+            if (rr) { redo_armed = false; return rr == MESO_REDO ? fail(4, "A rebuild outgrew its capacities twice in a row") : rr; }
+            ck_it = it; ck_step = ntimestep; ck_ago = ago_before;
+            redo_pending = 0;
             merged = true; ghosts_fresh = true;    // the rebuild merged with this step's seed
         }
         // the step in front of a rebuild inside this run: its force launch can run the rebuild's count in its epilogue (arrays may be
@@ -1915,7 +2007,7 @@ int Engine::run(int nsteps)
             const int a1_ = ago + 1;
             const bool next_rebuild_ = dist_check || (a1_ >= delay && a1_ % every == 0);
             const bool fusable = fuse_pair && fuse_step && it + 1 < nsteps && (!have_bonds || nbondtypes > 0) && ring_selected() && nranks == 1;
-            if (next_rebuild_ && fusable) TRY(prepare_count_in_epilogue(frc_args, count_here));
+            if (next_rebuild_ && fusable) TRY_STEP(prepare_count_in_epilogue(frc_args, count_here));
         }
         u32 sd = premix_tea<64>((u32)seed, (u32)ntimestep);
         if (!merged) TRY(merge_locals(sd));
@@ -2016,7 +2108,7 @@ int Engine::run(int nsteps)
             tbegin("nve");
             launch_nve_boundary(cur, 0.5 * dt, dt, groupbit, nlocal, next_rebuild ? 0 : 1, coord4, veloc4,
                                 0.5 * (subhi[0] + sublo[0]), 0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]),
-                                premix_tea<64>((u32)seed, (u32)(ntimestep + 1)), stream);
+                                premix_tea<64>((u32)seed, (u32)(ntimestep + 1)), stream, d_flags);
             tend("nve");
             initial_done = true;
             merged = !next_rebuild;
@@ -2029,6 +2121,8 @@ int Engine::run(int nsteps)
         }
         ev_valid = false;
     }
+#undef TRY_STEP
+    redo_armed = false;
     tend("total_steps");
     profile_tick(nsteps, nsteps);
     TRY(resolve_counts());

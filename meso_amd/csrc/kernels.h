@@ -33,11 +33,12 @@ struct HaloShift { double prd[3]; };
 //      domain_meso.cu:30-145, memory_meso.h:17, atom_vec_meso.h:90) -------------------------------------
 void launch_merge_xvt(const AtomSoA &a, float4 *coord4, float4 *veloc4, double cx, double cy, double cz,
                       uint32_t seed, int beg, int end, hipStream_t s);
-void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s);
-void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s);
+// (poison, nullable: a device flag - non-zero: the kernel changes nothing; Engine::run redoes the rebuild that raised it)
+void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s, const int *poison = nullptr);
+void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s, const int *poison = nullptr);
 // final(step s) + initial(step s+1) [+ merge for step s+1] in one pass
 void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, int merge, float4 *coord4,
-                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s);
+                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s, const int *poison = nullptr);
 void launch_sum_mv2(const AtomSoA &a, int groupbit, int n, double *partial, double *result, hipStream_t s);
 void launch_pbc(const AtomSoA &a, const double *boxlo, const double *boxhi, const int *periodic, int n,
                 hipStream_t s);
@@ -202,6 +203,10 @@ struct PairArgs {
     // ring kernel, fp32 styles: set to 1 when the 32-bit fixed-point force sum of an atom (16 fractional bits: +-32768 force units)
     // is beyond half its range (nullable).  Engine::check_overflow turns it into an error instead of a silently wrapped force.
     int *range_flag;
+    // non-zero: a rebuild of this interval reported an outgrown capacity (ghost list, cell bucket, border message).  The launch then
+    // computes but STORES nothing - no step boundary, no forces, no rebuild count - so the state stays what the rebuild left and
+    // Engine::run can redo that rebuild through the synchronous path (requested at kernel entry, looked at in front of the epilogue)
+    const int *poison;
 };
 void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 // fp32 style on chunked-8 rows: light cutoff scan per lane, hits compacted into a per-wave LDS ring of 4-byte

@@ -52,8 +52,9 @@ __global__ void __launch_bounds__(256) k_nve_initial(double *__restrict__ x, dou
                                                      const double *__restrict__ fx, const double *__restrict__ fy,
                                                      const double *__restrict__ fz, const int *__restrict__ mask,
                                                      const double *__restrict__ mass, double dtf, double dtv,
-                                                     int groupbit, int n)
+                                                     int groupbit, int n, const int *__restrict__ poison)
 {
+    if (poison && *poison) return;      // a rebuild of this interval reported an outgrown capacity: the state waits for its redo (Engine::run)
     for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (mask[i] & groupbit) {
             double dtfm = dtf * rcp_poly(mass[i]);
@@ -64,11 +65,11 @@ __global__ void __launch_bounds__(256) k_nve_initial(double *__restrict__ x, dou
     }
 }
 
-void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s)
+void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s, const int *poison)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_nve_initial, dim3(capgrid(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], a.v[0], a.v[1],
-                       a.v[2], a.f[0], a.f[1], a.f[2], a.mask, a.mass, dtf, dtv, groupbit, n);
+                       a.v[2], a.f[0], a.f[1], a.f[2], a.mask, a.mass, dtf, dtv, groupbit, n, poison);
 }
 
 // gpu_fix_NVE_final_integrate (fix_nve_meso.cu:157-178)
@@ -76,8 +77,9 @@ __global__ void __launch_bounds__(256) k_nve_final(double *__restrict__ vx, doub
                                                    double *__restrict__ vz, const double *__restrict__ fx,
                                                    const double *__restrict__ fy, const double *__restrict__ fz,
                                                    const int *__restrict__ mask, const double *__restrict__ mass,
-                                                   double dtf, int groupbit, int n)
+                                                   double dtf, int groupbit, int n, const int *__restrict__ poison)
 {
+    if (poison && *poison) return;
     for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (mask[i] & groupbit) {
             double dtfm = dtf * rcp_poly(mass[i]);
@@ -86,11 +88,11 @@ __global__ void __launch_bounds__(256) k_nve_final(double *__restrict__ vx, doub
     }
 }
 
-void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s)
+void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s, const int *poison)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_nve_final, dim3(capgrid(n, 256)), dim3(256), 0, s, a.v[0], a.v[1], a.v[2], a.f[0], a.f[1],
-                       a.f[2], a.mask, a.mass, dtf, groupbit, n);
+                       a.f[2], a.mask, a.mass, dtf, groupbit, n, poison);
 }
 
 // Step boundary fused into one pass over the particles: final_integrate of step s, initial_integrate of step s+1
@@ -98,18 +100,19 @@ void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStre
 // the three separate kernels, so results are bit-identical; it saves two launches and re-reading v, f, x
 // (56 -> ~30 us per step on the 64^3 box).
 __global__ void __launch_bounds__(256) k_nve_boundary(NveArgs a, const double *__restrict__ fx, const double *__restrict__ fy,
-                                                      const double *__restrict__ fz, int n)
+                                                      const double *__restrict__ fz, int n, const int *__restrict__ poison)
 {
+    if (poison && *poison) return;
     for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         nve_boundary_atom(a, i, fx[i], fy[i], fz[i]);
 }
 
 void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, int merge, float4 *coord4,
-                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s)
+                         float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s, const int *poison)
 {
     if (n <= 0) return;
     NveArgs nv = make_nve_args(a, dtf, dtv, groupbit, merge, coord4, veloc4, cx, cy, cz, seed_next);
-    hipLaunchKernelGGL(k_nve_boundary, dim3(capgrid(n, 256)), dim3(256), 0, s, nv, a.f[0], a.f[1], a.f[2], n);
+    hipLaunchKernelGGL(k_nve_boundary, dim3(capgrid(n, 256)), dim3(256), 0, s, nv, a.f[0], a.f[1], a.f[2], n, poison);
 }
 
 NveArgs make_nve_args(const AtomSoA &a, double dtf, double dtv, int groupbit, int merge, float4 *coord4_next,

@@ -57,6 +57,7 @@ struct FloorArgs {
     int *nhits;         // [waves]
     double *f[3];
     int *overflow;
+    int drop16;
     int cu_map;         // experiments: 1 = workgroups that the dispatcher places on one CU in its first round take adjacent groups of atoms
     u32 local_mask;     // experiments: 0 = the real partner indices; else partner -> (own group base) + (index & mask): every gather inside a window
 };
@@ -148,7 +149,9 @@ __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
     u32 fold = 0;
     u32 inside = 0;
     const u32 lmask = a.local_mask, lbase = (u32)base;
-    auto jx = [&](u32 j) -> u32 { return lmask ? lbase + (j & lmask) : j; };
+    const u32 drop = (u32)a.drop16;
+    // (drop16: experiments - that many sixteenths of the entries, picked by a hash of the partner index, are not fetched: out-of-range offset)
+    auto jx = [&](u32 j) -> u32 { if (drop && ((j * 2654435761u) >> 28) < drop) return 0x0FFFFFFFu; return lmask ? lbase + (j & lmask) : j; };
 
     // ---- per row entry: gather + distance test
     auto tests = [&](int k) {       // 64 full-lane tests on LDS operands: 3 sub, 3 mul/fma, 2 compares - the mandatory part of a cutoff test
@@ -279,6 +282,8 @@ __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
 int Engine::pair_floor(int mode, int reps, double *us, long *counts)
 {
     u32 local_mask = 0;
+    int drop16 = 0;
+    if (mode >= 10000) { drop16 = mode / 10000; mode %= 10000; }      // 10000 d + m: mode m with d sixteenths of the coordinate gathers not fetched
     if (mode >= 100) { local_mask = (1u << (mode / 100)) - 1u; mode %= 100; }
     int cu_map = 0;
     if (mode >= 50) { cu_map = 1; mode -= 50; }      // 50 + m: mode m with CU-local groups      // experiments: 800 + m = mode m with every gather inside a 256-atom window
@@ -299,7 +304,7 @@ int Engine::pair_floor(int mode, int reps, double *us, long *counts)
     a.nall = (int)std::min<long>((long)nlocal + nghost, (1L << 28) - 1);
     a.cutsq = (float)coeff[P_CUTSQ]; a.cutinv = (float)coeff[P_CUTINV]; a.a0 = (float)coeff[P_A0]; a.gamma = (float)coeff[P_GAMMA];
     a.sigma = (float)coeff[P_SIGMA]; a.dtis = (float)(1.0 / std::sqrt(dt));
-    a.hits = hits; a.nhits = nh; a.overflow = ovf; a.local_mask = local_mask; a.cu_map = cu_map;
+    a.hits = hits; a.nhits = nh; a.overflow = ovf; a.local_mask = local_mask; a.cu_map = cu_map; a.drop16 = drop16;
     for (int d = 0; d < 3; d++) a.f[d] = cur.f[d];
     hipLaunchKernelGGL(k_floor_prepare, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a);
     std::vector<int> hn((size_t)nw + 1);

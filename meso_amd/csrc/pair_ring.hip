@@ -112,6 +112,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     k_pair_dpd_ring(PairArgs a)
 {
     prefetch_kernargs<sizeof(PairArgs)>();
+    // (requested now, looked at in front of the epilogue's stores: no wait of its own)
+    const int poisoned = a.poison ? *a.poison : 0;
     // (no contraction left to the compiler: the pair evaluation is inlined at every drain point of the light phase, and copies that
     // fuse different multiply-adds would give one pair two forces that differ in the last bit, depending on which copy - and, for a
     // pair evaluated from both sides, which side - got it.  The fused operations of the fp32 style are written out below.)
@@ -459,6 +461,8 @@ __global__ void __launch_bounds__(64 * RG_WAVES, FAST ? ((NPART_ == 1 ? RG_OCC :
     NveImgPre ipre;
     if (RG_IMG_PRE && a.fuse_nve && mine && part == 0) nve_prefetch_images(a.nve, i, ipre);
     if (SHARE) __syncthreads();      // partners in other waves may still be adding to my sums
+    // (PairArgs::poison: an outgrown capacity was reported by this interval's rebuild - nothing is stored, the rebuild will be redone)
+    if (poisoned) return;
     double xn0 = 0.0, xn1 = 0.0, xn2 = 0.0;       // the atom's position after the step boundary (for the rebuild's count below)
     if (mine && part == 0) {
         double fx, fy, fz;

@@ -7,7 +7,9 @@
 // each, as the LOCAL transport's tests have them) run that very branch: it keeps RCCL's matching rules - point-to-point messages
 // between two ranks match in the order they were posted, a send and its receive must agree on the byte count, everything inside
 // one ncclGroupStart / ncclGroupEnd is posted together - and moves the bytes with device-to-device copies.  It is not shipped, not
-// linked by the product, and says nothing about RCCL's performance.
+// linked by the product, and says nothing about RCCL's performance.  Two modes: host-synchronous (default: validates sizes, offsets,
+// order and matching) and, with RCCL_STAND_IN_ASYNC=1, stream-ordered like RCCL itself (run_ops_async: also validates the engine's
+// stream and event order around its exchanges - buffer reuse, reads of ghosts in flight).
 //
 // Build: hipcc -shared -fPIC tests/c/rccl_stand_in.cpp -o tests/c/librccl_stand_in.so  (__graft_entry__.build())
 #include <hip/hip_runtime.h>
@@ -16,6 +18,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -30,6 +33,10 @@ struct Msg {
     const void *buf;
     size_t bytes;
     bool taken = false;
+    // asynchronous mode: `ready` is recorded on the sender's stream when the message is posted (what the buffer holds is complete
+    // once it has passed); `done` is recorded on the receiver's stream behind its copy (the sender's stream waits for it)
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool done_recorded = false;
 };
 struct Group {
     int nranks = 0;
@@ -66,9 +73,84 @@ size_t type_bytes(ncclDataType_t t)
     }
 }
 
+// RCCL_STAND_IN_ASYNC=1: RCCL's stream semantics instead of host synchronisation.  A group becomes work ON the callers' streams: the
+// receiver's stream waits for the sender's `ready` event, copies, records `done`; the sender's stream waits for `done` before anything
+// posted behind the send may run.  No hipStreamSynchronize anywhere - the host threads only rendezvous with each other (a receive needs
+// the peer's message descriptor, a send needs the event its receiver records), so whatever the engine enqueues behind a group really
+// runs concurrently with the peers' copies unless the engine's own stream / event order forbids it.  A staging buffer that is
+// rewritten from another stream without waiting for the exchange, or a ghost array read before its receive has landed, now corrupts
+// the trajectory and fails the bit-identity test; the synchronous mode (default) cannot see either.
+static bool async_mode()
+{
+    static const bool on = [] { const char *e = getenv("RCCL_STAND_IN_ASYNC"); return e && *e && *e != '0'; }();
+    return on;
+}
+
+ncclResult_t run_ops_async(std::vector<Op> &ops)
+{
+    std::vector<std::shared_ptr<Msg>> mine;
+    // 1. post every send: its `ready` event is on my stream before the peer can see the message
+    for (auto &o : ops) {
+        if (!o.send) continue;
+        Group *g = o.c->g;
+        auto m = std::make_shared<Msg>();
+        m->buf = o.buf; m->bytes = o.bytes;
+        if (hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(m->ready, o.stream) != hipSuccess)
+            return ncclUnhandledCudaError;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->box[(size_t)o.c->rank * g->nranks + o.peer].push_back(m);
+        }
+        g->cv.notify_all();
+        mine.push_back(m);
+    }
+    ncclResult_t rc = ncclSuccess;
+    // 2. every receive: wait (host) for the peer's descriptor, then the copy rides on MY stream behind the peer's `ready`
+    for (auto &o : ops) {
+        if (o.send) continue;
+        Group *g = o.c->g;
+        std::shared_ptr<Msg> m;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            auto &q = g->box[(size_t)o.peer * g->nranks + o.c->rank];
+            g->cv.wait(lk, [&] { return !q.empty(); });
+            m = q.front();
+            q.pop_front();
+        }
+        if (m->bytes != o.bytes) {
+            fprintf(stderr, "rccl stand-in: rank %d receives %zu bytes from rank %d, which sent %zu\n", o.c->rank, o.bytes, o.peer, m->bytes);
+            rc = ncclInvalidUsage;
+        } else if (hipStreamWaitEvent(o.stream, m->ready, 0) != hipSuccess ||
+                   (o.bytes && hipMemcpyAsync(o.buf, m->buf, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess))
+            rc = ncclUnhandledCudaError;
+        if (hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess || hipEventRecord(m->done, o.stream) != hipSuccess)
+            rc = ncclUnhandledCudaError;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            m->done_recorded = true;
+        }
+        g->cv.notify_all();
+    }
+    // 3. every send: my stream goes on only when the receiver's copy has run (the buffer may be rewritten behind this point)
+    for (size_t k = 0, s = 0; k < ops.size(); k++) {
+        if (!ops[k].send) continue;
+        Group *g = ops[k].c->g;
+        auto &m = mine[s++];
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv.wait(lk, [&] { return m->done_recorded; });
+        }
+        if (hipStreamWaitEvent(ops[k].stream, m->done, 0) != hipSuccess) rc = ncclUnhandledCudaError;
+        // (both events have their waiters enqueued: the runtime keeps what it still needs)
+        (void)hipEventDestroy(m->ready); (void)hipEventDestroy(m->done);
+    }
+    return rc;
+}
+
 ncclResult_t run_ops(std::vector<Op> &ops)
 {
     if (ops.empty()) return ncclSuccess;
+    if (async_mode()) return run_ops_async(ops);
     // what the messages hold must be complete before a peer copies it
     for (auto &o : ops) if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
     std::vector<std::shared_ptr<Msg>> mine;

@@ -19,6 +19,9 @@ from meso_amd.api import Meso, nccl_unique_id  # noqa: E402
 from meso_amd.datagen import make_box  # noqa: E402
 
 
+EXPECT_DIFFER = any(kv.startswith("expect_differ=") for kv in sys.argv[8:])
+
+
 def run(nranks, grid, L, style, steps, transport, opts):
     x, v, lo, hi = make_box(L)
     uid = nccl_unique_id() if transport == "rccl" else np.frombuffer(np.random.default_rng(7 * nranks + L).bytes(8), np.uint8)
@@ -48,6 +51,10 @@ def run(nranks, grid, L, style, steps, transport, opts):
     t_end = time.time() + 240
     while any(t.is_alive() for t in th) and time.time() < t_end and not errs:
         time.sleep(0.05)
+    if (errs or any(o is None for o in out)) and EXPECT_DIFFER and transport == "rccl":
+        print("PLANTED HAZARD SEEN: the run ended with", errs)
+        sys.stdout.flush()
+        os._exit(0)
     if errs or any(o is None for o in out):
         print("FAILED", transport, errs)
         sys.stdout.flush()
@@ -61,8 +68,15 @@ def main():
     nranks, gx, gy, gz, L = (int(t) for t in sys.argv[1:6])
     style, steps = sys.argv[6], int(sys.argv[7])
     opts = [(kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[8:]]
+    # expect_differ=1: a hazard planted on purpose (option debug_early_reuse) must show as a trajectory that differs from the LOCAL one
+    expect_differ = bool(dict(opts).pop("expect_differ", 0)) if any(k == "expect_differ" for k, _ in opts) else False
+    opts = [(k, val) for k, val in opts if k != "expect_differ"]
     a, ca, na, xa = run(nranks, (gx, gy, gz), L, style, steps, "rccl", opts)
-    b, cb, _, _ = run(nranks, (gx, gy, gz), L, style, steps, "local", opts)
+    b, cb, _, _ = run(nranks, (gx, gy, gz), L, style, steps, "local", [(k, val) for k, val in opts if k != "debug_early_reuse"])
+    if expect_differ:
+        same = all(np.array_equal(a[k], b[k], equal_nan=True) for k in range(3))
+        print("PLANTED HAZARD %s" % ("NOT SEEN" if same else "SEEN: trajectories differ"))
+        return
     if dict(opts).get("profile"):
         # option profile: every RCCL group sits between two HIP events on the exchange stream and is booked per kind of exchange
         # (meso_xchg_stats; the host / in-process transports keep a host-side account instead)

@@ -739,6 +739,51 @@ def test_fp32_force_sums_out_of_range_are_reported(Meso):
 
 
 @pytest.mark.parametrize("style", ["dpd/meso", "dpd/fast/meso"])
+def test_an_outgrown_capacity_is_redone_not_fatal(Meso, style):
+    """No default path may end a run (the reference regrows its buffers on the fly, comm_meso.cu:122,138,179-181).  An
+    asynchronous rebuild whose ghost list, border range or cell buckets outgrow what the previous rebuild reserved raises a device flag;
+    every launch behind it stores nothing (PairArgs::poison, the NVE kernels), and run() - when it next reads the rebuild's report, a few
+    steps later or at its end - goes back to that rebuild, redoes it through the synchronous path with regrown capacities and continues.
+    Positions, velocities and forces equal those of a run that never outgrew anything, bit for bit; `rebuilds_redone` counts."""
+    ref, _ = _engine(Meso, 16, style=style)
+    ref.run(23)
+    want = ref.gather()[:3]
+    ref.close()
+    # (a) the fused rebuild's ghost list, detected by the preparation of the NEXT rebuild; (b) the same, detected at the end of a short
+    # run; (c) the chain of small launches (fused_rebuild 0): its border scan's capacity check; (d) two rebuilds in a row
+    for opts, plan in (((), ((23, 10),)), ((), ((7, 10), (16, 0))), ((("fused_rebuild", 0),), ((23, 10),)), ((), ((8, 10), (15, 12)))):
+        m, _ = _engine(Meso, 16, style=style, opts=opts)
+        for nsteps, cap in plan:
+            if cap:
+                m.set_option("debug_ghost_cap", cap)
+            m.run(nsteps)
+        got = m.gather()[:3]
+        assert m.timer("rebuilds_redone")[1] == sum(1 for _, cap in plan if cap), (opts, plan)
+        m.close()
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), (opts, plan)
+
+
+def test_an_outgrown_cell_bucket_is_redone_not_fatal(Meso):
+    """The fused rebuild's cell buckets (option fused_cap 2: two atoms per cell, the rest through an overflow list of 65 536 entries) at
+    32^3, where the overflow list cannot hold the rest: the first asynchronous rebuild reports it, is redone through the chain of small
+    launches, and the buckets are twice as deep from there on.  Same bits as the default."""
+    res = []
+    # shallow from the start (setup deepens the buckets and builds again) / made shallow after setup (the first rebuild of the run is redone)
+    for before, after in (((), ()), ((("fused_cap", 2),), ()), ((), (("fused_cap", 2),))):
+        m, _ = _engine(Meso, 32, style="dpd/fast/meso", opts=before)
+        for k, val in after:
+            m.set_option(k, val)
+        m.run(12)
+        res.append(m.gather()[:3])
+        assert (m.timer("rebuilds_redone")[1] >= 1) == bool(after)
+        m.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("style", ["dpd/meso", "dpd/fast/meso"])
 def test_count_in_epilogue_does_not_regrow_ahead_of_the_force_launch(Meso, style):
     """The rebuild's count rides in the force launch IN FRONT of the rebuild (fuse_count).  When that rebuild will need more room than
     the atom arrays have (here: async_grid_scale 3 asks for three times the ghosts' head-room, beyond the capacity chosen at upload),
