@@ -68,7 +68,11 @@ int meso_device_sync(meso_ctx *ctx);
  *                    in a header, so the ghost stage needs neither a count exchange nor a host round trip
  *   mig_cap_floor 64  several ranks, async_counts: a migration message has the capacity 2 * (count of the previous rebuild) + floor and
  *                    carries its counts in a header (no separate count exchange); one that does not fit is sent again, exactly
- *   mr_cap_margin 0.5  see async_counts (a message that outgrows its capacity is an error, reported at the end of run(); between
+ *                    One rank: a ghost list / border range / cell bucket that outgrows what the previous rebuild reserved is NOT an error -
+ *                    every launch behind that rebuild stores nothing (a device flag) and meso_run redoes the rebuild through the
+ *                    synchronous path with regrown capacities (test_an_outgrown_capacity_is_redone_not_fatal; MesoComm::borders regrows
+ *                    its buffers on the fly as well, comm_meso.cu:122,138,179-181).
+ *   mr_cap_margin 0.5  see async_counts (several ranks: a message that outgrows its capacity is an error, reported at the end of run(); between
  *                    two rebuilds a slab's ghosts can grow by at most the atoms of a layer as thick as the largest displacement
  *                    next to it - 11.5 % at equal density with the default skin)
  *   row_part     -1  1 = the list builder writes every row in two sections (meso_neigh_parts): what the atom evaluates in front,
@@ -100,6 +104,13 @@ int meso_device_sync(meso_ctx *ctx);
  *                    from 32 counters - the reference's builder is a grid-stride loop, neigh_build_meso.cu:58; measured 6 % slower than
  *                    one workgroup per brick (64^3: 219 against 206 us per build), so off (test_config2_64cube_two_section_rows_are_bit_
  *                    identical_to_plain_rows keeps it alive)
+ *   Options whose non-default value lost in every measurement for three rounds stay as ONE tested alternative each, not as tuning knobs:
+ *   ghost_sort 1 (ghosts binned by sorting: test_reorder_by_counting_equals_reorder_by_sorting), tile_plan 1 (separate plan launch; what rows
+ *   shorter than 64 entries use by themselves: test_short_cutoff_rows_of_32_survive_several_fused_rebuilds), and - several ranks -
+ *   border_runs 0, mig_slim 0, border_fused 0, refresh_direct 0, refresh_epilogue 0 (the chains of small launches the round-3/4 kernels
+ *   replaced: all five in test_borders_without_host_round_trip_equal_the_synchronous_path of tests/test_gpu_multirank.py, the last two also
+ *   in tests/test_gpu_rccl_branch.py).  brick2_split is gone (the launcher decides from the number of bricks).
+ *   debug_ghost_cap, debug_early_reuse: planted faults for tests (test_an_outgrown_capacity_is_redone_not_fatal; tests/test_gpu_rccl_branch.py).
  *   check_launches 0  debugging: every stage of a rebuild (migration, reorder, borders, list builder) is synchronised and asked for
  *                    HIP errors, so that a fault names the stage instead of surfacing at the end of meso_run
  *   profile       0  HIP-event timers per phase (meso_timer_get); pair_debug: timing ablations (bench only) */

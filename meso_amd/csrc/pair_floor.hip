@@ -116,14 +116,15 @@ __global__ void __launch_bounds__(64 * FL_WAVES) k_floor_prepare(FloorArgs a)
 }
 
 // MODE bit 0: arithmetic, bit 1: the loads, bit 2: the loads with two row chunks of gathers in flight
-template <int MODE>
+// EXP: the experiment knobs (local_mask, drop16, cu_map) are compiled in; the plain modes carry none of their instructions
+template <int MODE, bool EXP = false>
 __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
 {
     constexpr bool ARITH = (MODE & 1) != 0, LOADS = (MODE & 2) != 0, DEEP = (MODE & 4) != 0;
     __shared__ float4 own_c[256], own_v[256];
     __shared__ u32 facc[3 * 256];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int blk = fl_block(gridDim.x, a.cu_map), base = blk * 256, i = base + w * 64 + lane;
+    const int blk = fl_block(gridDim.x, EXP ? a.cu_map : 0), base = blk * 256, i = base + w * 64 + lane;
     const bool mine = i < a.n;
     const int gw = blk * FL_WAVES + w;
     float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = c1;
@@ -148,10 +149,10 @@ __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, (int)nrec, 0x00020000);
     u32 fold = 0;
     u32 inside = 0;
-    const u32 lmask = a.local_mask, lbase = (u32)base;
-    const u32 drop = (u32)a.drop16;
+    const u32 lmask = EXP ? a.local_mask : 0u, lbase = (u32)base;
+    const u32 drop = EXP ? (u32)a.drop16 : 0u;
     // (drop16: experiments - that many sixteenths of the entries, picked by a hash of the partner index, are not fetched: out-of-range offset)
-    auto jx = [&](u32 j) -> u32 { if (drop && ((j * 2654435761u) >> 28) < drop) return 0x0FFFFFFFu; return lmask ? lbase + (j & lmask) : j; };
+    auto jx = [&](u32 j) -> u32 { if (!EXP) return j; if (drop && ((j * 2654435761u) >> 28) < drop) return 0x0FFFFFFFu; return lmask ? lbase + (j & lmask) : j; };
 
     // ---- per row entry: gather + distance test
     auto tests = [&](int k) {       // 64 full-lane tests on LDS operands: 3 sub, 3 mul/fma, 2 compares - the mandatory part of a cutoff test
@@ -289,6 +290,7 @@ int Engine::pair_floor(int mode, int reps, double *us, long *counts)
     if (mode >= 50) { cu_map = 1; mode -= 50; }      // 50 + m: mode m with CU-local groups      // experiments: 800 + m = mode m with every gather inside a 256-atom window
     if (!(mode >= 1 && mode <= 3) && mode != 6 && mode != 7) return fail(1, "pair_floor: mode 1 (arithmetic), 2 (loads), 3 (both); 6 / 7: 2 / 3 with two chunks of gathers in flight");
     if (reps < 1 || !us) return fail(1, "pair_floor: invalid arguments");
+    if ((local_mask || drop16 || cu_map) && mode != 2 && mode != 6) return fail(1, "pair_floor: the experiment knobs go with the loads-only modes 2 and 6");
     if (!is_setup || !pair_table || nlocal <= 0) return fail(3, "pair_floor: no neighbour table (run setup first)");
     if (!rows_part || part_group != 256 || ntypes != 1) return fail(3, "pair_floor: needs rows in two sections for 256-atom groups and one atom type");
     TRY(resolve_counts());
@@ -324,12 +326,17 @@ int Engine::pair_floor(int mode, int reps, double *us, long *counts)
     if (!rc) {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        const bool ex = local_mask || drop16 || cu_map;
         auto launch = [&]() {
-            if (mode == 1) hipLaunchKernelGGL(k_pair_floor<1>, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a);
-            else if (mode == 2) hipLaunchKernelGGL(k_pair_floor<2>, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a);
-            else if (mode == 3) hipLaunchKernelGGL(k_pair_floor<3>, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a);
-            else if (mode == 6) hipLaunchKernelGGL(k_pair_floor<6>, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a);
-            else hipLaunchKernelGGL(k_pair_floor<7>, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a);
+            const dim3 g(nblk), b(64 * FL_WAVES);
+            if (ex) {
+                if (mode == 2) hipLaunchKernelGGL((k_pair_floor<2, true>), g, b, 0, stream, a);
+                else hipLaunchKernelGGL((k_pair_floor<6, true>), g, b, 0, stream, a);
+            } else if (mode == 1) hipLaunchKernelGGL((k_pair_floor<1>), g, b, 0, stream, a);
+            else if (mode == 2) hipLaunchKernelGGL((k_pair_floor<2>), g, b, 0, stream, a);
+            else if (mode == 3) hipLaunchKernelGGL((k_pair_floor<3>), g, b, 0, stream, a);
+            else if (mode == 6) hipLaunchKernelGGL((k_pair_floor<6>), g, b, 0, stream, a);
+            else hipLaunchKernelGGL((k_pair_floor<7>), g, b, 0, stream, a);
         };
         for (int r = 0; r < 3; r++) launch();
         (void)hipEventRecord(e0, stream);

@@ -326,6 +326,11 @@ __device__ __forceinline__ void fr_gather_block(const FusedArgs &a, const int bi
 {
     const int n = (int)blockDim.x * bidx + (int)threadIdx.x;
     const bool valid = n < a.n;
+    // A cell bucket + the overflow list too small (flag >= 300000, raised by the count or the ordering kernel in front of this launch):
+    // atoms were lost on the way and the permutation has holes that hold whatever the memory held before - nothing is gathered
+    // through it.  The engine deepens the buckets and builds again from the arrays this launch would have read (Engine::reneighbor,
+    // prepare_redo).
+    if (*a.flags >= 300000) return;
     double X[3] = {0.0, 0.0, 0.0};
     if (valid && LISTS) {
         MergeOut mg = a.mg;
@@ -393,6 +398,7 @@ __device__ __forceinline__ void fr_ghosts_tile(const FusedArgs &a, const int bid
     // (gorder: only the tiles that hold ghost cells run - nine tenths of the tiles of a large box are interior; the list builder
     // then takes a cell's ghosts from (gstart, gcnt) of ghost cells only)
     const int t = a.gorder ? a.gorder[bidx] : bidx, tid = threadIdx.x;
+    const bool reorder_lost = *a.flags >= 300000;      // (the reorder in front lost atoms: see fr_gather_block)
     const int ntiles = a.M / FR_GTILE;
     const int code0 = t * FR_GTILE;
     int nc = 0;
@@ -455,6 +461,7 @@ __device__ __forceinline__ void fr_ghosts_tile(const FusedArgs &a, const int bid
     }
     if (tid == 0) { a.gttot_next[t] = 0; gl[FR_GTILE] = 0; }
     __syncthreads();
+    if (reorder_lost) return;      // (the report above went out; no ghost is read through a permutation with holes)
     // candidates -> ghost flags, ghosts per cell (passes over sub-ranges of cells whose candidates fit the LDS stage)
     int cb = 0;
     while (cb < FR_GTILE) {
