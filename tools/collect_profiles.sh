@@ -48,6 +48,7 @@ echo "pair-only pmc done"
 bash tools/pmc_focus.sh ${tag}_focus --other-boxes "" --opt fuse_pair=0 > gpurun_out/${tag}_focus.log 2>&1 || echo "focus counters failed"
 # ... and of the fp64 style (dpd/meso: configs[1] and configs[3])
 bash tools/pmc_focus.sh ${tag}_focus_dp --other-boxes "" --style dpd/meso --opt fuse_pair=0 > gpurun_out/${tag}_focus_dp.log 2>&1 || echo "fp64 focus counters failed"
+bash tools/pmc_kernel.sh ${tag}_tb tile_build --other-boxes "" > gpurun_out/${tag}_tb.log 2>&1 || echo "list builder counters failed"
 echo "focus pmc done"
 # the other configurations of BASELINE.json (parity-test cases; timed for the record)
 timeout -k 10 300 python3 bench.py --box 25 --no-cpu-baseline > gpurun_out/${tag}_bench25_fast.json 2>/dev/null

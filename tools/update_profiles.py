@@ -57,11 +57,29 @@ if os.path.exists(foc):
         lim = {"units": "VALU issue and texture addresser", "kernel_cycles": cyc,
                "valu_issue_frac": round(c["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cyc, 3),       # wave-instructions / 1024 SIMDs x 4 cycles
                "source": "profiles/%s_pmc_ring_focus.txt (tools/pmc_focus.sh, force kernel launched alone)" % tag}
+        if "SQ_WAVE_CYCLES" in c:
+            # mean resident waves over the launch / wave slots of the card (SQ_WAVE_CYCLES x 4 / kernel cycles / slots); the
+            # fp32 ring kernel is compiled for 20 waves per CU (RG_OCC)
+            lim["occupancy_mean"] = round(c["SQ_WAVE_CYCLES"] * 4.0 / cyc / (20 * 256), 3)
         if "TA_TA_BUSY_sum" in c:
             lim["ta_busy_frac"] = round(c["TA_TA_BUSY_sum"] / 256.0 / cyc, 3)               # per CU
         if "TCP_PENDING_STALL_CYCLES_sum" in c and "TCP_GATE_EN1_sum" in c:
             lim["l1_pending_stall_frac"] = round(c["TCP_PENDING_STALL_CYCLES_sum"] / c["TCP_GATE_EN1_sum"], 3)
         t["limiter"] = lim
+tb = "gpurun_out/pmck_%s_tb.txt" % tag
+if os.path.exists(tb):
+    shutil.copy(tb, "profiles/%s_pmc_tile_build.txt" % tag)
+    c = {}
+    for ln in open(tb):
+        m = re.match(r"(.*?)\s+(\S+)\s+mean\s+([0-9.e+]+)", ln)
+        if m and "k_tile_build" in m.group(1):
+            c[m.group(2)] = float(m.group(3))
+    if "SQ_BUSY_CYCLES" in c and "SQ_WAVE_CYCLES" in c and "limiter" in t:
+        # (k_tile_build<2, true>: 72 VGPRs -> seven waves per SIMD)
+        t["limiter"]["list_builder"] = {"kernel": "k_tile_build<2, true>", "kernel_cycles": c["SQ_BUSY_CYCLES"] / 32.0,
+                                        "occupancy_mean": round(c["SQ_WAVE_CYCLES"] * 4.0 / (c["SQ_BUSY_CYCLES"] / 32.0) / (7 * 1024), 3),
+                                        "insts_valu": c.get("SQ_INSTS_VALU"), "insts_salu": c.get("SQ_INSTS_SALU"),
+                                        "source": "profiles/%s_pmc_tile_build.txt (tools/pmc_kernel.sh)" % tag}
 json.dump(t, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
 json.dump(t, open("profiles/force_kernel_profile.json", "w"), indent=1)      # the file bench.py reads
 print(json.dumps(t, indent=1))
