@@ -24,7 +24,10 @@ for case in range(ncases):
     split = int(rng.choice([-1, 1]))
     x, v, types, bonds, lo, hi = make_polymer_box(L, frac=frac)
     res = []
-    for opts in ((("split_gather", split),), PLAIN):
+    # (third run, round 6: the default path with an outgrown ghost capacity planted at a random step - redone inside run())
+    k_plant = int(rng.integers(1, 20))
+    for idx, opts in enumerate(((("split_gather", split),), PLAIN, (("split_gather", split),))):
+        planted = idx == 2
         m = Meso()
         for k, val in opts:
             m.set_option(k, val)
@@ -41,9 +44,14 @@ for case in range(ncases):
             m.pair_coeff(i, j, a, 4.5, 3.0, 1.0, 1.0)
         m.timestep(0.004); m.setup()
         m.force_clear(); m.compute(0, 0); m.bond_compute(0)
-        m.run(23)
+        if planted:
+            m.run(k_plant)
+            m.set_option("debug_ghost_cap", 3)
+            m.run(23 - k_plant)
+        else:
+            m.run(23)
         res.append(m.gather()[:3]); m.close()
-    same = all(np.array_equal(a, b) for a, b in zip(*res))
+    same = all(np.array_equal(a, b) for a, b in zip(res[0], res[1])) and all(np.array_equal(a, b) for a, b in zip(res[0], res[2]))
     fin = bool(np.isfinite(res[0][0]).all())
     print("case %2d  L %2d  n %6d  chains %.1f  special %s  %-8s  every %d  split_gather %2d  %-13s  %s" % (
         case, L, len(x), frac, special, bond, every, split, style, "equal" if same and fin else ("NOT FINITE (deck blew up)" if not fin else "DIFFERENT")), flush=True)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """tools/fuzz_paths.py [NCASES] [SEED] [MIN_EDGE] [MAX_EDGE] [MAX_ATOMS]: random decks (box shape, density, periodicity, types and masses, rebuild interval, style) run 23
 steps through the default path and through the plain one (every fusion of the rebuild and of the step boundary switched off): positions,
-velocities and forces must be equal bit for bit (both start from the ring kernel's forces, whose sums do not depend on entry order).
+velocities and forces must be equal bit for bit (both start from the ring kernel's forces, whose sums do not depend on entry order); and
+a third time through the default path with an outgrown ghost capacity planted at a random step (option debug_ghost_cap: the rebuild that
+reports it is redone inside run()) - the same bits again.
 A check beyond the test-suite's fixed decks; prints one line per case and exits non-zero on the first difference."""
 import sys
 import numpy as np
@@ -35,7 +37,12 @@ for case in range(ncases):
     every = int(rng.choice([1, 2, 5, 7]))
     style = str(rng.choice(["dpd/meso", "dpd/fast/meso"]))
     res = []
-    for opts in ((), PLAIN):
+    # third run (round 6): the default path with an outgrown ghost capacity planted at a random step - the rebuild is redone inside run()
+    k_plant = int(rng.integers(1, 20))
+    for opts in ((), PLAIN, "planted"):
+        planted = opts == "planted"
+        if planted:
+            opts = ()
         m = Meso()
         for k, val in opts:
             m.set_option(k, val)
@@ -47,9 +54,14 @@ for case in range(ncases):
                 m.pair_coeff(i, j, 15.0 if i == j else 30.0, 4.5, 3.0, 1.0, 1.0)
         m.timestep(0.004); m.setup()
         m.force_clear(); m.compute(0, 0)
-        m.run(23)
+        if planted:
+            m.run(k_plant)
+            m.set_option("debug_ghost_cap", 3)
+            m.run(23 - k_plant)
+        else:
+            m.run(23)
         res.append(m.gather()[:3]); m.close()
-    same = all(np.array_equal(a, b) for a, b in zip(*res))
+    same = all(np.array_equal(a, b) for a, b in zip(res[0], res[1])) and all(np.array_equal(a, b) for a, b in zip(res[0], res[2]))
     fin = bool(np.isfinite(res[0][0]).all())
     print("case %2d  box %5.1f x %5.1f x %5.1f  rho %.0f  n %6d  per %s  types %d  every %d  %-13s  %s" % (
         case, dims[0], dims[1], dims[2], rho, n, per, ntypes, every, style, "equal" if same and fin else "DIFFERENT"), flush=True)
