@@ -1967,6 +1967,8 @@ int Engine::run(int nsteps)
         if (_rc == MESO_REDO && ck_it >= 0) { redo_pending = 1; goto redo_rebuild; } \
         if (_rc) { redo_armed = false; return _rc == MESO_REDO ? fail(4, "A rebuild outgrew its capacities outside a run") : _rc; } \
     } while (0)
+    // (armed for the duration of this call only, whichever way it returns: outside run() an outgrown capacity is an error)
+    struct Disarm { bool &b; ~Disarm() { b = false; } } disarm{redo_armed};
     redo_armed = true;
     for (int it = 0; it <= nsteps; it++) {
         if (it == nsteps) {

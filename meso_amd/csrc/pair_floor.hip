@@ -57,7 +57,7 @@ struct FloorArgs {
     int *nhits;         // [waves]
     double *f[3];
     int *overflow;
-    int drop16;
+    int drop16, keep16;
     int cu_map;         // experiments: 1 = workgroups that the dispatcher places on one CU in its first round take adjacent groups of atoms
     u32 local_mask;     // experiments: 0 = the real partner indices; else partner -> (own group base) + (index & mask): every gather inside a window
 };
@@ -135,6 +135,10 @@ __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
         c1 = a.coord4[i]; v1 = a.veloc4[i]; n = a.count[i];
         if (LOADS && n > 0) { w0 = rows[0]; w1 = rows[1]; }
     }
+    // experiments (keep16 in 1..15): only keep16 sixteenths of every row are walked with gathers - whole gather INSTRUCTIONS fewer - and
+    // the rest of the row's entries are read from the workgroup's LDS copy instead (what a row section of in-group partners would cost)
+    int n_lds = 0;
+    if (EXP && a.keep16 > 0 && a.keep16 < 16) { const int nk = (n * a.keep16 + 15) >> 4; n_lds = n - nk; n = nk; }
     const int nh = a.nhits[gw];
     const int ob = w * 64 + lane;
     own_c[ob] = c1; own_v[ob] = v1;
@@ -149,6 +153,16 @@ __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.veloc4, 0, (int)nrec, 0x00020000);
     u32 fold = 0;
     u32 inside = 0;
+    if (EXP && LOADS) {
+        int lmax = n_lds;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o, 64));
+        lmax = __builtin_amdgcn_readfirstlane(lmax);
+        for (int k = 0; k < lmax; k++) {
+            const float4 p = own_c[(lane * 37 + k * 101 + w * 64) & 255];
+            if (k < n_lds) fold ^= __float_as_uint(p.x) ^ __float_as_uint(p.y) ^ __float_as_uint(p.z) ^ __float_as_uint(p.w);
+        }
+    }
     const u32 lmask = EXP ? a.local_mask : 0u, lbase = (u32)base;
     const u32 drop = EXP ? (u32)a.drop16 : 0u;
     // (drop16: experiments - that many sixteenths of the entries, picked by a hash of the partner index, are not fetched: out-of-range offset)
@@ -283,14 +297,15 @@ __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
 int Engine::pair_floor(int mode, int reps, double *us, long *counts)
 {
     u32 local_mask = 0;
-    int drop16 = 0;
+    int drop16 = 0, keep16 = 0;
+    if (mode >= 1000000) { keep16 = mode / 1000000; mode %= 1000000; }      // 1000000 k + m: mode m walking k sixteenths of every row with gathers, the rest from LDS
     if (mode >= 10000) { drop16 = mode / 10000; mode %= 10000; }      // 10000 d + m: mode m with d sixteenths of the coordinate gathers not fetched
     if (mode >= 100) { local_mask = (1u << (mode / 100)) - 1u; mode %= 100; }
     int cu_map = 0;
     if (mode >= 50) { cu_map = 1; mode -= 50; }      // 50 + m: mode m with CU-local groups      // experiments: 800 + m = mode m with every gather inside a 256-atom window
     if (!(mode >= 1 && mode <= 3) && mode != 6 && mode != 7) return fail(1, "pair_floor: mode 1 (arithmetic), 2 (loads), 3 (both); 6 / 7: 2 / 3 with two chunks of gathers in flight");
     if (reps < 1 || !us) return fail(1, "pair_floor: invalid arguments");
-    if ((local_mask || drop16 || cu_map) && mode != 2 && mode != 6) return fail(1, "pair_floor: the experiment knobs go with the loads-only modes 2 and 6");
+    if ((local_mask || drop16 || cu_map || keep16) && mode != 2 && mode != 6) return fail(1, "pair_floor: the experiment knobs go with the loads-only modes 2 and 6");
     if (!is_setup || !pair_table || nlocal <= 0) return fail(3, "pair_floor: no neighbour table (run setup first)");
     if (!rows_part || part_group != 256 || ntypes != 1) return fail(3, "pair_floor: needs rows in two sections for 256-atom groups and one atom type");
     TRY(resolve_counts());
@@ -306,7 +321,7 @@ int Engine::pair_floor(int mode, int reps, double *us, long *counts)
     a.nall = (int)std::min<long>((long)nlocal + nghost, (1L << 28) - 1);
     a.cutsq = (float)coeff[P_CUTSQ]; a.cutinv = (float)coeff[P_CUTINV]; a.a0 = (float)coeff[P_A0]; a.gamma = (float)coeff[P_GAMMA];
     a.sigma = (float)coeff[P_SIGMA]; a.dtis = (float)(1.0 / std::sqrt(dt));
-    a.hits = hits; a.nhits = nh; a.overflow = ovf; a.local_mask = local_mask; a.cu_map = cu_map; a.drop16 = drop16;
+    a.hits = hits; a.nhits = nh; a.overflow = ovf; a.local_mask = local_mask; a.cu_map = cu_map; a.drop16 = drop16; a.keep16 = keep16;
     for (int d = 0; d < 3; d++) a.f[d] = cur.f[d];
     hipLaunchKernelGGL(k_floor_prepare, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a);
     std::vector<int> hn((size_t)nw + 1);
@@ -326,7 +341,7 @@ int Engine::pair_floor(int mode, int reps, double *us, long *counts)
     if (!rc) {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        const bool ex = local_mask || drop16 || cu_map;
+        const bool ex = local_mask || drop16 || cu_map || keep16;
         auto launch = [&]() {
             const dim3 g(nblk), b(64 * FL_WAVES);
             if (ex) {

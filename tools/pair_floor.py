@@ -32,7 +32,7 @@ n = len(x)
 lines = []
 res = {}
 for rep in range(2):
-    for mode in (1, 2, 3, 6, 7, 802, 1202, 52, 56, 40002, 60002, 80002):
+    for mode in (1, 2, 3, 6, 7, 802, 1202, 52, 56, 40002, 60002, 80002, 10000002, 12000002):
         us, nt, ne = m.pair_floor(mode, a.reps)
         res.setdefault(mode, []).append(us)
 info = m.neigh_info()
@@ -45,7 +45,8 @@ lines.append("%-34s %8s %8s   %s" % ("kernel", "us", "us (2nd)", "B_pair / t / 8
 for mode, name in ((1, "(a) arithmetic only"), (2, "(b) loads only"), (3, "(c) both, independent"), (6, "(b') loads, 16 gathers in flight"), (7, "(c') both, 16 gathers in flight"),
                    (802, "(b) with every gather inside the group's own 256 atoms"), (1202, "(b) with every gather inside a 4096-atom window"),
                    (52, "(b) first-round workgroups of a CU adjacent"), (56, "(b') first-round workgroups of a CU adjacent"),
-                   (40002, "(b) 4/16 of the coordinate gathers not fetched"), (60002, "(b) 6/16 not fetched"), (80002, "(b) 8/16 not fetched")):
+                   (40002, "(b) 4/16 of the coordinate gathers not fetched"), (60002, "(b) 6/16 not fetched"), (80002, "(b) 8/16 not fetched"),
+                   (10000002, "(b) 10/16 of every row gathered, the rest read from LDS"), (12000002, "(b) 12/16 gathered, rest from LDS")):
     u = res[mode]
     lines.append("%-34s %8.1f %8.1f   %.3f" % (name, u[0], u[1], b_pair / (min(u) * 1e-6) / 8e12))
 lines.append("%-34s %8.1f %8s   %.3f" % ("k_pair_dpd_ring alone (same session)", real_us, "", b_pair / (real_us * 1e-6) / 8e12))
