@@ -1,3 +1,6 @@
+"""tools/row_walk_stats.py [BOX]: how many 8-entry chunks a wave of the force kernel walks (its longest row) against what its atoms need, on the
+front sections of a thermalised table - and what dealing the 256 atoms of a workgroup to the lanes by row length would give
+(profiles/r06_notes.md section 8)."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np

@@ -1,3 +1,5 @@
+"""tools/stamp_small.py [BOX]: per-phase shader-clock cycles of the ring kernel's waves, step boundary fused and not (run with
+MESO_LIB=meso_amd/libmeso_hip_stamp.so from tools/build_variant.sh stamp "-DRG_STAMP -DRG_FEW" pair_ring.hip; profiles/r06_notes.md section 5)."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 from meso_amd.api import Meso
