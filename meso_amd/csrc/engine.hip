@@ -90,6 +90,8 @@ void Engine::free_all()
     dfree(estart); dfree(gstart); dfree(gcount); dfree(rcount); dfree(gslot); dfree(mr_gcnt); dfree(mig_cnt); dfree(mig_lst); dfree(d_vofs); dfree(d_center27);
     dfree(binrange);
     dfree(brick_hoff); dfree(brick_hmap); dfree(brick_hdr); dfree(brick_own); dfree(brick_order2); dfree(tile_queue);
+    if (debug_event) { (void)hipEventDestroy(debug_event); debug_event = nullptr; }
+    if (debug_stream) { (void)hipStreamDestroy(debug_stream); debug_stream = nullptr; }
     dfree(sendlist); dfree(chunk_count); dfree(chunk_offset); dfree(d_dir_start);
     dfree(d_partial); dfree(d_scalar); dfree(d_flags); dfree(sendlist_aux); dfree(d_mr);
     if (stage_send) (void)hipFree(stage_send);
