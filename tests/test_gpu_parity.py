@@ -764,6 +764,27 @@ def test_an_outgrown_capacity_is_redone_not_fatal(Meso, style):
             assert np.array_equal(a, b), (opts, plan)
 
 
+def test_an_outgrown_ghost_list_is_redone_in_the_streaming_rebuild(Meso):
+    """The same at 32^3 (131 072 atoms): from 50 000 local atoms on the rebuild's payload moves in a streaming gather with the ghost tiles
+    in its launch (split_gather, merge_ghosts) - the path the 64^3 benchmark takes.  Planted at the rebuild of step 10, detected by the
+    preparation of the one at step 15; and planted at the last rebuild of a run, detected at its end."""
+    ref, _ = _engine(Meso, 32, style="dpd/fast/meso")
+    ref.run(18)
+    want = ref.gather()[:3]
+    ref.close()
+    for plan in (((7, 0), (11, 40)), ((12, 0), (3, 40), (3, 0))):
+        m, _ = _engine(Meso, 32, style="dpd/fast/meso")
+        for nsteps, cap in plan:
+            if cap:
+                m.set_option("debug_ghost_cap", cap)
+            m.run(nsteps)
+        got = m.gather()[:3]
+        assert m.timer("rebuilds_redone")[1] == 1, plan
+        m.close()
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), plan
+
+
 def test_an_outgrown_cell_bucket_is_redone_not_fatal(Meso):
     """The fused rebuild's cell buckets (option fused_cap 2: two atoms per cell, the rest through an overflow list of 65 536 entries) at
     32^3, where the overflow list cannot hold the rest: the first asynchronous rebuild reports it, is redone through the chain of small
