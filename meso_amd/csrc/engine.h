@@ -90,6 +90,7 @@ public:
     int pair_compute(int range, int eflag, int vflag);
     int tally_ev();
     void launch_pair(PairArgs &p, int ev);
+    bool launch_refused = false;    // the ring kernel's launcher declined a launch (reported by run() / pair_compute as an error)
     bool ring_selected() const;
     char pair_variant[128] = "";    // instantiation of the force kernel THIS engine launched last (meso_pair_kernel_name)
 

@@ -1850,7 +1850,7 @@ void Engine::launch_pair(PairArgs &p, int ev)
     for (int t = 0; t < ntypes * ntypes; t++) p.uniform_cut &= coeff[(size_t)t * 7 + P_CUT] == coeff[P_CUT] ? 1 : 0;
     // two kernels: the ring kernel (both styles) and the lane-per-atom kernel that also books energy and virial
     if (ev || pair_kernel == 0) launch_pair_dpd(p, pair_style, ev, stream);
-    else launch_pair_dpd_ring(p, pair_style, stream, pair_variant);
+    else if (!launch_pair_dpd_ring(p, pair_style, stream, pair_variant)) launch_refused = true;
 }
 
 int Engine::pair_compute(int r, int eflag, int vflag)
@@ -1881,6 +1881,7 @@ int Engine::pair_compute(int r, int eflag, int vflag)
     tbegin("pair");
     launch_pair(p, ev);
     tend("pair");
+    if (launch_refused) { launch_refused = false; return fail(2, "The force kernel has no form for this combination of row layout and record format"); }
     if (ev) ev_valid = true;
     return 0;
 }
@@ -2124,6 +2125,16 @@ int Engine::run(int nsteps)
             merged = false;
         }
         ev_valid = false;
+        // a launch that the runtime refused (configuration, resources) is reported at the step that made it, not at the end of the run
+        // (a host-side query, no synchronisation; faults inside kernels still surface with the next synchronisation - option
+        // check_launches 1 waits behind every stage of a rebuild)
+        if (launch_refused) { launch_refused = false; return fail(2, "The force kernel has no form for this combination of row layout and record format"); }
+        if (hipError_t le = hipPeekAtLastError(); le != hipSuccess) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "HIP launch error at timestep %ld: %s", (long)ntimestep, hipGetErrorString(le));
+            (void)hipGetLastError();
+            return fail(2, msg);
+        }
     }
 #undef TRY_STEP
     redo_armed = false;

@@ -214,7 +214,7 @@ void launch_pair_dpd(const PairArgs &p, int fast, int evflag, hipStream_t s);
 int pair_ring_group();   // atoms per workgroup of the ring kernel (alignment of paired launches)
 int pair_ring_group_for(int n, int npart_opt);   // pairing group of a launch over n atoms (64 / lanes per atom * waves)
 // variant_out (nullable, 128 bytes): the instantiation launched, spelled as a profiler prints it
-void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *variant_out = nullptr);
+bool launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *variant_out = nullptr);
 // cell-ordered list builder (locals in reorder order, ghosts sorted by Morton bin)
 void launch_bin_ranges(const int *estart, const int *gstart, int M, int nlocal, int4 *binrange, hipStream_t s);
 struct ExclArgs;

@@ -543,11 +543,12 @@ void launch_pair_dpd_ring_dp(const PairArgs &pl, dim3 grid, dim3 block, size_t s
 // only while this is the kernel they were collected for
 // (written into the caller's buffer: several engines - the in-process ranks of the LOCAL transport - launch from several host threads)
 
-void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *variant_out)
+// returns false (nothing launched) for a combination the kernel has no form for; the engine reports it as an error of the run
+bool launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *variant_out)
 {
     char g_last_variant[128];
     int n = p.end - p.beg;
-    if (n <= 0) return;
+    if (n <= 0) return true;
     PairArgs pl = p;
     pl.lds_veloc = n >= 700000 ? 1 : 0;      // (see issue(): pays from about two rounds of waves on)
     const bool nt1 = p.ntypes == 1;
@@ -570,7 +571,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     // any other launch over such a table needs every neighbour (2: front and back section, one lane per atom, paired by the index
     // rule when it may pair at all).  (The engine does not partition for the wide records.)
     int parted = 0;
-    if (wide && p.nback) { fprintf(stderr, "launch_pair_dpd_ring: partitioned rows with the wide record format\n"); abort(); }
+    if (wide && p.nback) return false;      // (partitioned rows under the wide record format: the engine never builds them)
     if (p.nback != nullptr) {
         parted = (share && !wide && p.part_group == 64 / npart * RG_WAVES) ? 1 : 2;
         if (parted == 2) { npart = 1; share = share && (p.beg & (RG_GROUP - 1)) == 0; }
@@ -644,7 +645,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
     if (variant_out) snprintf(variant_out, 128, "%s", g_last_variant);
 #ifdef RG_FEW
     // (timing builds, tools/build_variant.sh: only the instantiations of the one-type benchmark decks)
-    if (!(fast && nt1 && ew1 && share && plain)) { fprintf(stderr, "RG_FEW build: variant not compiled\n"); abort(); }
+    if (!(fast && nt1 && ew1 && share && plain)) return false;      // (timing build: variant not compiled)
     RG_LAUNCH2(true, 0, true, true, true);
 #else
     // (the fp64 instantiations are compiled by their own translation unit, pair_ring_dp.hip: half the build time)
@@ -671,6 +672,7 @@ void launch_pair_dpd_ring(const PairArgs &p, int fast, hipStream_t s, char *vari
                 sum[7] / live, sum[8] / live, sum[9] / live);
     }
 #endif
+    return true;
 }
 
 // lanes per atom the launcher picks for a launch over n atoms (the engine tags rows for the matching pairing group)
