@@ -100,6 +100,10 @@ int meso_device_sync(meso_ctx *ctx);
  *                    separately (in Morton order an XCD's border share lies next to its bulk share); 0 = one contiguous range of atoms
  *                    per XCD, which leaves every border atom - a fifth more pairs, the periodic images - to the last XCD
  *                    (test_config2_64cube_two_section_rows_are_bit_identical_to_plain_rows)
+ *   report_poll   1  one rank, fused rebuild: the kernel that reports the rebuild's counts into pinned host memory writes the rebuild's
+ *                    sequence number behind them and the host polls that word when it next needs the counts; 0 = an event recorded behind
+ *                    the rebuild's last launch (a marker packet: ~6 us of bubble in front of the list builder on every rebuild;
+ *                    test_rebuild_variants_give_the_same_trajectory runs both)
  *   tile_persist  0  1 = the tile list builder runs as persistent workgroups (as many as the card holds at once) that draw their bricks
  *                    from 32 counters - the reference's builder is a grid-stride loop, neigh_build_meso.cu:58; measured 6 % slower than
  *                    one workgroup per brick (64^3: 219 against 206 us per build), so off (test_config2_64cube_two_section_rows_are_bit_

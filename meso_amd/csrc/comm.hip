@@ -1756,6 +1756,7 @@ int Engine::halo_borders_multi_async()
     HIPCHK(hipMemcpyAsync(h_flags + 8, d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
     if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ev_counts, stream));
+    counts_by_seq = false;
     counts_pending = true;
     mr_pending = true;
     nsend = bound_s; nghost = bound_r;            // launch bounds until resolve_counts() has the numbers

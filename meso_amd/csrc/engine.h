@@ -307,6 +307,9 @@ private:
     double async_grid_scale = 1.125;   // grids of the ghost kernels: previous ghost count x this + 1024 (they loop: any count is covered)
     bool counts_pending = false;
     hipEvent_t ev_counts = nullptr;
+    int report_seq = 0;             // one rank, fused rebuild: the report carries a sequence number the host polls (no event between the kernels)
+    bool counts_by_seq = false;
+    int report_poll = 1;            // option: 0 = an event behind the rebuild's last launch, as before
     int nghost_prev = -1, n_bulk_prev = -1;
     bool async_ok() const;
     // ... and with the two halves of the rebuild on two streams (option overlap_rebuild): the reorder of the locals on the

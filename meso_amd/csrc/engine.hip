@@ -8,6 +8,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 namespace meso {
 
@@ -330,6 +333,7 @@ int Engine::set_option(const std::string &key, double val)
     if (key == "brick2") { brick2 = (int)val; return 0; }
     if (key == "brick2_limit") { brick2_limit = (int)val; return 0; }
     if (key == "tile_persist") { tile_persist = (int)val; return 0; }
+    if (key == "report_poll") { report_poll = (int)val; return 0; }
     if (key == "debug_early_reuse") { debug_early_reuse = (int)val; return 0; }
     if (key == "debug_ghost_cap") { debug_ghost_cap = (int)val; return 0; }      // tests: the next asynchronous rebuild reserves this many ghosts only
     if (key == "fused_cap") { fr_cap_user = (int)val; return 0; }       // tests: atoms per cell bucket (the rest takes the overflow list)
@@ -1206,6 +1210,7 @@ int Engine::rebuild_overlapped()
     launch_translate_list(sendlist, perm_inverse, nsend, ng_dev, estart + bargs.M, h_flags_dev, stream);
     if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ev_counts, stream));
+    counts_by_seq = false;
     counts_pending = true;
     bulk_pending = true;
     ghosts_binned = true;
@@ -1346,12 +1351,17 @@ int Engine::rebuild_fused()
     a.dir_start = d_dir_start;
     a.report = h_flags_dev;
     a.merged_ghosts = merge_ghosts ? 1 : 0;      // (honoured with the order-only placing kernel: launch_fused_rebuild)
+    // the report names this rebuild: the host polls the word in pinned memory when it next needs the counts (resolve_counts)
+    counts_by_seq = report_poll != 0 && a.gttot != nullptr;      // (the ghost tiles write the report)
+    if (counts_by_seq) { report_seq = report_seq % 1000000 + 1; a.report_seq = report_seq; }
     launch_fused_rebuild(a, stream, count_in_epilogue);
     count_in_epilogue = false;
     std::swap(cur, alt); ck_swapped = !ck_swapped;
     merged_in_reorder = true;
-    if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev_counts, stream));
+    if (!counts_by_seq) {
+        if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_counts, stream));
+    }
     counts_pending = true;
     bulk_pending = true;
     ghosts_binned = true;
@@ -1391,6 +1401,7 @@ int Engine::halo_borders()
         }
         if (!ev_counts) HIPCHK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
         HIPCHK(hipEventRecord(ev_counts, stream));
+        counts_by_seq = false;
         counts_pending = true;
         nsend = nghost = bound;            // launch bounds until resolve_counts() has the numbers
         launch_border_fill(cur, beg, end, slab_lo, slab_hi, nullptr, chunk_offset, nchunk, sendlist, stream);
@@ -1568,8 +1579,20 @@ bool Engine::async_ok() const
 // the host's copy of the counts a rebuild left on the device (see halo_borders)
 int Engine::resolve_counts()
 {
-    if (!counts_pending) return 0;
-    HIPCHK(hipEventSynchronize(ev_counts));
+    if (!counts_pending) { counts_by_seq = false; return 0; }
+    if (counts_by_seq) {
+        // the ghost tiles wrote the counts and then the rebuild's number (system-scope release): long since there when the host asks -
+        // four steps later, as a rule; a stream synchronisation only if it does not show up
+        volatile int *seq = (volatile int *)h_flags + 12;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+        while (*seq != report_seq && std::chrono::steady_clock::now() < t_end) std::this_thread::yield();
+        if (*seq != report_seq) {
+            HIPCHK(hipStreamSynchronize(stream));
+            if (*seq != report_seq) return fail(2, "The rebuild's report did not arrive");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        counts_by_seq = false;
+    } else HIPCHK(hipEventSynchronize(ev_counts));
     counts_pending = false;
     bulk_pending = false;
     if (h_flags[8]) {

@@ -738,6 +738,7 @@ struct FusedArgs {
     int *dir_start;            // device [28]: [27] = ghost count (the per-step refresh loops to it)
     int *flags;                // device flags ([0] overflow code)
     int *report;               // pinned host memory as the device sees it
+    int report_seq;            // != 0: written to report[12] BEHIND the counts (system-scope fence): the host polls it instead of an event
 };
 void launch_fused_rebuild(const FusedArgs &a, hipStream_t s, bool counted = false);      // counted: the count ran in the force kernel's epilogue
 FrCountArgs fused_count_args(const FusedArgs &a);

@@ -447,6 +447,10 @@ __device__ __forceinline__ void fr_ghosts_tile(const FusedArgs &a, const int bid
             a.report[10] = a.flags[5];              // fullest brick neighbourhood of the previous list build
             a.report[11] = a.flags[6];              // ... a 2-brick neighbourhood neared its stage
             a.report[16 + 27] = ng;
+            // (the host polls this word instead of waiting for an event behind the launch: an event record between two kernels of a
+            // stream is a marker packet the command processor takes ~6 us to pass - a bubble in front of the list builder on every
+            // rebuild, profiles/r06_notes.md section 10)
+            if (a.report_seq) { __threadfence_system(); __hip_atomic_store(&a.report[12], a.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }
     if (tid < 64) {

@@ -702,7 +702,9 @@ def test_rebuild_variants_give_the_same_trajectory(Meso, style):
                  (("lean_boundary", 0),),
                  # merge_ghosts: the ghost tiles in the gather's launch (default with split_gather) or in a launch of their own
                  (("split_gather", 1),), (("split_gather", 1), ("merge_ghosts", 0)), (("split_gather", 1), ("merge_ghosts", 1), ("fuse_count", 0)),
-                 (("split_gather", 1), ("merge_ghosts", 1), ("lean_boundary", 0), ("fused_cap", 2))):
+                 (("split_gather", 1), ("merge_ghosts", 1), ("lean_boundary", 0), ("fused_cap", 2)),
+                 # report_poll: the rebuild's report found by polling its sequence number in pinned memory (default) or behind an event
+                 (("report_poll", 0),), (("report_poll", 0), ("split_gather", 1))):
         m, _ = _engine(Meso, 16, style=style, opts=opts)
         m.run(23)
         res.append(m.gather())
