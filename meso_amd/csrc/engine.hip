@@ -2010,7 +2010,19 @@ int Engine::run(int nsteps)
         }
         profile_tick(it, nsteps);
         ntimestep++;
-        if (!initial_done) TRY(nve_initial());
+        if (!initial_done) {
+            // the first step of a run (or the step behind an unfused boundary): when it provably keeps the neighbour table, the
+            // initial integration and the merge of the locals are one pass
+            const bool keeps = !dist_check && !redo_pending && !(ago + 1 >= delay && (ago + 1) % every == 0);
+            if (keeps && fuse_step && !merged) {
+                tbegin("nve");
+                launch_nve_initial_merge(cur, 0.5 * dt, dt, groupbit, nlocal, coord4, veloc4, 0.5 * (subhi[0] + sublo[0]),
+                                         0.5 * (subhi[1] + sublo[1]), 0.5 * (subhi[2] + sublo[2]), premix_tea<64>((u32)seed, (u32)ntimestep),
+                                         stream, d_flags);
+                tend("nve");
+                merged = true;
+            } else TRY(nve_initial());
+        }
         int rebuild = 0;
         if (redo_pending) { rebuild = 1; ago++; }
         else TRY(decide(&rebuild));

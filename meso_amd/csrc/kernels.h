@@ -36,6 +36,9 @@ void launch_merge_xvt(const AtomSoA &a, float4 *coord4, float4 *veloc4, double c
 // (poison, nullable: a device flag - non-zero: the kernel changes nothing; Engine::run redoes the rebuild that raised it)
 void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, hipStream_t s, const int *poison = nullptr);
 void launch_nve_final(const AtomSoA &a, double dtf, int groupbit, int n, hipStream_t s, const int *poison = nullptr);
+// initial_integrate + merge of the locals for the step that follows, one pass (the first step of a run that keeps the table)
+void launch_nve_initial_merge(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, float4 *coord4, float4 *veloc4, double cx,
+                              double cy, double cz, uint32_t seed, hipStream_t s, const int *poison = nullptr);
 // final(step s) + initial(step s+1) [+ merge for step s+1] in one pass
 void launch_nve_boundary(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, int merge, float4 *coord4,
                          float4 *veloc4, double cx, double cy, double cz, uint32_t seed_next, hipStream_t s, const int *poison = nullptr);

@@ -72,6 +72,46 @@ void launch_nve_initial(const AtomSoA &a, double dtf, double dtv, int groupbit, 
                        a.v[2], a.f[0], a.f[1], a.f[2], a.mask, a.mass, dtf, dtv, groupbit, n, poison);
 }
 
+// gpu_fix_NVE_init_intgrate<0> + gpu_merge_xvt for the same atom in one pass (the first step of a run() that keeps the neighbour table:
+// the two kernels in the same order on the same values - bit-identical - one launch and one reading of x, v less)
+__global__ void __launch_bounds__(256) k_nve_initial_merge(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                                           double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+                                                           const double *__restrict__ fx, const double *__restrict__ fy,
+                                                           const double *__restrict__ fz, const int *__restrict__ mask,
+                                                           const double *__restrict__ mass, const int *__restrict__ type,
+                                                           const int *__restrict__ tag, float4 *__restrict__ coord4, float4 *__restrict__ veloc4,
+                                                           double dtf, double dtv, int groupbit, double cx, double cy, double cz, u32 seed, int n,
+                                                           const int *__restrict__ poison)
+{
+    if (poison && *poison) return;
+    for (int i = blockDim.x * blockIdx.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double px = x[i], py = y[i], pz = z[i], a = vx[i], b = vy[i], c = vz[i];
+        if (mask[i] & groupbit) {
+            double dtfm = dtf * rcp_poly(mass[i]);
+            a = a + dtfm * fx[i]; b = b + dtfm * fy[i]; c = c + dtfm * fz[i];
+            vx[i] = a; vy[i] = b; vz[i] = c;
+            px += dtv * a; py += dtv * b; pz += dtv * c;
+            x[i] = px; y[i] = py; z[i] = pz;
+        }
+        float4 cc;
+        cc.x = (float)(px - cx); cc.y = (float)(py - cy); cc.z = (float)(pz - cz);
+        cc.w = __uint_as_float((u32)(type[i] - 1));
+        coord4[i] = cc;
+        float4 v;
+        v.x = (float)a; v.y = (float)b; v.z = (float)c;
+        v.w = __uint_as_float(signature(seed, tag[i], v.x, v.y, v.z));
+        veloc4[i] = v;
+    }
+}
+
+void launch_nve_initial_merge(const AtomSoA &a, double dtf, double dtv, int groupbit, int n, float4 *coord4, float4 *veloc4, double cx,
+                              double cy, double cz, uint32_t seed, hipStream_t s, const int *poison)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_nve_initial_merge, dim3(capgrid(n, 256)), dim3(256), 0, s, a.x[0], a.x[1], a.x[2], a.v[0], a.v[1], a.v[2], a.f[0],
+                       a.f[1], a.f[2], a.mask, a.mass, a.type, a.tag, coord4, veloc4, dtf, dtv, groupbit, cx, cy, cz, seed, n, poison);
+}
+
 // gpu_fix_NVE_final_integrate (fix_nve_meso.cu:157-178)
 __global__ void __launch_bounds__(256) k_nve_final(double *__restrict__ vx, double *__restrict__ vy,
                                                    double *__restrict__ vz, const double *__restrict__ fx,
