@@ -11,7 +11,7 @@
 // order and matching) and, with RCCL_STAND_IN_ASYNC=1, stream-ordered like RCCL itself (run_ops_async: also validates the engine's
 // stream and event order around its exchanges - buffer reuse, reads of ghosts in flight).
 //
-// Build: hipcc -shared -fPIC tests/c/rccl_stand_in.cpp -o tests/c/librccl_stand_in.so  (__graft_entry__.build())
+// Build: hipcc --offload-arch=gfx950 -shared -fPIC tests/c/rccl_stand_in.cpp -o tests/c/librccl_stand_in.so  (__graft_entry__.build())
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -80,6 +80,24 @@ size_t type_bytes(ncclDataType_t t)
 // runs concurrently with the peers' copies unless the engine's own stream / event order forbids it.  A staging buffer that is
 // rewritten from another stream without waiting for the exchange, or a ghost array read before its receive has landed, now corrupts
 // the trajectory and fails the bit-identity test; the synchronous mode (default) cannot see either.
+// RCCL_STAND_IN_DELAY_US=n (stream-ordered mode): every receive is held back by a spin kernel of n microseconds on the receiver's stream, so
+// that whatever the engine enqueues behind a group WITHOUT ordering it behind the group has certainly run before the bytes move - a
+// hazard then shows on every run, not on the runs where the race happens to go that way
+__global__ void k_stand_in_delay(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static long long delay_ticks()
+{
+    static const long long t = [] {
+        const char *e = getenv("RCCL_STAND_IN_DELAY_US");
+        const long long us = (e && *e) ? atoll(e) : 0;
+        return us > 0 ? us * 100 : 0;          // wall_clock64 counts at 100 MHz on gfx9
+    }();
+    return t;
+}
+
 static bool async_mode()
 {
     static const bool on = [] { const char *e = getenv("RCCL_STAND_IN_ASYNC"); return e && *e && *e != '0'; }();
@@ -120,9 +138,11 @@ ncclResult_t run_ops_async(std::vector<Op> &ops)
         if (m->bytes != o.bytes) {
             fprintf(stderr, "rccl stand-in: rank %d receives %zu bytes from rank %d, which sent %zu\n", o.c->rank, o.bytes, o.peer, m->bytes);
             rc = ncclInvalidUsage;
-        } else if (hipStreamWaitEvent(o.stream, m->ready, 0) != hipSuccess ||
-                   (o.bytes && hipMemcpyAsync(o.buf, m->buf, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess))
-            rc = ncclUnhandledCudaError;
+        } else {
+            if (hipStreamWaitEvent(o.stream, m->ready, 0) != hipSuccess) rc = ncclUnhandledCudaError;
+            if (delay_ticks()) hipLaunchKernelGGL(k_stand_in_delay, dim3(1), dim3(1), 0, o.stream, delay_ticks());
+            if (o.bytes && hipMemcpyAsync(o.buf, m->buf, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess) rc = ncclUnhandledCudaError;
+        }
         if (hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess || hipEventRecord(m->done, o.stream) != hipSuccess)
             rc = ncclUnhandledCudaError;
         {

@@ -27,7 +27,7 @@ LIB = os.path.join(ROOT, "tests", "c", "librccl_stand_in.so")
 def _build():
     src = os.path.join(ROOT, "tests", "c", "rccl_stand_in.cpp")
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        r = subprocess.run(["hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", src, "-o", LIB], capture_output=True, text=True)
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O1", "-shared", "-fPIC", "-std=c++17", src, "-o", LIB], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
 
 
@@ -43,7 +43,9 @@ def _build():
 @pytest.mark.parametrize("mode", ["host-synchronous", "stream-ordered"])
 def test_rccl_branch_equals_local_transport(nranks, grid, L, style, steps, opts, mode):
     _build()
-    env = dict(os.environ, LD_PRELOAD=LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", RCCL_STAND_IN_ASYNC="1" if mode == "stream-ordered" else "0")
+    # (stream-ordered mode: every receive held back by 50 us on the receiver's stream - transfers that arrive late, as over a real link)
+    env = dict(os.environ, LD_PRELOAD=LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", RCCL_STAND_IN_ASYNC="1" if mode == "stream-ordered" else "0",
+               RCCL_STAND_IN_DELAY_US="50")
     cmd = [sys.executable, os.path.join(ROOT, "tests", "rccl_stand_in_run.py"), str(nranks)] + [str(g) for g in grid] + [str(L), style, str(steps)] + list(opts)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "OK ranks" in r.stdout, (r.stdout + r.stderr)[-3000:]
@@ -59,7 +61,9 @@ def test_stream_ordered_stand_in_sees_a_send_buffer_reused_too_early():
     _build()
     seen = {}
     for mode in ("0", "1"):
-        env = dict(os.environ, LD_PRELOAD=LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", RCCL_STAND_IN_ASYNC=mode)
+        # (every receive held back by 2 ms: the scribble, posted right behind the exchange on a stream that waits for nothing, has
+        # certainly run when the bytes move - the outcome does not depend on how the race goes)
+        env = dict(os.environ, LD_PRELOAD=LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", RCCL_STAND_IN_ASYNC=mode, RCCL_STAND_IN_DELAY_US="2000")
         cmd = [sys.executable, os.path.join(ROOT, "tests", "rccl_stand_in_run.py"), "8", "2", "2", "2", "12", "dpd/fast/meso", "23",
                "debug_early_reuse=1", "expect_differ=1"]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
