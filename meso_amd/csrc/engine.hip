@@ -2164,7 +2164,7 @@ int Engine::run(int nsteps)
         // (a host-side query, no synchronisation; faults inside kernels still surface with the next synchronisation - option
         // check_launches 1 waits behind every stage of a rebuild)
         if (launch_refused) { launch_refused = false; return fail(2, "The force kernel has no form for this combination of row layout and record format"); }
-        if (hipError_t le = hipPeekAtLastError(); le != hipSuccess) {
+        if (hipError_t le = hipPeekAtLastError(); le != hipSuccess && le != hipErrorNotReady) {      // (NotReady: a stream / event query that found work in flight)
             char msg[200];
             snprintf(msg, sizeof msg, "HIP launch error at timestep %ld: %s", (long)ntimestep, hipGetErrorString(le));
             (void)hipGetLastError();
