@@ -291,6 +291,59 @@ __global__ void __launch_bounds__(64 * FL_WAVES, 5) k_pair_floor(FloorArgs a)
     }
 }
 
+// What an INCREMENTAL list build would cost at the least (profiles/r06_notes.md section 2): every atom walks a stored row
+// - here its front and back sections, 36 entries: the stand-in for the 46 of a wider previous row - gathers each candidate's 16-byte
+// record, tests it against the list cutoff and writes the row back in the same two sections, compaction and classification for free
+// (a rejected entry becomes the atom itself in place).  No index translation, no ghosts' identity, no count-in-front pass.
+__global__ void __launch_bounds__(64 * FL_WAVES, 5) k_refilter_floor(FloorArgs a, const int *__restrict__ nback, const int *__restrict__ back, int nb_col,
+                                                                     int *__restrict__ out_f, int *__restrict__ out_b, int *__restrict__ out_n, float rlist2)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int blk = fl_block(gridDim.x), i = blk * 256 + w * 64 + lane;
+    const bool mine = i < a.n;
+    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int nsec[2] = {0, 0};
+    if (mine) { c1 = a.coord4[i]; nsec[0] = a.count[i]; nsec[1] = nback[i]; }
+    const u32 nrec = (u32)min((unsigned long long)(u32)a.nall * 16ull, 0xFFFFFFFFull);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.coord4, 0, (int)nrec, 0x00020000);
+    int kept = 0;
+#pragma unroll 1
+    for (int sec = 0; sec < 2; sec++) {
+        const int pitch = sec ? nb_col : a.n_col, n = nsec[sec];
+        const int4 *rows = (const int4 *)(sec ? back : a.table) + 2 * row_word8(mine ? i : 0, 0, pitch);
+        int4 *outr = (int4 *)(sec ? out_b : out_f) + 2 * row_word8(mine ? i : 0, 0, pitch);
+        int nmax = n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+        const int nch = (n + 7) >> 3, nchmax = (__builtin_amdgcn_readfirstlane(nmax) + 7) >> 3;
+        int4 w0 = make_int4(0, 0, 0, 0), w1 = w0;
+        if (nch > 0) { w0 = rows[0]; w1 = rows[1]; }
+#pragma unroll 1
+        for (int ch = 0; ch < nchmax; ch++) {
+            const int4 v0 = w0, v1 = w1;
+            w0 = make_int4(0, 0, 0, 0); w1 = w0;
+            if (ch + 1 < nch) { w0 = rows[(size_t)(ch + 1) * 128]; w1 = rows[(size_t)(ch + 1) * 128 + 1]; }
+            int j[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            float4 c2[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) c2[q] = fl_buf_load4(rc, ch < nch ? ((u32)j[q] << 4) : 0xFFFFFFF0u);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float dx = c1.x - c2[q].x, dy = c1.y - c2[q].y, dz = c1.z - c2[q].z;
+                const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                const bool keep = (rsq <= rlist2) & (ch * 8 + q < n) & (j[q] != i);
+                kept += keep ? 1 : 0;
+                j[q] = keep ? j[q] : i;
+            }
+            if (ch < nch) {
+                outr[(size_t)ch * 128] = make_int4(j[0], j[1], j[2], j[3]);
+                outr[(size_t)ch * 128 + 1] = make_int4(j[4], j[5], j[6], j[7]);
+            }
+        }
+    }
+    if (mine) out_n[i] = kept;
+}
+
 // mode 1: arithmetic, 2: loads, 3: both; us = mean over reps launches (HIP events on the engine's stream); counts[0..1]: row entries
 // walked, pairs evaluated.  Needs a built neighbour table with rows in two sections and one
 // atom type; writes the force arrays (call it outside a run: the next setup / compute overwrites them).
@@ -303,6 +356,39 @@ int Engine::pair_floor(int mode, int reps, double *us, long *counts)
     if (mode >= 100) { local_mask = (1u << (mode / 100)) - 1u; mode %= 100; }
     int cu_map = 0;
     if (mode >= 50) { cu_map = 1; mode -= 50; }      // 50 + m: mode m with CU-local groups      // experiments: 800 + m = mode m with every gather inside a 256-atom window
+    if (mode == 8) {
+        // the least an incremental list build costs (k_refilter_floor): scratch tables of the stored tables' sizes
+        if (!is_setup || !pair_table || !pair_back || !rows_part || nlocal <= 0) return fail(3, "pair_floor 8: needs a built table with rows in two sections");
+        const int nblk = ((nlocal + 255) / 256 + 7) / 8 * 8;
+        int *of = nullptr, *ob = nullptr, *on = nullptr;
+        HIPCHK(hipMalloc(&of, table_tiles * 64 * (size_t)n_col * sizeof(int)));
+        HIPCHK(hipMalloc(&ob, table_tiles * 64 * (size_t)nb_col * sizeof(int)));
+        HIPCHK(hipMalloc(&on, (size_t)nmax * sizeof(int)));
+        FloorArgs a = {};
+        a.coord4 = coord4; a.veloc4 = veloc4; a.count = pair_count; a.table = pair_table; a.n_col = n_col; a.n = nlocal;
+        a.nall = (int)std::min<long>((long)nlocal + nghost, (1L << 28) - 1);
+        const float rl2 = (float)((cutmax + skin) * (cutmax + skin));
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_refilter_floor, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a, pair_nback, pair_back, nb_col, of, ob, on, rl2);
+        (void)hipEventRecord(e0, stream);
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_refilter_floor, dim3(nblk), dim3(64 * FL_WAVES), 0, stream, a, pair_nback, pair_back, nb_col, of, ob, on, rl2);
+        (void)hipEventRecord(e1, stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *us = 1.0e3 * (double)ms / reps;
+        if (counts) {
+            std::vector<int> hn((size_t)nlocal);
+            HIPCHK(hipMemcpy(hn.data(), on, hn.size() * sizeof(int), hipMemcpyDeviceToHost));
+            long k = 0;
+            for (int q = 0; q < nlocal; q++) k += hn[q];
+            counts[0] = k; counts[1] = 0;
+        }
+        (void)hipFree(of); (void)hipFree(ob); (void)hipFree(on);
+        return hipGetLastError() == hipSuccess ? 0 : fail(2, "pair_floor 8: launch failed");
+    }
     if (!(mode >= 1 && mode <= 3) && mode != 6 && mode != 7) return fail(1, "pair_floor: mode 1 (arithmetic), 2 (loads), 3 (both); 6 / 7: 2 / 3 with two chunks of gathers in flight");
     if (reps < 1 || !us) return fail(1, "pair_floor: invalid arguments");
     if ((local_mask || drop16 || cu_map || keep16) && mode != 2 && mode != 6) return fail(1, "pair_floor: the experiment knobs go with the loads-only modes 2 and 6");

@@ -50,6 +50,14 @@ for mode, name in ((1, "(a) arithmetic only"), (2, "(b) loads only"), (3, "(c) b
     u = res[mode]
     lines.append("%-34s %8.1f %8.1f   %.3f" % (name, u[0], u[1], b_pair / (min(u) * 1e-6) / 8e12))
 lines.append("%-34s %8.1f %8s   %.3f" % ("k_pair_dpd_ring alone (same session)", real_us, "", b_pair / (real_us * 1e-6) / 8e12))
+try:
+    us8, kept, _ = m.pair_floor(8, a.reps)
+    ms_n, calls_n = m.timer("neigh")
+    lines.append("the least an incremental list build costs - every stored row (front + back, %.1f entries per atom) walked, one gather and one"
+                 % (kept / n))
+    lines.append("list-cutoff test per entry, rows written back in place of compaction: %.1f us per pass (the bin scan: see k_tile_build in the kernel statistics)" % us8)
+except Exception as e:
+    lines.append("refilter floor skipped: %s" % e)
 out = "\n".join(lines)
 print(out)
 if a.out:
